@@ -1,0 +1,193 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own loss code (build container only).
+
+Run from the repo root:  ``python -m oracle.make_golden``
+
+/root/reference exists only in the build container; its Python never travels to
+the GPU box.  This script imports /root/reference/losses/ddpm_deletion_loss.py
+(torch-only), drives it with seeded inputs and a small deterministic stand-in
+network for ``unet``, and stores inputs + outputs as small .npz fixtures.  The
+fixtures pin oracle/loss.py and oracle/step.py (tests/test_oracle_golden.py) and,
+through them, the HIP path.
+
+The keep/forget draw (`torch.rand(B)`, ddpm_deletion_loss.py:18,:101) is made
+reproducible by patching ``torch.rand`` to hand back the recorded uniforms ``u``
+for the duration of the reference call -- the reference source is untouched.
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _ref_loss_class():
+    sys.path.insert(0, REF)
+    from losses.ddpm_deletion_loss import DDPMDeletionLoss  # noqa: E402
+    return DDPMDeletionLoss
+
+
+@contextlib.contextmanager
+def inject_uniforms(u):
+    real = torch.rand
+
+    def fake(*size, **kw):
+        n = size[0] if isinstance(size[0], int) else size[0][0]
+        assert n == u.shape[0], (size, u.shape)
+        return u.clone()
+    torch.rand = fake
+    try:
+        yield
+    finally:
+        torch.rand = real
+
+
+class RefLossWithU:
+    """Adapter: same surface, but accepts ``u=`` and injects it into the reference."""
+
+    def __init__(self, ref):
+        self.ref = ref
+
+    def __getattr__(self, name):
+        fn = getattr(self.ref, name)
+
+        def call(*a, u=None, **kw):
+            if u is None:
+                return fn(*a, **kw)
+            with inject_uniforms(u):
+                return fn(*a, **kw)
+        return call
+
+
+from oracle.toy import ToyEps  # noqa: E402
+
+
+def _np(d):
+    out = {}
+    for k, v in d.items():
+        if v is None:
+            continue
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    return out
+
+
+def loss_cases():
+    from oracle import schedule as S
+    Ref = _ref_loss_class()
+    ac = S.alphas_cumprod()
+    gamma, sigma = S.gamma_sigma(ac)
+    ref = RefLossWithU(Ref(gamma, sigma))
+    cases = {}
+    specs = [  # name, C, HW, t-mode, lambd
+        ("t999_c3_h32_l05", 3, 32, "t999", 0.5),
+        ("t999_c1_h8_l03", 1, 8, "t999", 0.3),
+        ("tuniform_c3_h8_l05", 3, 8, "uniform", 0.5),
+        ("tsmall_saturating_c3_h32_l05", 3, 32, "small", 0.5),
+        ("t999_c3_h8_l00", 3, 8, "t999", 0.0),
+        ("t999_c3_h8_l10", 3, 8, "t999", 1.0),
+        ("tmid_c1_h32_l03", 1, 32, "mid", 0.3),
+    ]
+    for i, (name, c, hw, tmode, lambd) in enumerate(specs):
+        g = torch.Generator().manual_seed(1000 + i)
+        B = 4
+        x0 = torch.rand(B, c, hw, hw, generator=g) * 2 - 1
+        a0 = (torch.rand(1, c, hw, hw, generator=g) * 2 - 1).repeat(B, 1, 1, 1)
+        noise = torch.randn(B, c, hw, hw, generator=g)
+        if tmode == "t999":
+            t = torch.full((B,), 999, dtype=torch.long)
+        elif tmode == "uniform":
+            t = torch.randint(0, 1000, (B,), generator=g)
+        elif tmode == "small":
+            t = torch.tensor([10, 3, 50, 0])
+        else:
+            t = torch.tensor([500, 400, 650, 300])
+        u = torch.rand(B, generator=g)
+        net = ToyEps(c, seed=7 + i)
+        keep = {"og_latents": x0, "noisy_latents": S.add_noise(ac, x0, noise, t)}
+        forget = {"og_latents": a0, "noisy_latents": S.add_noise(ac, a0, noise, t)}
+        out = ref.importance_sampling_with_mixture(net, t, noise, {}, keep, forget, lambd, u=u)
+        _, lx, la, iwx, iwa, wlx, wla = out
+        x_mix = torch.where((u > lambd)[:, None, None, None], keep["noisy_latents"], forget["noisy_latents"])
+        pred = net(x_mix, t)[0]
+        cases[name] = _np(dict(
+            x0=x0, a0=a0, noise=noise, t=t, u=u, lambd=lambd, net_seed=7 + i,
+            noisy_keep=keep["noisy_latents"], noisy_forget=forget["noisy_latents"],
+            x_mix=x_mix, pred=pred, loss_x=lx, loss_a=la, iw_x=iwx, iw_a=iwa,
+            weighted_loss_x=wlx, weighted_loss_a=wla))
+        # the other objectives on the same inputs (class-surface pins, a-2 / a-4)
+        o2 = ref.double_forward_with_neg_del(net, t, noise, {}, keep, forget)
+        cases[name].update(_np(dict(no_is_loss_x=o2[1], no_is_loss_a=o2[2])))
+        o3 = ref.simple_neg_del(net, t, noise, {}, keep, forget, superfactor=3.0)
+        cases[name].update(_np(dict(neg_loss=o3[0])))
+        o4 = ref.naive_del(net, t, noise, {}, keep, forget)
+        cases[name].update(_np(dict(naive_loss=o4[0])))
+        if lambd < 1.0:   # the reference raises ZeroDivisionError at lambd == 1 (:110)
+            o5 = ref.subscore_bernoulli(net, t, noise, {}, keep, forget, lambd, u=u)
+            cases[name].update(_np(dict(bern_loss_x=o5[1], bern_loss_a=o5[2])))
+    return cases
+
+
+def step_cases():
+    from oracle import schedule as S
+    from oracle.step import unlearning_step
+    Ref = _ref_loss_class()
+    ac = S.alphas_cumprod()
+    gamma, sigma = S.gamma_sigma(ac)
+    ref = RefLossWithU(Ref(gamma, sigma))
+    cases = {}
+    for name, loss_fn, ga, tmode in [
+            ("siss_step_ga1", "importance_sampling_with_mixture", 1, "t999"),
+            ("siss_step_ga2", "importance_sampling_with_mixture", 2, "t999"),
+            ("siss_step_tuniform", "importance_sampling_with_mixture", 1, "uniform"),
+            ("no_is_step", "double_forward_with_neg_del", 1, "t999")]:
+        g = torch.Generator().manual_seed(4242 + ga + len(name))
+        B, c, hw = 4, 3, 8
+        net = ToyEps(c, seed=11)
+        opt = torch.optim.AdamW(net.parameters(), lr=5e-3, betas=(0.95, 0.999),
+                                weight_decay=1e-6, eps=1e-8)
+        rec = {"lambd": 0.5, "scaling_norm": 5.0, "ga": ga, "lr": 5e-3, "net_seed": 11}
+        for step in range(2):
+            mbs = []
+            for k in range(ga):
+                x0 = torch.rand(B, c, hw, hw, generator=g) * 2 - 1
+                a0 = (torch.rand(1, c, hw, hw, generator=g) * 2 - 1).repeat(B, 1, 1, 1)
+                noise = torch.randn(B, c, hw, hw, generator=g)
+                t = (torch.full((B,), 999, dtype=torch.long) if tmode == "t999"
+                     else torch.randint(0, 1000, (B,), generator=g))
+                u = torch.rand(B, generator=g)
+                mbs.append(dict(x0=x0, a0=a0, noise=noise, t=t, u=u))
+                for kk, vv in mbs[-1].items():
+                    rec[f"s{step}_m{k}_{kk}"] = vv
+            lp = {"lambd": 0.5} if "mixture" in loss_fn else {}
+            st, gx, ga_, gfin = unlearning_step(
+                net, opt, ref, loss_fn, ac, mbs, train_batch_size=B, scaling_norm=5.0,
+                loss_params=lp)
+            rec[f"s{step}_stats"] = np.array([st.norm_loss_x, st.norm_loss_a, st.scaling_factor,
+                                              st.pre_clip_norm, st.weighted_loss_x, st.weighted_loss_a])
+            for n in gx:
+                rec[f"s{step}_gx/{n}"] = gx[n]
+                rec[f"s{step}_ga/{n}"] = ga_[n]
+                rec[f"s{step}_g/{n}"] = gfin[n]
+            for n, p in net.named_parameters():
+                rec[f"s{step}_param/{n}"] = p.detach().clone()
+        cases[name] = _np(rec)
+    return cases
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, rec in loss_cases().items():
+        np.savez_compressed(os.path.join(OUT, f"siss_loss_{name}.npz"), **rec)
+    for name, rec in step_cases().items():
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
