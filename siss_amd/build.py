@@ -1,0 +1,62 @@
+"""Build libsiss_hip.so (all HIP kernels + the C-ABI) for gfx950 with hipcc, in-tree.
+
+    python -m siss_amd.build          # incremental
+    python -m siss_amd.build --force
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libsiss_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(dst, srcs):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    jobs = []
+    objs = []
+    for f in sources():
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append(["hipcc", *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+        return cmd[-1]
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            for done in ex.map(run, jobs):
+                if verbose:
+                    print("compiled", os.path.basename(done))
+    if force or jobs or _stale(LIB, objs):
+        run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+        if verbose:
+            print("linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

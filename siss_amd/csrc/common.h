@@ -1,0 +1,59 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // storage type for bf16 in global memory / C-ABI signatures
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define SISS_OK 0
+#define SISS_ERR_ARG 1
+#define SISS_ERR_LAUNCH 2
+
+#define SISS_CHECK_ARG(cond) \
+    do {                     \
+        if (!(cond)) return SISS_ERR_ARG; \
+    } while (0)
+
+#define SISS_LAUNCH_RET()                                 \
+    do {                                                  \
+        return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH; \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) {
+    return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+// d/dz [z * sigmoid(z)]
+__device__ __forceinline__ float dsilu_f(float z) {
+    float s = 1.f / (1.f + __expf(-z));
+    return s * (1.f + z * (1.f - s));
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,213 @@
+// conv_out (Cout = in/out image channels, 1..4): 3x3 convolution with a tiny output-channel
+// count.  N = 3 would waste 97 % of a 128-wide MFMA tile, and the op is HBM-bound anyway
+// (it reads a C=128 activation to produce 3 channels), so these are direct VALU kernels:
+//   fprop : padded NHWC bf16 [B][H+2][W+2][C]  -> pred NCHW f32 [B][CO][H][W]
+//   dgrad : cotangent NCHW f32 [N2][CO][H][W]  -> dX padded NHWC bf16 [N2][..][C]
+//   wgrad : dW[set][tap][co][ci] += sum c * x ;  dbias[set][co] += sum c
+// Weight layout: native [9][CO][C] f32 (tap = ky*3+kx).  C/8 lanes cover one pixel row
+// (16 B per lane, coalesced); partial dot products are folded with wave shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ void unpack8(u32x4_t r, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = __builtin_bit_cast(float, r[j] << 16);
+        v[2 * j + 1] = __builtin_bit_cast(float, r[j] & 0xffff0000u);
+    }
+}
+
+template <int CO>
+__global__ __launch_bounds__(kThreads) void conv_out_fprop_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ pred, int B, int H, int W, int C) {
+    extern __shared__ float shw[];   // [9][CO][C]
+    for (int i = threadIdx.x; i < 9 * CO * C; i += kThreads) shw[i] = w[i];
+    __syncthreads();
+    const int lpp = C / 8, ppb = kThreads / lpp;
+    const int slot = threadIdx.x / lpp, cc = threadIdx.x - slot * lpp;
+    const long npix = (long)B * H * W;
+    const int Wp = W + 2;
+    for (long pbase = (long)blockIdx.x * ppb; pbase < npix; pbase += (long)gridDim.x * ppb) {
+        const long p = pbase + slot;
+        const bool ok = p < npix;
+        const long pc = ok ? p : npix - 1;
+        const int xx = pc % W; long t = pc / W;
+        const int yy = t % H; const int n = t / H;
+        const long row = ((long)n * (H + 2) + yy + 1) * Wp + xx + 1;
+        float acc[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const long r = row + (tap / 3 - 1) * Wp + (tap % 3 - 1);
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(x + r * C + cc * 8), v);
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                const float* ww = shw + (tap * CO + o) * C + cc * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o] += v[e] * ww[e];
+            }
+        }
+        for (int off = lpp >> 1; off > 0; off >>= 1)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) acc[o] += __shfl_xor(acc[o], off, 64);
+        if (ok && cc == 0) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) pred[(((long)n * CO + o) * H + yy) * W + xx] = acc[o] + bias[o];
+        }
+    }
+}
+
+template <int CO>
+__global__ __launch_bounds__(kThreads) void conv_out_dgrad_kernel(
+    const float* __restrict__ c, const float* __restrict__ w, bf16_t* __restrict__ dx, int N2, int H, int W,
+    int C) {
+    extern __shared__ float shw[];   // [9][CO][C]
+    for (int i = threadIdx.x; i < 9 * CO * C; i += kThreads) shw[i] = w[i];
+    __syncthreads();
+    const int lpp = C / 8;
+    const long total = (long)N2 * H * W * lpp;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const int cc = i % lpp; long t = i / lpp;
+        const int xx = t % W; t /= W;
+        const int yy = t % H; const int n = t / H;
+        float acc[8] = {};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // x[y,x] feeds out[y - (ky-1), x - (kx-1)] through tap (ky,kx)
+            const int oy = yy - (tap / 3 - 1), ox = xx - (tap % 3 - 1);
+            if (oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                const float g = c[(((long)n * CO + o) * H + oy) * W + ox];
+                const float* ww = shw + (tap * CO + o) * C + cc * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += g * ww[e];
+            }
+        }
+        const long row = ((long)n * (H + 2) + yy + 1) * (W + 2) + xx + 1;
+        *reinterpret_cast<u32x4_t*>(dx + row * C + cc * 8) =
+            u32x4_t{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7])};
+    }
+}
+
+// grid: (blocks, 3 (ky), nsets).  Each lane keeps acc[CO][3 kx][8 ch].
+template <int CO>
+__global__ __launch_bounds__(kThreads) void conv_out_wgrad_kernel(
+    const float* __restrict__ c, const bf16_t* __restrict__ x, float* __restrict__ dW, float* __restrict__ dbias,
+    int set_images, int nx, long set_stride_w, long set_stride_b, int H, int W, int C) {
+    extern __shared__ float sh[];   // [3][CO][C] + CO
+    const int ky = blockIdx.y, set = blockIdx.z;
+    for (int i = threadIdx.x; i < 3 * CO * C + CO; i += kThreads) sh[i] = 0.f;
+    __syncthreads();
+    const int lpp = C / 8, ppb = kThreads / lpp;
+    const int slot = threadIdx.x / lpp, cc = threadIdx.x - slot * lpp;
+    const long npix = (long)set_images * H * W;
+    const int Wp = W + 2;
+    float acc[CO][3][8];
+    float bsum[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        bsum[o] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][k][e] = 0.f;
+    }
+    if (slot < ppb)
+        for (long p = (long)blockIdx.x * ppb + slot; p < npix; p += (long)gridDim.x * ppb) {
+            const int xx = p % W; long t = p / W;
+            const int yy = t % H; const int nl = t / H;
+            const int n2 = set * set_images + nl, n = n2 % nx;
+            float g[CO];
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                g[o] = c[(((long)n2 * CO + o) * H + yy) * W + xx];
+                if (cc == 0 && ky == 0) bsum[o] += g[o];
+            }
+            const long row = ((long)n * (H + 2) + yy + 1 + (ky - 1)) * Wp + xx + 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float v[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(x + (row + kx - 1) * C + cc * 8), v);
+#pragma unroll
+                for (int o = 0; o < CO; ++o)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o][kx][e] += g[o] * v[e];
+            }
+        }
+    if (slot < ppb) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(&sh[(kx * CO + o) * C + cc * 8 + e], acc[o][kx][e]);
+            if (cc == 0 && ky == 0) atomicAdd(&sh[3 * CO * C + o], bsum[o]);
+        }
+    }
+    __syncthreads();
+    float* out = dW + (long)set * set_stride_w + (long)(ky * 3) * CO * C;
+    for (int i = threadIdx.x; i < 3 * CO * C; i += kThreads) atomicAdd(out + i, sh[i]);
+    if (ky == 0 && threadIdx.x < CO) atomicAdd(dbias + (long)set * set_stride_b + threadIdx.x, sh[3 * CO * C + threadIdx.x]);
+}
+
+inline bool lpp_ok(int C) {
+    if (C % 8) return false;
+    const int l = C / 8;
+    return l >= 1 && l <= 64 && (l & (l - 1)) == 0;
+}
+
+}  // namespace
+
+#define DISPATCH_CO(CO, CALL) \
+    switch (CO) {             \
+        case 1: { constexpr int kCO = 1; CALL; } break; \
+        case 2: { constexpr int kCO = 2; CALL; } break; \
+        case 3: { constexpr int kCO = 3; CALL; } break; \
+        case 4: { constexpr int kCO = 4; CALL; } break; \
+        default: return SISS_ERR_ARG; \
+    }
+
+extern "C" {
+
+int siss_conv_out_fprop(const void* x, const float* w, const float* bias, float* pred, int B, int H, int W, int C,
+                        int CO, void* stream) {
+    SISS_CHECK_ARG(x && w && bias && pred && B > 0 && H > 0 && W > 0 && lpp_ok(C));
+    const int ppb = kThreads / (C / 8);
+    long nb = ((long)B * H * W + ppb - 1) / ppb;
+    if (nb > 4096) nb = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_CO(CO, (conv_out_fprop_kernel<kCO><<<(int)nb, kThreads, 9 * kCO * C * sizeof(float), st>>>((const bf16_t*)x, w, bias, pred, B, H, W, C)));
+    SISS_LAUNCH_RET();
+}
+
+int siss_conv_out_dgrad(const float* c, const float* w, void* dx, int N2, int H, int W, int C, int CO, void* stream) {
+    SISS_CHECK_ARG(c && w && dx && N2 > 0 && H > 0 && W > 0 && C % 8 == 0);
+    long nb = ((long)N2 * H * W * (C / 8) + kThreads - 1) / kThreads;
+    if (nb > 8192) nb = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_CO(CO, (conv_out_dgrad_kernel<kCO><<<(int)nb, kThreads, 9 * kCO * C * sizeof(float), st>>>(c, w, (bf16_t*)dx, N2, H, W, C)));
+    SISS_LAUNCH_RET();
+}
+
+// c: [nsets*set_images][CO][H][W] f32 cotangent; x: saved conv_out input (nx images, index n2 % nx).
+int siss_conv_out_wgrad(const float* c, const void* x, float* dW, float* dbias, int nsets, int set_images, int nx,
+                        long set_stride_w, long set_stride_b, int H, int W, int C, int CO, void* stream) {
+    SISS_CHECK_ARG(c && x && dW && dbias && nsets > 0 && set_images > 0 && nx > 0 && lpp_ok(C));
+    const int ppb = kThreads / (C / 8);
+    long nb = ((long)set_images * H * W + (long)ppb * 64 - 1) / ((long)ppb * 64);
+    if (nb < 1) nb = 1;
+    if (nb > 256) nb = 256;
+    dim3 grid((int)nb, 3, nsets);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_CO(CO, (conv_out_wgrad_kernel<kCO><<<grid, kThreads, (3 * kCO * C + kCO) * sizeof(float), st>>>(c, (const bf16_t*)x, dW, dbias, set_images, nx, set_stride_w, set_stride_b, H, W, C)));
+    SISS_LAUNCH_RET();
+}
+
+}  // extern "C"

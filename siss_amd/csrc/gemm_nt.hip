@@ -1,0 +1,249 @@
+// Panelled NT GEMM on bf16 MFMA: the conv3x3 / conv1x1 / linear fprop and dgrad kernel
+// (SURVEY.md §2b K2-K4, K7 projections).
+//
+//   C[r, n] = alpha * sum_p sum_k A[r + shift_p, coff_p + k] * W[p][n][k]  (+ bias[n] + rowbias[img(r)][n] + R[r, n])
+//
+// Activations are NHWC with a one-pixel zero halo, flattened to rows r = (img, y, x) of C
+// contiguous channels.  In that flat space a 3x3 convolution is nine row-shifted GEMM panels
+// (shift = (ky-1)*(W+2) + (kx-1)): no im2col, no per-pixel bounds checks -- zero padding comes
+// from the halo rows, which every producer keeps at zero (this kernel writes zeros there).
+// dgrad is the same kernel with negated shifts and the [tap][ci][co] weight copy.
+//
+// Tiling (gfx950): 128x128 output tile, BK = 64, 256 threads = 4 waves (2x2), each wave a
+// 64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 accumulators.  Both operands are K-contiguous
+// rows, staged global->LDS by global_load_lds_dwordx4 (16 B/lane, 8 rows x 128 B per
+// wave-instruction) into a double buffer.  LDS rows are 128 B; the 16-B chunk index is XORed
+// with (row>>1)&7 -- applied on the per-lane SOURCE address (the DMA destination is
+// lane-linear) and again on the ds_read_b128 address -- which makes every 16-lane read group
+// hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+// The MFMA takes the weight fragment as its A operand so that each lane ends up with four
+// CONSECUTIVE output channels of one pixel: the epilogue stages f32 through LDS (528-B padded
+// rows) and writes 16-B coalesced bf16 rows.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kThreads = 256;
+constexpr int kStageBytes = (BM + BN) * BK * 2;          // 32 KiB per stage
+constexpr int kCRow = BN * 4 + 16;                       // f32 epilogue row, padded (bank spread)
+constexpr int kSmemBytes = (2 * kStageBytes > BM * kCRow) ? 2 * kStageBytes : BM * kCRow;
+constexpr int kMaxPanels = 9;
+
+struct NTParams {
+    const bf16_t* A; const bf16_t* W; bf16_t* C;
+    const float* bias; const float* rowbias; const bf16_t* R;
+    long lda, ldc, ldr;
+    long strideA, strideW, strideC;   // per blockIdx.z batch (elements)
+    int M, N, Kp, npanels;
+    int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
+    float alpha;
+    int shift[kMaxPanels];
+    int coff[kMaxPanels];
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+
+    // XCD-aware tile order: blocks b, b+8, ... share an L2; give each XCD a contiguous run of
+    // tiles (n-tiles of one m-tile adjacent) so shifted A panels and weights hit in L2.
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int bz = blockIdx.z;
+    const bf16_t* A = p.A + (long)bz * p.strideA;
+    const bf16_t* W = p.W + (long)bz * p.strideW;
+
+    // per-lane staging sources: 4 pieces of 8 rows for A and for W
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = w * 32 + j * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
+        int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+        asrc[j] = A + (long)gr * p.lda + lc * 8;
+        wsrc[j] = W + (long)gn * p.Kp + lc * 8;
+    }
+    const int kchunks = p.Kp / BK;
+    const int steps = p.npanels * kchunks;
+    const long wpanel = (long)p.N * p.Kp;
+
+    auto stage = [&](int buf, int step) {
+        const int pn = step / kchunks, kc = step - pn * kchunks;
+        const long aoff = (long)p.shift[pn] * p.lda + p.coff[pn] + kc * BK;
+        const long woff = pn * wpanel + kc * BK;
+        char* base = smem + buf * kStageBytes + (w * 32) * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(asrc[j] + aoff, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(wsrc[j] + woff, base + BM * 128 + j * 1024);
+    };
+
+    f32x4_t acc[4][4];   // [n-tile][m-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes within a stage), kk = 0; kk = 1 flips chunk bit 2
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[4], w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + frow;
+        a_off[i] = ra * 128 + ((fq ^ ((ra >> 1) & 7)) << 4);
+        const int rw = wn * 64 + i * 16 + frow;
+        w_off[i] = BM * 128 + rw * 128 + ((fq ^ ((rw >> 1) & 7)) << 4);
+    }
+
+    stage(0, 0);
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) {
+            stage(buf ^ 1, s + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // step s landed; s+1 stays in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* sb = smem + buf * kStageBytes;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sb + (a_off[i] ^ (kk << 6)));
+                wf[i] = *reinterpret_cast<const bf16x8_t*>(sb + (w_off[i] ^ (kk << 6)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();   // everyone done reading buf before it is restaged
+    }
+
+    // ---- epilogue: f32 through LDS, then coalesced bf16 rows ----
+    // acc[i][j][r]: channel n = wn*64 + i*16 + fq*4 + r, pixel m = wm*64 + j*16 + frow
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = wm * 64 + j * 16 + frow, n = wn * 64 + i * 16 + fq * 4;
+            f32x4_t v = acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            *reinterpret_cast<f32x4_t*>(smem + m * kCRow + n * 4) = v;
+        }
+    __syncthreads();
+    bf16_t* C = p.C + (long)bz * p.strideC;
+    const int chunk = tid & 15;           // 8 channels per chunk
+    const int nc = n0 + chunk * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && nc + e < p.N) ? p.bias[nc + e] : 0.f;
+    const int rpi = p.rows_per_image;
+#pragma unroll 2
+    for (int it = 0; it < BM / 16; ++it) {
+        const int row = it * 16 + (tid >> 4);
+        const int r = m0 + row;
+        if (r >= p.M || nc >= p.N) continue;
+        bool halo = false;
+        if (p.Hp > 0) {
+            const int rem = r % rpi, y = rem / p.Wp, x = rem - y * p.Wp;
+            halo = (y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1);
+        }
+        float v[8];
+        if (halo) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        } else {
+            const f32x4_t* src = reinterpret_cast<const f32x4_t*>(smem + row * kCRow + chunk * 32);
+            f32x4_t lo = src[0], hi = src[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
+            if (p.rowbias) {
+                const float* rb = p.rowbias + (long)(r / rpi) * p.N + nc;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (nc + e < p.N) v[e] += rb[e];
+            }
+            if (p.R) {
+                if (nc + 8 <= p.N) {
+                    u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __builtin_bit_cast(float, rr[e] << 16);
+                        v[2 * e + 1] += __builtin_bit_cast(float, rr[e] & 0xffff0000u);
+                    }
+                } else {
+                    for (int e = 0; e < 8 && nc + e < p.N; ++e) v[e] += bf2f(p.R[(long)bz * p.strideC + (long)r * p.ldr + nc + e]);
+                }
+            }
+        }
+        bf16_t* dst = C + (long)r * p.ldc + nc;
+        if (nc + 8 <= p.N) {
+            *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]),
+                                                        pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+        } else {
+            for (int e = 0; e < 8 && nc + e < p.N; ++e) dst[e] = f2bf(v[e]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Flat argument list (ctypes-friendly).  shifts/coffs are HOST arrays of npanels ints.
+// Returns SISS_ERR_ARG for shapes the kernel does not cover (Kp % 64, alignment, panel count).
+int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+                 const float* rowbias, const void* R, long ldr, int M, int N, int Kp, int npanels,
+                 const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
+                 int batch, long strideA, long strideW, long strideC, void* stream) {
+    SISS_CHECK_ARG(A && W && C && shifts && coffs);
+    SISS_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % BK == 0 && npanels >= 1 && npanels <= kMaxPanels);
+    SISS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0) && batch >= 1);
+    SISS_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)R) % 16 == 0);
+    SISS_CHECK_ARG(strideA % 8 == 0 && strideW % 8 == 0 && strideC % 8 == 0);
+    SISS_CHECK_ARG(rows_per_image > 0 && (Hp == 0 || (long)Hp * Wp == rows_per_image));
+    NTParams p;
+    p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = (bf16_t*)C;
+    p.bias = bias; p.rowbias = rowbias; p.R = (const bf16_t*)R;
+    p.lda = lda; p.ldc = ldc; p.ldr = ldr;
+    p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
+    p.M = M; p.N = N; p.Kp = Kp; p.npanels = npanels;
+    p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
+    for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
+    for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
+            return SISS_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    dim3 grid(tiles, 1, batch);
+    gemm_nt_kernel<<<grid, kThreads, kSmemBytes, (hipStream_t)stream>>>(p);
+    SISS_LAUNCH_RET();
+}
+
+}  // extern "C"

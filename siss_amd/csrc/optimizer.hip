@@ -1,0 +1,209 @@
+// Flat-buffer gradient bookkeeping + AdamW.
+//
+// Reference semantics: delete_celeb.py:714-753 (||g_x||, ||g_a||, s = scaling_norm/||g_a||,
+// g = g_x - s*g_a), :767 (clip_grad_norm_ 1.0) and :769 (torch.optim.AdamW.step).
+// The reference walks 450 tensors five times (~2,250 launches, 3 clones); here parameters
+// and both gradient sets live in ONE flat buffer each, so the whole block is two
+// streaming passes:
+//   pass 1  reads g_x, g_a                      -> ||g_x||^2, ||g_a||^2, <g_x,g_a>  (f64 slabs)
+//   pass 2  reads g_x, g_a, p, m, v; writes p, m, v (+ bf16 shadow of p)
+// ||g||^2 = ||g_x||^2 - 2 s <g_x,g_a> + s^2 ||g_a||^2 is formed from the f64 sums, so the clip
+// coefficient needs no third pass.  All scalars (s, clip, step count) stay on the device:
+// no host sync, and the launches replay correctly from a hipGraph.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;
+
+struct StepScalars {   // lives in device memory; 16 floats
+    float norm_x, norm_a, dot, scale;      // 0..3  (scale = s in g = g_x - s*g_a)
+    float pre_clip_norm, clip_coef, step, pad0;  // 4..7
+    float bc1, bc2_sqrt, pad1, pad2;       // 8..11
+    float pad3[4];
+};
+
+__global__ __launch_bounds__(kThreads) void norms_kernel(const float* __restrict__ gx,
+                                                         const float* __restrict__ ga, long n,
+                                                         double* __restrict__ partials) {
+    __shared__ double sh[3 * kThreads / 64];
+    double sxx = 0, saa = 0, sxa = 0;
+    const long nvec = n / 4;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (long)gridDim.x * kThreads) {
+        f32x4_t x = reinterpret_cast<const f32x4_t*>(gx)[i];
+        f32x4_t a = reinterpret_cast<const f32x4_t*>(ga)[i];
+        float pxx = 0, paa = 0, pxa = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pxx += x[j] * x[j]; paa += a[j] * a[j]; pxa += x[j] * a[j]; }
+        sxx += pxx; saa += paa; sxa += pxa;
+    }
+    if (blockIdx.x == 0)
+        for (long i = nvec * 4 + threadIdx.x; i < n; i += kThreads) {
+            sxx += (double)gx[i] * gx[i]; saa += (double)ga[i] * ga[i]; sxa += (double)gx[i] * ga[i];
+        }
+    sxx = wave_sum_d(sxx); saa = wave_sum_d(saa); sxa = wave_sum_d(sxa);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[3 * w] = sxx; sh[3 * w + 1] = saa; sh[3 * w + 2] = sxa; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0, b = 0, c = 0;
+        for (int i = 0; i < kThreads / 64; ++i) { a += sh[3 * i]; b += sh[3 * i + 1]; c += sh[3 * i + 2]; }
+        partials[3 * blockIdx.x] = a; partials[3 * blockIdx.x + 1] = b; partials[3 * blockIdx.x + 2] = c;
+    }
+}
+
+// mode 0: norm fixing  s = scaling_norm / ||g_a||        (delete_celeb.py:746)
+// mode 1: erasediff    s = -max(eta - <gx,ga>/||ga||^2, 0) (:740-742)
+// mode 2: like 0 but s = 0 when it would be inf          (delete_tshirt.py:688-690)
+__global__ void scalars_kernel(const double* __restrict__ partials, int nblk, int mode, float knob,
+                               float max_norm, float beta1, float beta2, StepScalars* __restrict__ sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double xx = 0, aa = 0, xa = 0;
+    for (int i = 0; i < nblk; ++i) { xx += partials[3 * i]; aa += partials[3 * i + 1]; xa += partials[3 * i + 2]; }
+    const double nx = sqrt(xx), na = sqrt(aa);
+    double s;
+    if (mode == 1) {
+        s = (double)knob - xa / aa;
+        s = -(s > 0 ? s : 0);
+    } else {
+        s = (double)knob / na;
+        if (mode == 2 && isinf(s)) s = 0;
+    }
+    double g2 = xx - 2 * s * xa + s * s * aa;
+    if (g2 < 0) g2 = 0;
+    const double gn = sqrt(g2);
+    double coef = (double)max_norm / (gn + 1e-6);   // torch.nn.utils.clip_grad_norm_
+    if (coef > 1) coef = 1;
+    const float step = sc->step + 1.f;
+    sc->norm_x = (float)nx; sc->norm_a = (float)na; sc->dot = (float)xa; sc->scale = (float)s;
+    sc->pre_clip_norm = (float)gn; sc->clip_coef = (float)coef; sc->step = step;
+    sc->bc1 = 1.f - powf(beta1, step);
+    sc->bc2_sqrt = sqrtf(1.f - powf(beta2, step));
+}
+
+// pass 2: g = clip * (g_x - s g_a); torch.optim.AdamW single-tensor update order.
+__global__ __launch_bounds__(kThreads) void recombine_adamw_kernel(
+    const float* __restrict__ gx, const float* __restrict__ ga, float* __restrict__ p,
+    float* __restrict__ m, float* __restrict__ v, bf16_t* __restrict__ shadow,
+    float* __restrict__ g_out, long n, float lr, float beta1, float beta2, float eps, float wd,
+    const StepScalars* __restrict__ sc) {
+    const float s = sc->scale, clip = sc->clip_coef, bc1 = sc->bc1, bc2s = sc->bc2_sqrt;
+    const float step_size = lr / bc1;
+    const float decay = 1.f - lr * wd;
+    const long nvec = n / 4;
+    auto upd = [&](float x, float a, float& pp, float& mm, float& vv) -> float {
+        const float g = __fmul_rn(__fsub_rn(x, __fmul_rn(s, a)), clip);
+        pp = __fmul_rn(pp, decay);
+        mm = __fadd_rn(mm, __fmul_rn(__fsub_rn(g, mm), 1.f - beta1));           // lerp
+        vv = __fadd_rn(__fmul_rn(vv, beta2), __fmul_rn(__fmul_rn(g, g), 1.f - beta2));
+        const float den = __fadd_rn(sqrtf(vv) / bc2s, eps);
+        pp = __fsub_rn(pp, __fmul_rn(step_size, mm / den));
+        return g;
+    };
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (long)gridDim.x * kThreads) {
+        f32x4_t x = reinterpret_cast<const f32x4_t*>(gx)[i], a = reinterpret_cast<const f32x4_t*>(ga)[i];
+        f32x4_t pp = reinterpret_cast<f32x4_t*>(p)[i], mm = reinterpret_cast<f32x4_t*>(m)[i],
+                vv = reinterpret_cast<f32x4_t*>(v)[i], gg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float P = pp[j], M = mm[j], V = vv[j]; gg[j] = upd(x[j], a[j], P, M, V); pp[j] = P; mm[j] = M; vv[j] = V; }
+        reinterpret_cast<f32x4_t*>(p)[i] = pp;
+        reinterpret_cast<f32x4_t*>(m)[i] = mm;
+        reinterpret_cast<f32x4_t*>(v)[i] = vv;
+        if (g_out) reinterpret_cast<f32x4_t*>(g_out)[i] = gg;
+        if (shadow) reinterpret_cast<u32x2_t*>(shadow)[i] = u32x2_t{pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3])};
+    }
+    if (blockIdx.x == 0)
+        for (long i = nvec * 4 + threadIdx.x; i < n; i += kThreads) {
+            float P = p[i], M = m[i], V = v[i];
+            const float g = upd(gx[i], ga[i], P, M, V);
+            p[i] = P; m[i] = M; v[i] = V;
+            if (g_out) g_out[i] = g;
+            if (shadow) shadow[i] = f2bf(P);
+        }
+}
+
+__global__ __launch_bounds__(kThreads) void cast_bf16_kernel(const float* __restrict__ src,
+                                                             bf16_t* __restrict__ dst, long n) {
+    const long nvec = n / 4;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (long)gridDim.x * kThreads) {
+        f32x4_t x = reinterpret_cast<const f32x4_t*>(src)[i];
+        reinterpret_cast<u32x2_t*>(dst)[i] = u32x2_t{pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+    }
+    if (blockIdx.x == 0)
+        for (long i = nvec * 4 + threadIdx.x; i < n; i += kThreads) dst[i] = f2bf(src[i]);
+}
+
+// [taps][co][ci] f32 master -> [taps][ci][co] bf16 with the tap order reversed (dgrad operand).
+__global__ void conv_weight_dgrad_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int taps,
+                                         int co, int ci) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const float* src = w + (long)tap * co * ci;
+    bf16_t* dst = wt + (long)(taps - 1 - tap) * co * ci;
+    const int c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int o = o0 + r, c = c0 + threadIdx.x;
+        tile[r][threadIdx.x] = (o < co && c < ci) ? src[(long)o * ci + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int c = c0 + r, o = o0 + threadIdx.x;
+        if (c < ci && o < co) dst[(long)c * co + o] = f2bf(tile[threadIdx.x][r]);
+    }
+}
+
+inline int grid_for(long n) {
+    long b = (n / 4 + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+long siss_opt_partials_words(void) { return 3L * kMaxBlocks; }
+long siss_opt_scalars_words(void) { return sizeof(StepScalars) / sizeof(float); }
+
+// pass 1 + on-device scalars.  `scalars` (16 floats, zero-initialised once; holds the step count).
+int siss_grad_norms_scale(const float* gx, const float* ga, long n, int mode, float knob, float max_norm,
+                          float beta1, float beta2, double* partials, float* scalars, void* stream) {
+    SISS_CHECK_ARG(gx && ga && partials && scalars && n > 0 && mode >= 0 && mode <= 2);
+    SISS_CHECK_ARG(((uintptr_t)gx | (uintptr_t)ga) % 16 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = grid_for(n);
+    norms_kernel<<<nblk, kThreads, 0, s>>>(gx, ga, n, partials);
+    scalars_kernel<<<1, 64, 0, s>>>(partials, nblk, mode, knob, max_norm, beta1, beta2,
+                                    reinterpret_cast<StepScalars*>(scalars));
+    SISS_LAUNCH_RET();
+}
+
+// pass 2.  shadow (bf16 copy of the updated parameters) and g_out (final clipped gradient) are optional.
+int siss_recombine_clip_adamw(const float* gx, const float* ga, float* p, float* m, float* v, void* shadow,
+                              float* g_out, long n, float lr, float beta1, float beta2, float eps, float wd,
+                              const float* scalars, void* stream) {
+    SISS_CHECK_ARG(gx && ga && p && m && v && scalars && n > 0);
+    SISS_CHECK_ARG(((uintptr_t)gx | (uintptr_t)ga | (uintptr_t)p | (uintptr_t)m | (uintptr_t)v) % 16 == 0);
+    SISS_CHECK_ARG(!shadow || (uintptr_t)shadow % 8 == 0);
+    recombine_adamw_kernel<<<grid_for(n), kThreads, 0, (hipStream_t)stream>>>(
+        gx, ga, p, m, v, reinterpret_cast<bf16_t*>(shadow), g_out, n, lr, beta1, beta2, eps, wd,
+        reinterpret_cast<const StepScalars*>(scalars));
+    SISS_LAUNCH_RET();
+}
+
+int siss_cast_f32_bf16(const float* src, void* dst, long n, void* stream) {
+    SISS_CHECK_ARG(src && dst && n > 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0);
+    cast_bf16_kernel<<<grid_for(n), kThreads, 0, (hipStream_t)stream>>>(src, reinterpret_cast<bf16_t*>(dst), n);
+    SISS_LAUNCH_RET();
+}
+
+int siss_conv_weight_dgrad_layout(const float* w, void* wt, int taps, int co, int ci, void* stream) {
+    SISS_CHECK_ARG(w && wt && taps > 0 && co > 0 && ci > 0);
+    dim3 grid(cdiv(ci, 32), cdiv(co, 32), taps), block(32, 8);
+    conv_weight_dgrad_kernel<<<grid, block, 0, (hipStream_t)stream>>>(w, reinterpret_cast<bf16_t*>(wt), taps, co, ci);
+    SISS_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+"""ctypes binding of libsiss_hip.so -- the C-ABI declared in include/siss_hip.h.
+
+The product path has NO CPU fallback: if the library is missing or a launcher returns a
+non-zero status, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsiss_hip.so")
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+IP = C.POINTER(C.c_int)
+
+# name -> argtypes (all launchers return int status unless listed in _RET_LONG)
+SIGNATURES = {
+    "siss_loss_partials_words": [I, L],
+    "siss_mixture_fwd": [P, P, P, I, P, P, P, P, P, F, I, L, P, P, P, P, P, P, P, P, P],
+    "siss_loss_bwd_seed": [P, P, P, P, I, P, P, P, P, F, I, L, P, P, P, P, P, P, P, P],
+    "siss_mse_bwd_seed": [P, P, I, F, I, L, P, P, P, P, P],
+    "siss_opt_partials_words": [],
+    "siss_opt_scalars_words": [],
+    "siss_grad_norms_scale": [P, P, L, I, F, F, F, F, P, P, P],
+    "siss_recombine_clip_adamw": [P, P, P, P, P, P, P, L, F, F, F, F, F, P, P],
+    "siss_cast_f32_bf16": [P, P, L, P],
+    "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],
+    "siss_gemm_nt": [P, L, P, P, L, P, P, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
+    "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P],
+}
+_RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words"}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m siss_amd.build` "
+            "(there is no CPU fallback for the SISS hot path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_long if name in _RET_LONG else C.c_int
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor; None -> NULL."""
+    if t is None:
+        return None
+    if torch.is_tensor(t):
+        return C.c_void_p(t.data_ptr())
+    return t
+
+
+def int_array(xs):
+    return (C.c_int * len(xs))(*xs)
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Call a launcher on torch's current stream; tensors are passed as raw pointers."""
+    lib = load()
+    fn = getattr(lib, name)
+    conv = [ptr(a) if (torch.is_tensor(a) or a is None) else a for a in args]
+    rc = fn(*conv, stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with status {rc} "
+                           f"({'bad argument' if rc == 1 else 'launch error'})")
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)

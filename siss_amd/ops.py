@@ -1,0 +1,109 @@
+"""Thin Python launch wrappers over the C-ABI (raw device pointers on torch's current stream).
+
+Native parameter layouts (what the flat master buffer holds):
+  conv3x3 weight  [9][Cout][Cin]   (tap = ky*3+kx; the reference/diffusers layout is [Cout][Cin][3][3])
+  conv1x1 / linear weight [Cout][Cin]
+"""
+import torch
+
+from . import lib
+from .layout import Act, conv3x3_panels
+
+_ZERO = {}
+
+
+def zero_page(device):
+    z = _ZERO.get(device)
+    if z is None:
+        z = torch.zeros(4096, dtype=torch.bfloat16, device=device)
+        _ZERO[device] = z
+    return z
+
+
+# ---------------------------------------------------------------- weight layout helpers
+def conv_w_to_native(w):
+    """[Co, Ci, kh, kw] -> [kh*kw, Co, Ci]"""
+    co, ci, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci).contiguous()
+
+
+def conv_w_from_native(wn, kh=3, kw=3):
+    t, co, ci = wn.shape
+    return wn.reshape(kh, kw, co, ci).permute(2, 3, 0, 1).contiguous()
+
+
+def dgrad_weight(w_native_f32):
+    """[T][Co][Ci] f32 -> [T][Ci][Co] bf16 with the tap order reversed (device kernel)."""
+    t, co, ci = w_native_f32.shape
+    out = torch.empty(t, ci, co, dtype=torch.bfloat16, device=w_native_f32.device)
+    lib.call("siss_conv_weight_dgrad_layout", w_native_f32, out, t, co, ci)
+    return out
+
+
+# ---------------------------------------------------------------- panelled NT GEMM
+def gemm_nt(a_ptr, lda, w, c_ptr, ldc, M, N, Kp, shifts, coffs, *, bias=None, rowbias=None,
+            res_ptr=None, ldr=0, rows_per_image=1, hp=0, wp=0, alpha=1.0, batch=1,
+            stride_a=0, stride_w=0, stride_c=0):
+    lib.call("siss_gemm_nt", a_ptr, lda, w, c_ptr, ldc, bias, rowbias, res_ptr, ldr, M, N, Kp,
+             len(shifts), lib.int_array(shifts), lib.int_array(coffs), rows_per_image, hp, wp,
+             float(alpha), batch, stride_a, stride_w, stride_c)
+
+
+def conv_fprop(x: Act, w_bf16, out: Act, bias=None, rowbias=None, residual: Act = None, ksize=3):
+    """out = conv(x) (+bias +rowbias[img] +residual); w_bf16 [T][Co][Ci] bf16."""
+    t, co, ci = w_bf16.shape
+    assert ci == x.c and co == out.c and (x.n, x.h, x.w) == (out.n, out.h, out.w)
+    if ksize == 3:
+        shifts, coffs = conv3x3_panels(x.wp, ci)
+    else:
+        shifts, coffs = [0], [0]
+    assert t == len(shifts)
+    gemm_nt(lib.ptr(x.data), x.c, w_bf16, lib.ptr(out.data), out.c, x.rows, co, ci, shifts, coffs,
+            bias=bias, rowbias=rowbias, res_ptr=lib.ptr(residual.data) if residual is not None else None,
+            ldr=residual.c if residual is not None else 0,
+            rows_per_image=x.rows_per_image, hp=x.hp, wp=x.wp)
+    return out
+
+
+def conv_dgrad(dy: Act, wT_bf16, out: Act, residual: Act = None, ksize=3):
+    """out = conv_transpose(dy) for a stride-1 'same' conv; wT_bf16 from dgrad_weight()."""
+    t, ci, co = wT_bf16.shape
+    assert co == dy.c and ci == out.c
+    if ksize == 3:
+        # dX[q] = sum_tap dY[q - shift(tap)] W[tap]^T ; tap order already reversed in wT
+        shifts, coffs = conv3x3_panels(dy.wp, co)
+    else:
+        shifts, coffs = [0], [0]
+    gemm_nt(lib.ptr(dy.data), dy.c, wT_bf16, lib.ptr(out.data), out.c, dy.rows, ci, co, shifts, coffs,
+            res_ptr=lib.ptr(residual.data) if residual is not None else None,
+            ldr=residual.c if residual is not None else 0,
+            rows_per_image=dy.rows_per_image, hp=dy.hp, wp=dy.wp)
+    return out
+
+
+def _nsplits(base_blocks, rows):
+    want = max(1, -(-1024 // base_blocks))
+    return max(1, min(want, -(-rows // 512)))
+
+
+def conv_wgrad(dy: Act, x: Act, dW, nsets, ksize=3):
+    """dW[set][T][Co][Ci] += dy^T x over each set's images (dy has nsets*B images; x has B or nsets*B)."""
+    co, ci = dy.c, x.c
+    assert dy.n % nsets == 0
+    b = dy.n // nsets
+    assert x.n in (b, dy.n) and (x.h, x.w) == (dy.h, dy.w)
+    if ksize == 3:
+        shifts, coffs = conv3x3_panels(dy.wp, ci)
+    else:
+        shifts, coffs = [0], [0]
+    t = len(shifts)
+    assert dW.dtype == torch.float32 and dW.numel() == nsets * t * co * ci
+    rows_per_set = b * dy.rows_per_image
+    x_set_rows = 0 if x.n == b else rows_per_set
+    rb, re = dy.wp + 1, rows_per_set - (dy.wp + 1)
+    tiles = (-(-co // 128)) * (-(-ci // 128))
+    ns = _nsplits(tiles * t * nsets, re - rb)
+    lib.call("siss_gemm_tn", dy.data, dy.c, x.data, x.c, dW, t * co * ci, co, ci, t,
+             lib.int_array(shifts), lib.int_array(coffs), nsets, rows_per_set, x_set_rows, rb, re, ns,
+             zero_page(dy.buf.device))
+    return dW
