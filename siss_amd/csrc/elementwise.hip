@@ -191,7 +191,8 @@ __global__ void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restri
 
 // out[set][c] += sum over the set's rows of y[r][c]    (rows are flat; halo rows are zero)
 __global__ __launch_bounds__(kThreads) void colsum_kernel(const bf16_t* __restrict__ y, long rows_per_set,
-                                                          int C, long out_set_stride, float* __restrict__ out) {
+                                                          int C, long out_set_stride, float* __restrict__ out,
+                                                          float* __restrict__ out2) {
     extern __shared__ float sh[];   // C floats
     const int set = blockIdx.y, cc = C / 8;
     for (int i = threadIdx.x; i < C; i += kThreads) sh[i] = 0.f;
@@ -210,7 +211,10 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(const bf16_t* __restri
         for (int e = 0; e < 8; ++e) atomicAdd(&sh[c * 8 + e], a[e]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += kThreads) atomicAdd(out + (long)set * out_set_stride + i, sh[i]);
+    for (int i = threadIdx.x; i < C; i += kThreads) {
+        atomicAdd(out + (long)set * out_set_stride + i, sh[i]);
+        if (out2) atomicAdd(out2 + (long)set * out_set_stride + i, sh[i]);
+    }
 }
 
 // conv_in front end: NCHW image (f32 or bf16) -> im2col rows [N][H+2][W+2][K] bf16, K >= 9*Cin,
@@ -311,14 +315,16 @@ int siss_transpose_bf16(const void* in, void* out, int batch, int R, int C, void
     SISS_LAUNCH_RET();
 }
 // out[set][0:C] += column sums of y over each set's rows.  y: [nsets*rows_per_set][C] bf16.
-int siss_colsum(const void* y, long rows_per_set, int C, int nsets, long out_set_stride, float* out, void* stream) {
+// out2 (optional) receives the same sums (two biases that feed the same pre-activation).
+int siss_colsum(const void* y, long rows_per_set, int C, int nsets, long out_set_stride, float* out, float* out2,
+                void* stream) {
     SISS_CHECK_ARG(y && out && rows_per_set > 0 && C > 0 && C % 8 == 0 && C / 8 <= kThreads && nsets > 0);
     const int ppi = kThreads / (C / 8);
     long nb = (rows_per_set + (long)ppi * 64 - 1) / ((long)ppi * 64);
     if (nb < 1) nb = 1;
     if (nb > 512) nb = 512;
     dim3 grid((int)nb, nsets);
-    colsum_kernel<<<grid, kThreads, C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)y, rows_per_set, C, out_set_stride, out);
+    colsum_kernel<<<grid, kThreads, C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)y, rows_per_set, C, out_set_stride, out, out2);
     SISS_LAUNCH_RET();
 }
 int siss_im2col3x3(const void* img, int img_bf16, void* out, int N, int Cin, int H, int W, int K, void* stream) {

@@ -76,7 +76,7 @@ __global__ void linear_bwd_dx_kernel(const float* __restrict__ dy, const float* 
 // one thread per (set, n, k); also db when k == 0
 __global__ void linear_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                      const float* __restrict__ x, float* __restrict__ dW, float* __restrict__ db,
-                                     int M2, int Mx, int set_rows, long set_stride_w, long set_stride_b, int N,
+                                     float* __restrict__ db2, int M2, int Mx, int set_rows, long set_stride_w, long set_stride_b, int N,
                                      int K, int act_in) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nsets = M2 / set_rows;
@@ -94,7 +94,10 @@ __global__ void linear_bwd_dw_kernel(const float* __restrict__ dy, const float* 
         bsum += d;
     }
     dW[(long)set * set_stride_w + (long)n * K + k] += acc;
-    if (k == 0) db[(long)set * set_stride_b + n] += bsum;
+    if (k == 0) {
+        db[(long)set * set_stride_b + n] += bsum;
+        if (db2) db2[(long)set * set_stride_b + n] += bsum;
+    }
 }
 
 }  // namespace
@@ -114,14 +117,15 @@ int siss_linear_small_fwd(const float* x, const float* W, const float* b, float*
 }
 
 // dx may be NULL (first layer).  dW/db are accumulated in place (+=): zero them at step start.
+// db2 (optional) receives the same bias sums (conv1 bias shares its gradient with time_emb_proj bias).
 int siss_linear_small_bwd(const float* dy, const float* yact, const float* x, const float* W, float* dx, int accumulate_dx,
-                          float* dW, float* db, int M2, int Mx, int set_rows, long set_stride_w, long set_stride_b,
-                          int N, int K, int act_in_silu, void* stream) {
+                          float* dW, float* db, float* db2, int M2, int Mx, int set_rows, long set_stride_w,
+                          long set_stride_b, int N, int K, int act_in_silu, void* stream) {
     SISS_CHECK_ARG(dy && x && W && dW && db && M2 > 0 && Mx > 0 && set_rows > 0 && M2 % set_rows == 0 && N > 0 && K > 0);
     hipStream_t st = (hipStream_t)stream;
     if (dx) linear_bwd_dx_kernel<<<cdiv((long)M2 * K, 256), 256, 0, st>>>(dy, yact, W, dx, M2, Mx, N, K, accumulate_dx);
     const long tot = (long)(M2 / set_rows) * N * K;
-    linear_bwd_dw_kernel<<<cdiv(tot, 256), 256, 0, st>>>(dy, yact, x, dW, db, M2, Mx, set_rows, set_stride_w, set_stride_b, N, K, act_in_silu);
+    linear_bwd_dw_kernel<<<cdiv(tot, 256), 256, 0, st>>>(dy, yact, x, dW, db, db2, M2, Mx, set_rows, set_stride_w, set_stride_b, N, K, act_in_silu);
     SISS_LAUNCH_RET();
 }
 

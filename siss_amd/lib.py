@@ -28,8 +28,32 @@ SIGNATURES = {
     "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],
     "siss_gemm_nt": [P, L, P, P, L, P, P, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P],
+    "siss_gn_partial_words": [I, I, I, I, I],
+    "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
+    "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, L, I, I, I, I, I, I, P],
+    "siss_upsample2x": [P, P, I, I, I, I, P],
+    "siss_upsample2x_bwd": [P, P, I, I, I, I, P],
+    "siss_concat": [P, P, P, I, I, I, I, I, P],
+    "siss_concat_bwd": [P, P, P, I, I, I, I, I, I, P],
+    "siss_add_inplace": [P, P, I, I, I, I, P],
+    "siss_space_to_depth": [P, P, I, I, I, I, P],
+    "siss_depth_to_space": [P, P, I, I, I, I, I, P],
+    "siss_pad_to_compact": [P, P, I, I, I, I, P],
+    "siss_compact_add_to_pad": [P, P, P, I, I, I, I, P],
+    "siss_transpose_bf16": [P, P, I, I, I, P],
+    "siss_colsum": [P, L, I, I, L, P, P, P],
+    "siss_im2col3x3": [P, I, P, I, I, I, I, I, P],
+    "siss_conv_out_fprop": [P, P, P, P, I, I, I, I, I, P],
+    "siss_conv_out_dgrad": [P, P, P, I, I, I, I, I, P],
+    "siss_conv_out_wgrad": [P, P, P, P, I, I, I, L, L, I, I, I, I, P],
+    "siss_softmax_fwd": [P, P, L, I, P],
+    "siss_softmax_bwd": [P, P, P, L, L, I, F, P],
+    "siss_timestep_sincos": [P, P, I, I, I, F, P],
+    "siss_linear_small_fwd": [P, P, P, P, I, I, I, I, P],
+    "siss_linear_small_bwd": [P, P, P, P, P, I, P, P, P, I, I, I, L, L, I, I, I, P],
 }
-_RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words"}
+_RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words",
+             "siss_gn_partial_words"}
 
 _lib = None
 

@@ -56,7 +56,8 @@ def mixture_fwd(x0, a0, noise, t, u, alphas_cumprod, gamma_tab, sigma_tab, lambd
     return m
 
 
-def loss_bwd_seed(pred, m: Mixture, x0, a0, scale, want_losses=False, want_cotangents=True, partials=None):
+def loss_bwd_seed(pred, m: Mixture, x0, a0, scale, want_losses=False, want_cotangents=True, partials=None,
+                  c_out=None):
     """Cotangents c_x, c_a = d/dpred [ sum(iw * (pred - eps)^2) * scale ]  (delete_celeb.py:686-687;
     scale = 1/(train_batch_size * grad_accum)) + per-sample loss sums for the stats block (:626-663)."""
     assert pred.dtype == torch.float32 and pred.is_contiguous()
@@ -64,7 +65,12 @@ def loss_bwd_seed(pred, m: Mixture, x0, a0, scale, want_losses=False, want_cotan
     chw = pred[0].numel()
     dev = pred.device
     e = lambda: torch.empty_like(pred)
-    s = LossSeed(e() if want_cotangents else None, e() if want_cotangents else None,
+    if c_out is not None:          # caller-provided stacked [2B,...] cotangent buffer: rows [0,B)=c_x, [B,2B)=c_a
+        assert c_out.shape[0] == 2 * B and c_out.dtype == torch.float32 and c_out.is_contiguous()
+        cx, ca = c_out[:B], c_out[B:]
+    else:
+        cx, ca = (e(), e()) if want_cotangents else (None, None)
+    s = LossSeed(cx, ca,
                  e() if want_losses else None, e() if want_losses else None,
                  torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev))
     if partials is None:

@@ -1,0 +1,125 @@
+"""One SISS unlearning optimizer step on HIP -- the hot loop body of the reference's
+delete_celeb.py:557-773 (delete_tshirt.py:501-717), in closed form:
+
+    per micro-batch k:  x_mix, iw     = mixture_fwd(x0, a0, noise, t, u)                   [fused pre-kernel]
+                        pred          = UNet(x_mix, t)                                      [one forward]
+                        c_x, c_a      = d/dpred sum(iw * (pred - eps)^2) / (B_total * GA)   [fused post-kernel]
+                        [g_x ; g_a]  += J^T [c_x ; c_a]                                    [ONE dual-cotangent backward]
+    sync step:          (all-reduce [g_x ; g_a] over ranks)                                 [one RCCL collective]
+                        s = scaling_norm / ||g_a|| ; g = g_x - s g_a ; clip ; AdamW         [two flat passes]
+
+What the reference does with two ``backward`` calls, three 450-tensor clone loops, two norm
+loops and a foreach optimizer is here a fixed kernel schedule with no host synchronisation;
+the logged scalars stay on the device until ``stats()`` is called.
+
+Data parallelism: every rank runs the same schedule on its own keep / forget
+shard; the only exchange is one sum all-reduce of the flat [g_x ; g_a] buffer per optimizer
+step.  Loss normaliser = global batch (train_batch_size * world_size), so the result equals
+the single-process step on the concatenated batch.
+"""
+import torch
+
+from . import lib
+from .loss import loss_bwd_seed, mixture_fwd, mse_bwd_seed
+from .optim import FlatAdamW
+from .unet import UNetEngine
+
+SISS = "importance_sampling_with_mixture"
+NO_IS = "double_forward_with_neg_del"
+
+
+class SISSStepper:
+    def __init__(self, engine: UNetEngine, alphas_cumprod, *, lr, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-2, scaling_norm=None, eta=None, lambd=0.5, train_batch_size,
+                 grad_accum=1, max_grad_norm=1.0, loss_fn=SISS, inf_guard=False, process_group=None,
+                 mixed_precision="bf16"):
+        self.e = engine
+        dev = engine.device
+        ac = alphas_cumprod.to(device=dev, dtype=torch.float32).contiguous()
+        self.ac = ac
+        self.gamma_tab = (ac ** 0.5).contiguous()           # delete_celeb.py:367-371
+        self.sigma_tab = ((1 - ac) ** 0.5).contiguous()
+        self.lambd, self.scaling_norm, self.eta, self.inf_guard = float(lambd), scaling_norm, eta, inf_guard
+        self.train_batch_size, self.ga = int(train_batch_size), int(grad_accum)
+        self.loss_fn = loss_fn
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.io_dtype = torch.bfloat16 if mixed_precision == "bf16" else torch.float32
+        self.opt = FlatAdamW(engine.ps.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                             max_grad_norm=max_grad_norm, shadow=engine.ps.shadow)
+        self._micro = 0
+        self.last = None
+
+    # ------------------------------------------------------------------ one micro-batch
+    def micro_step(self, x0, a0, noise, t, u):
+        """Inputs: x0/a0/noise [B,C,H,W] (cast to the io dtype like delete_celeb.py:561-581),
+        t [B] int64, u [B] keep/forget uniforms.  Enqueues fwd + dual backward; no host sync."""
+        e = self.e
+        if self._micro == 0:
+            e.zero_grad()
+        x0, a0, noise = (v.to(device=e.device, dtype=self.io_dtype).contiguous() for v in (x0, a0, noise))
+        B = x0.shape[0]
+        scale = 1.0 / (self.train_batch_size * self.world * self.ga)
+        if self.loss_fn == SISS:
+            m = mixture_fwd(x0, a0, noise, t, u, self.ac, self.gamma_tab, self.sigma_tab, self.lambd)
+            pred = e.forward(m.x_mix, t)
+            cot = e._buf("cot", (2 * B, *pred.shape[1:]))
+            # c_x / c_a go straight into the stacked cotangent buffer that seeds the dual backward
+            seed = loss_bwd_seed(pred, m, x0, a0, scale, c_out=cot, partials=self._partials(B, pred[0].numel()))
+            e.backward(cot, nsets=2)
+            self.last = dict(iw_x=m.iw_x, iw_a=m.iw_a, sum_loss_x=seed.sum_loss_x, sum_loss_a=seed.sum_loss_a,
+                             chw=pred[0].numel())
+        elif self.loss_fn == NO_IS:
+            # two forwards as ONE batch-2B forward (ddpm_deletion_loss.py:60-67), plain noise target
+            m = mixture_fwd(x0, a0, noise, t, torch.ones(B, device=e.device), self.ac, self.gamma_tab,
+                            self.sigma_tab, 0.0)   # u=1 > 0: keep rows -> q_sample(x0)
+            mf = mixture_fwd(x0, a0, noise, t, torch.zeros(B, device=e.device), self.ac, self.gamma_tab,
+                             self.sigma_tab, 0.5)  # u=0 <= .5: forget rows -> q_sample(a0)
+            xin = torch.cat([m.x_mix, mf.x_mix], 0)
+            pred = e.forward(xin, torch.cat([t, t], 0))
+            tgt = torch.cat([noise, noise], 0)
+            cot, _, sums = mse_bwd_seed(pred, tgt, scale)
+            e.backward(cot, nsets=2)
+            self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums[:B], sum_loss_a=sums[B:], chw=pred[0].numel())
+        else:
+            raise ValueError(f"loss_fn {self.loss_fn!r} is not on the HIP fast path")
+        self._micro += 1
+        if self._micro == self.ga:
+            self._micro = 0
+            self._sync_and_update()
+
+    def _partials(self, B, chw):
+        return self.e._buf("loss_partials", (lib.query("siss_loss_partials_words", B, chw),), torch.float64)
+
+    def _sync_and_update(self):
+        g = self.e.ps.grads
+        if self.pg is not None and self.world > 1:
+            # the ONE collective of the step: sum of [g_x ; g_a] over ranks (RCCL over xGMI)
+            torch.distributed.all_reduce(g, group=self.pg)
+        self.opt.launch(g, scaling_norm=self.scaling_norm, eta=self.eta, inf_guard=self.inf_guard)
+        self.e.refresh_weights()
+
+    def step(self, x0, a0, noise, t, u):
+        """GA=1 convenience."""
+        assert self.ga == 1
+        self.micro_step(x0, a0, noise, t, u)
+
+    # ------------------------------------------------------------------ logging (one small D2H)
+    def stats(self):
+        st = self.opt.stats()
+        if self.last is not None:
+            chw = self.last["chw"]
+            lx, la = self.last["sum_loss_x"].float().cpu() / chw, self.last["sum_loss_a"].float().cpu() / chw
+            st.update({"loss_x/mean": float(lx.mean()), "loss_x/max": float(lx.max()), "loss_x/min": float(lx.min()),
+                       "loss_a/mean": float(la.mean()), "loss_a/max": float(la.max()), "loss_a/min": float(la.min())})
+            if lx.numel() > 1:
+                st["loss_x/std"], st["loss_a/std"] = float(lx.std()), float(la.std())
+            if self.last["iw_x"] is not None:
+                for k in ("iw_x", "iw_a"):
+                    v = self.last[k].cpu()
+                    name = "importance_weight_" + k[-1]
+                    st.update({f"{name}/mean": float(v.mean()), f"{name}/max": float(v.max()),
+                               f"{name}/min": float(v.min())})
+                    if v.numel() > 1:
+                        st[f"{name}/std"] = float(v.std())
+        return st

@@ -1,0 +1,712 @@
+"""DDPM UNet (diffusers ``UNet2DModel`` architecture) forward + dual-cotangent backward on HIP.
+
+This is the a-U row of SURVEY.md §8: the network the reference reaches through
+``unet(x, t, return_dict=False)[0]`` (losses/ddpm_deletion_loss.py:24) and differentiates
+twice with ``retain_graph=True`` (delete_celeb.py:686-711).  Here it is a static schedule of
+hand-written gfx950 kernels (csrc/*.hip) over
+
+  * ONE flat f32 master parameter buffer (+ bf16 shadow in kernel-native layouts),
+  * ONE flat f32 gradient buffer with two sets  [g_x ; g_a],
+  * NHWC bf16 activations with a zero halo (layout.py),
+
+and the backward pass carries BOTH cotangents at once (batch 2B against B saved
+activations): activations are read once for g_x and g_a, dgrad runs at batch 2B and the
+weight-gradient GEMMs write the two sets side by side.  No autograd, no tracing: the schedule
+is replayable from a hipGraph.
+
+Parameter names are the diffusers state-dict keys, so checkpoints round-trip.
+"""
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import lib, ops
+from .config import UNet2DConfig
+from .layout import Act
+
+ALIGN = 64  # floats; keeps every bf16 shadow slice 128-B aligned
+
+
+@dataclass
+class PSpec:
+    name: str
+    kind: str          # conv3 | conv_in | conv1 | mat | vec
+    ref_shape: tuple
+    native_shape: tuple
+    off: int
+    numel: int
+
+
+class ParamStore:
+    """Flat master parameters / gradients / bf16 shadow, with reference<->native layout maps."""
+
+    def __init__(self):
+        self.specs = {}
+        self.total = 0
+
+    def add(self, name, kind, ref_shape):
+        if kind == "conv3":
+            co, ci = ref_shape[:2]
+            native = (9, co, ci)
+        elif kind == "conv_in":
+            co, ci = ref_shape[:2]
+            kp = -(-9 * ci // 64) * 64
+            native = (co, kp)
+        elif kind == "conv1":
+            native = tuple(ref_shape[:2])
+        else:
+            native = tuple(ref_shape)
+        numel = int(math.prod(native))
+        sp = PSpec(name, kind, tuple(ref_shape), native, self.total, numel)
+        self.specs[name] = sp
+        self.total += -(-numel // ALIGN) * ALIGN
+        return sp
+
+    def allocate(self, device, nsets=2):
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(nsets, self.total, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=device)
+        self.nsets = nsets
+
+    # views -----------------------------------------------------------------
+    def p(self, name):
+        sp = self.specs[name]
+        return self.flat[sp.off:sp.off + sp.numel].view(sp.native_shape)
+
+    def sh(self, name):
+        sp = self.specs[name]
+        return self.shadow[sp.off:sp.off + sp.numel].view(sp.native_shape)
+
+    def g(self, name, base_set=0):
+        """gradient slice of `name` starting at set `base_set` (kernels add set*total themselves)."""
+        sp = self.specs[name]
+        return self.grads[base_set, sp.off:sp.off + sp.numel]
+
+    # layout maps -----------------------------------------------------------
+    @staticmethod
+    def to_native(sp, t):
+        t = t.detach().to(torch.float32)
+        if sp.kind == "conv3":
+            return ops.conv_w_to_native(t)
+        if sp.kind == "conv_in":
+            co, ci = t.shape[:2]
+            out = torch.zeros(sp.native_shape, dtype=torch.float32, device=t.device)
+            out[:, :9 * ci] = t.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+            return out
+        if sp.kind == "conv1":
+            return t.reshape(sp.native_shape)
+        return t
+
+    @staticmethod
+    def from_native(sp, t):
+        if sp.kind == "conv3":
+            return ops.conv_w_from_native(t.view(sp.native_shape))
+        if sp.kind == "conv_in":
+            co, ci = sp.ref_shape[:2]
+            return t.view(sp.native_shape)[:, :9 * ci].reshape(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()
+        return t.reshape(sp.ref_shape).clone()
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [n for n in self.specs if n not in sd]
+        extra = [n for n in sd if n not in self.specs]
+        if strict and (missing or extra):
+            raise KeyError(f"state_dict mismatch: missing {missing[:5]} unexpected {extra[:5]}")
+        for n, sp in self.specs.items():
+            if n not in sd:
+                continue
+            t = sd[n]
+            if tuple(t.shape) != sp.ref_shape:
+                raise ValueError(f"{n}: shape {tuple(t.shape)} != {sp.ref_shape}")
+            self.flat[sp.off:sp.off + sp.numel] = self.to_native(sp, t.to(self.flat.device)).reshape(-1)
+
+    def state_dict(self):
+        return {n: self.from_native(sp, self.flat[sp.off:sp.off + sp.numel]).cpu() for n, sp in self.specs.items()}
+
+    def grads_ref(self, which):
+        """Gradient set `which` (0 = g_x, 1 = g_a) in reference layout, {name: cpu tensor}."""
+        return {n: self.from_native(sp, self.grads[which, sp.off:sp.off + sp.numel]).cpu()
+                for n, sp in self.specs.items()}
+
+    def flat_to_ref(self, flat):
+        return {n: self.from_native(sp, flat[sp.off:sp.off + sp.numel]).cpu() for n, sp in self.specs.items()}
+
+
+class UNetEngine:
+    """Static-schedule UNet.  ``forward(x, t)`` then ``backward(c, nsets)``."""
+
+    def __init__(self, cfg: UNet2DConfig, device="cuda"):
+        lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.ps = ParamStore()
+        self._declare_params()
+        self.ps.allocate(self.device)
+        self.wT = {}
+        self._acts = {}
+        self._bufs = {}
+        self._pool = {}
+        self.tape = []
+        self.gmap = {}
+        self._uid = 0
+
+    # ------------------------------------------------------------------ parameters
+    def _declare_resnet(self, pre, cin, cout, temb):
+        a = self.ps.add
+        a(f"{pre}.norm1.weight", "vec", (cin,)); a(f"{pre}.norm1.bias", "vec", (cin,))
+        a(f"{pre}.conv1.weight", "conv3", (cout, cin, 3, 3)); a(f"{pre}.conv1.bias", "vec", (cout,))
+        a(f"{pre}.time_emb_proj.weight", "mat", (cout, temb)); a(f"{pre}.time_emb_proj.bias", "vec", (cout,))
+        a(f"{pre}.norm2.weight", "vec", (cout,)); a(f"{pre}.norm2.bias", "vec", (cout,))
+        a(f"{pre}.conv2.weight", "conv3", (cout, cout, 3, 3)); a(f"{pre}.conv2.bias", "vec", (cout,))
+        if cin != cout:
+            a(f"{pre}.conv_shortcut.weight", "conv1", (cout, cin, 1, 1)); a(f"{pre}.conv_shortcut.bias", "vec", (cout,))
+
+    def _declare_attn(self, pre, ch):
+        a = self.ps.add
+        a(f"{pre}.group_norm.weight", "vec", (ch,)); a(f"{pre}.group_norm.bias", "vec", (ch,))
+        for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+            a(f"{pre}.{nm}.weight", "mat", (ch, ch)); a(f"{pre}.{nm}.bias", "vec", (ch,))
+
+    def _declare_params(self):
+        cfg, a = self.cfg, self.ps.add
+        ch = cfg.block_out_channels
+        temb = ch[0] * 4
+        self.temb_dim = temb
+        a("conv_in.weight", "conv_in", (ch[0], cfg.in_channels, 3, 3)); a("conv_in.bias", "vec", (ch[0],))
+        a("time_embedding.linear_1.weight", "mat", (temb, ch[0])); a("time_embedding.linear_1.bias", "vec", (temb,))
+        a("time_embedding.linear_2.weight", "mat", (temb, temb)); a("time_embedding.linear_2.bias", "vec", (temb,))
+        self.plan_down, self.plan_up = [], []
+        out = ch[0]
+        for i, kind in enumerate(cfg.down_block_types):
+            cin, out = out, ch[i]
+            attn, down = kind.startswith("Attn"), i != len(ch) - 1
+            for j in range(cfg.layers_per_block):
+                self._declare_resnet(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else out, out, temb)
+                if attn:
+                    self._declare_attn(f"down_blocks.{i}.attentions.{j}", out)
+            if down:
+                a(f"down_blocks.{i}.downsamplers.0.conv.weight", "conv3", (out, out, 3, 3))
+                a(f"down_blocks.{i}.downsamplers.0.conv.bias", "vec", (out,))
+            self.plan_down.append((i, cin, out, attn, down))
+        c = ch[-1]
+        self._declare_resnet("mid_block.resnets.0", c, c, temb)
+        self._declare_attn("mid_block.attentions.0", c)
+        self._declare_resnet("mid_block.resnets.1", c, c, temb)
+        rev = list(reversed(ch))
+        out = rev[0]
+        n = cfg.layers_per_block + 1
+        for i, kind in enumerate(cfg.up_block_types):
+            prev, out = out, rev[i]
+            cin = rev[min(i + 1, len(ch) - 1)]
+            attn, up = kind.startswith("Attn"), i != len(ch) - 1
+            rs = []
+            for j in range(n):
+                skip = cin if j == n - 1 else out
+                rin = prev if j == 0 else out
+                self._declare_resnet(f"up_blocks.{i}.resnets.{j}", rin + skip, out, temb)
+                rs.append((rin, skip))
+                if attn:
+                    self._declare_attn(f"up_blocks.{i}.attentions.{j}", out)
+            if up:
+                a(f"up_blocks.{i}.upsamplers.0.conv.weight", "conv3", (out, out, 3, 3))
+                a(f"up_blocks.{i}.upsamplers.0.conv.bias", "vec", (out,))
+            self.plan_up.append((i, out, attn, up, rs))
+        a("conv_norm_out.weight", "vec", (ch[0],)); a("conv_norm_out.bias", "vec", (ch[0],))
+        a("conv_out.weight", "conv3", (cfg.out_channels, ch[0], 3, 3)); a("conv_out.bias", "vec", (cfg.out_channels,))
+
+    def init_random(self, seed=0, std=0.02):
+        """Random-init weights of the exact architecture (no checkpoints in the repo): conv/linear
+        ~ N(0, 1/fan_in) scaled, GroupNorm gamma=1 beta=0, biases small."""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        for n, sp in self.ps.specs.items():
+            if sp.kind == "vec":
+                if n.endswith("norm1.weight") or n.endswith("norm2.weight") or n.endswith("group_norm.weight") \
+                        or n == "conv_norm_out.weight":
+                    sd[n] = torch.ones(sp.ref_shape) + 0.05 * torch.randn(sp.ref_shape, generator=g)
+                else:
+                    sd[n] = 0.02 * torch.randn(sp.ref_shape, generator=g)
+            else:
+                fan_in = math.prod(sp.ref_shape[1:])
+                sd[n] = torch.randn(sp.ref_shape, generator=g) / math.sqrt(fan_in)
+        self.load_state_dict(sd)
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        self.ps.load_state_dict(sd, strict)
+        self.refresh_weights(cast_shadow=True)
+
+    def state_dict(self):
+        return self.ps.state_dict()
+
+    def refresh_weights(self, cast_shadow=False):
+        """bf16 operand copies derived from the f32 master: the fprop shadow (optionally; the fused
+        AdamW kernel already refreshes it) and the transposed/flipped dgrad copies."""
+        ps = self.ps
+        if cast_shadow:
+            lib.call("siss_cast_f32_bf16", ps.flat, ps.shadow, ps.total)
+        for n, sp in ps.specs.items():
+            if sp.kind in ("conv3", "conv1", "mat") and n != "conv_out.weight" and "time_emb" not in n:
+                if sp.kind == "conv3":
+                    t, co, ci = sp.native_shape
+                else:
+                    t, (co, ci) = 1, sp.native_shape
+                wt = self.wT.get(n)
+                if wt is None:
+                    wt = torch.empty(t, ci, co, dtype=torch.bfloat16, device=self.device)
+                    self.wT[n] = wt
+                lib.call("siss_conv_weight_dgrad_layout", ps.p(n), wt, t, co, ci)
+
+    # ------------------------------------------------------------------ buffers
+    def _act(self, name, n, h, w, c):
+        k = (name, n, h, w, c)
+        a = self._acts.get(k)
+        if a is None:
+            a = Act(n, h, w, c, self.device)
+            self._acts[k] = a
+        return a
+
+    def _buf(self, name, shape, dtype=torch.float32):
+        k = (name, tuple(shape), dtype)
+        b = self._bufs.get(k)
+        if b is None:
+            # slack: tile-granular kernels may READ (never use) up to one 256-B row past a small operand
+            n = int(math.prod(shape))
+            b = torch.zeros(n + 1024, dtype=dtype, device=self.device)[:n].view(shape)
+            self._bufs[k] = b
+        return b
+
+    def _get(self, n, h, w, c):
+        lst = self._pool.setdefault((n, h, w, c), [])
+        return lst.pop() if lst else Act(n, h, w, c, self.device)
+
+    def _put(self, a):
+        if a is not None:
+            self._pool.setdefault((a.n, a.h, a.w, a.c), []).append(a)
+
+    def _name(self, base):
+        self._uid += 1
+        return f"{base}#{self._uid}"
+
+    # gradient map (cotangent accumulation across multiple consumers, e.g. skip connections)
+    def _give(self, act, g):
+        cur = self.gmap.get(id(act))
+        if cur is None:
+            self.gmap[id(act)] = g
+        else:
+            lib.call("siss_add_inplace", cur.data, g.data, cur.n, cur.h, cur.w, cur.c)
+            self._put(g)
+
+    def _take(self, act):
+        return self.gmap.pop(id(act))
+
+    # ------------------------------------------------------------------ primitive ops (fwd + taped bwd)
+    def _gn_partial(self, n, h, w, c):
+        words = lib.query("siss_gn_partial_words", n, h, w, c, self.cfg.norm_num_groups)
+        assert words > 0
+        return self._buf("gn_partial", (max(words, 1),))
+
+    def gn(self, x: Act, pre, silu, compact_out=False):
+        """GroupNorm(+SiLU).  Returns Act (or a compact [N*H*W, C] bf16 tensor)."""
+        G, eps = self.cfg.norm_num_groups, self.cfg.norm_eps
+        ps = self.ps
+        nm = self._name(pre)
+        mean = self._buf(nm + ".mean", (x.n, G))
+        rstd = self._buf(nm + ".rstd", (x.n, G))
+        if compact_out:
+            y = self._buf(nm + ".y", (x.n * x.h * x.w, x.c), torch.bfloat16)
+            yptr = y
+        else:
+            y = self._act(nm + ".y", x.n, x.h, x.w, x.c)
+            yptr = y.data
+        lib.call("siss_groupnorm_fwd", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
+                 self._gn_partial(x.n, x.h, x.w, x.c), x.n, x.h, x.w, x.c, G, float(eps), int(silu), int(compact_out))
+
+        def bwd(dy, colsum=None, accum: Act = None):
+            """dy: Act (padded) or compact tensor, nb samples.  Returns dx Act (nb samples)."""
+            nb = self.nb
+            dx = accum if accum is not None else self._get(nb, x.h, x.w, x.c)
+            dyp = dy.data if isinstance(dy, Act) else dy
+            lib.call("siss_groupnorm_bwd", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
+                     dx.data, accum.data if accum is not None else None,
+                     ps.g(pre + ".weight", self.gbase), ps.g(pre + ".bias", self.gbase), colsum,
+                     self._gn_partial(nb, x.h, x.w, x.c), nb, x.n, self.set_images, ps.total,
+                     x.h, x.w, x.c, G, int(silu), int(not isinstance(dy, Act)))
+            return dx
+        return y, bwd
+
+    def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None):
+        """stride-1 'same' conv (3x3 or 1x1) with fused bias / time-embedding row bias / residual."""
+        ps = self.ps
+        w = ps.sh(pre + ".weight")
+        if ksize == 1:
+            w = w.view(1, *w.shape)
+        co = w.shape[1]
+        y = self._act(self._name(out_name or pre), x.n, x.h, x.w, co)
+        ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize)
+
+        def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None):
+            if bias_grad:
+                lib.call("siss_colsum", dy.data, self.set_images * dy.rows_per_image, co, self.nsets, ps.total,
+                         ps.g(pre + ".bias", self.gbase), bias_grad2)
+            t = 9 if ksize == 3 else 1
+            dW = ps.grads[self.gbase:, ps.specs[pre + ".weight"].off:]
+            self._wgrad(dy, x, dW, co, x.c, ksize)
+            if not need_dx:
+                return None
+            dx = accum if accum is not None else self._get(dy.n, x.h, x.w, x.c)
+            ops.conv_dgrad(dy, self.wT[pre + ".weight"], dx, residual=accum, ksize=ksize)
+            return dx
+        return y, bwd
+
+    def _wgrad(self, dy: Act, x: Act, dW_view, co, ci, ksize, shifts=None, coffs=None, ldx=None):
+        """dW_view: grads[gbase:, off:] -- a strided view whose [0,0] element is the target."""
+        ps = self.ps
+        if shifts is None:
+            if ksize == 3:
+                from .layout import conv3x3_panels
+                shifts, coffs = conv3x3_panels(dy.wp, ci)
+            else:
+                shifts, coffs = [0], [0]
+        t = len(shifts)
+        rows_per_set = self.set_images * dy.rows_per_image
+        assert x.n in (dy.n, self.set_images)
+        x_set_rows = rows_per_set if x.n == dy.n else 0      # 0: every set reads the same saved rows
+        rb, re = dy.wp + 1, rows_per_set - (dy.wp + 1)
+        tiles = (-(-co // 128)) * (-(-ci // 128))
+        ns = ops._nsplits(tiles * t * self.nsets, re - rb)
+        lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or x.c, dW_view, ps.total, co, ci, t,
+                 lib.int_array(shifts), lib.int_array(coffs), self.nsets, rows_per_set, x_set_rows, rb, re, ns,
+                 ops.zero_page(self.device))
+
+    # ------------------------------------------------------------------ time embedding
+    def time_embed(self, t):
+        cfg, ps = self.cfg, self.ps
+        B = t.shape[0]
+        c0 = cfg.block_out_channels[0]
+        e0 = self._buf("temb.e0", (B, c0))
+        h1 = self._buf("temb.h1", (B, self.temb_dim))
+        emb = self._buf("temb.emb", (B, self.temb_dim))
+        lib.call("siss_timestep_sincos", t, e0, B, c0, int(cfg.flip_sin_to_cos), float(cfg.freq_shift))
+        lib.call("siss_linear_small_fwd", e0, ps.p("time_embedding.linear_1.weight"),
+                 ps.p("time_embedding.linear_1.bias"), h1, B, self.temb_dim, c0, 0)
+        lib.call("siss_linear_small_fwd", h1, ps.p("time_embedding.linear_2.weight"),
+                 ps.p("time_embedding.linear_2.bias"), emb, B, self.temb_dim, self.temb_dim, 1)
+        self.emb = emb
+
+        def bwd():
+            nb, T = self.nb, self.temb_dim
+            d_s = self._buf("temb.d_s", (nb, T))           # grad wrt silu(emb), accumulated by the resnets
+            d_s1 = self._buf("temb.d_s1", (nb, T))
+            gb = self.gbase
+            lib.call("siss_linear_small_bwd", d_s, emb, h1, ps.p("time_embedding.linear_2.weight"), d_s1, 0,
+                     ps.g("time_embedding.linear_2.weight", gb), ps.g("time_embedding.linear_2.bias", gb), None,
+                     nb, B, self.set_images, ps.total, ps.total, T, T, 1)
+            lib.call("siss_linear_small_bwd", d_s1, h1, e0, ps.p("time_embedding.linear_1.weight"), None, 0,
+                     ps.g("time_embedding.linear_1.weight", gb), ps.g("time_embedding.linear_1.bias", gb), None,
+                     nb, B, self.set_images, ps.total, ps.total, T, c0, 0)
+        self.tape.append(bwd)
+
+    # ------------------------------------------------------------------ blocks
+    def resnet(self, x: Act, pre):
+        ps = self.ps
+        cin = x.c
+        cout = ps.specs[pre + ".conv1.weight"].ref_shape[0]
+        B = x.n
+        a1, gn1_b = self.gn(x, pre + ".norm1", True)
+        tp = self._buf(self._name(pre + ".tp"), (B, cout))
+        lib.call("siss_linear_small_fwd", self.emb, ps.p(pre + ".time_emb_proj.weight"),
+                 ps.p(pre + ".time_emb_proj.bias"), tp, B, cout, self.temb_dim, 1)
+        h, c1_b = self.conv(a1, pre + ".conv1", rowbias=tp)
+        a2, gn2_b = self.gn(h, pre + ".norm2", True)
+        has_sc = cin != cout
+        if has_sc:
+            sc, sc_b = self.conv(x, pre + ".conv_shortcut", ksize=1)
+            res = sc
+        else:
+            res = x
+        out, c2_b = self.conv(a2, pre + ".conv2", residual=res)
+
+        def bwd():
+            nb = self.nb
+            dout = self._take(out)
+            gb = self.gbase
+            # conv2 (its bias gradient equals the shortcut conv's bias gradient: same pre-activation)
+            da2 = c2_b(dout, bias_grad2=ps.g(pre + ".conv_shortcut.bias", gb) if has_sc else None)
+            dtp = self._buf("dtp", (nb, cout))
+            dtp.zero_()
+            dh = gn2_b(da2, colsum=dtp, accum=None)
+            self._put(da2)
+            # time_emb_proj (+ conv1 bias: same sums)
+            d_s = self._buf("temb.d_s", (nb, self.temb_dim))
+            lib.call("siss_linear_small_bwd", dtp, None, self.emb, ps.p(pre + ".time_emb_proj.weight"), d_s, 1,
+                     ps.g(pre + ".time_emb_proj.weight", gb), ps.g(pre + ".time_emb_proj.bias", gb),
+                     ps.g(pre + ".conv1.bias", gb), nb, B, self.set_images, ps.total, ps.total, cout,
+                     self.temb_dim, 1)
+            da1 = c1_b(dh, bias_grad=False)
+            self._put(dh)
+            if has_sc:
+                dxs = sc_b(dout, bias_grad=False)
+                self._put(dout)
+                dx = gn1_b(da1, accum=dxs)
+            else:
+                dx = gn1_b(da1, accum=dout)
+            self._put(da1)
+            self._give(x, dx)
+        self.tape.append(bwd)
+        return out
+
+    def attention(self, x: Act, pre):
+        """Single-head spatial self-attention block (attention_head_dim = C)."""
+        ps = self.ps
+        C, B, S = x.c, x.n, x.h * x.w
+        assert self.cfg.head_dim(C) == C, "multi-head attention is not on the HIP path yet"
+        scale = C ** -0.5
+        rows = B * S
+        nm = self._name(pre)
+        hn, gn_b = self.gn(x, pre + ".group_norm", False, compact_out=True)
+        bb = lambda s, shape: self._buf(nm + s, shape, torch.bfloat16)
+        q, k, v = bb(".q", (rows, C)), bb(".k", (rows, C)), bb(".v", (rows, C))
+        vT, sc, p = bb(".vT", (B, C, S)), bb(".s", (B, S, S)), bb(".p", (B, S, S))
+        o, y = bb(".o", (rows, C)), bb(".y", (rows, C))
+
+        def lin(a, wname, out, n_rows, bias=True):
+            ops.gemm_nt(lib.ptr(a), C, ps.sh(wname + ".weight"), lib.ptr(out), C, n_rows, C, C, [0], [0],
+                        bias=ps.p(wname + ".bias") if bias else None)
+        lin(hn, pre + ".to_q", q, rows); lin(hn, pre + ".to_k", k, rows); lin(hn, pre + ".to_v", v, rows)
+        lib.call("siss_transpose_bf16", v, vT, B, S, C)
+        ops.gemm_nt(lib.ptr(q), C, k, lib.ptr(sc), S, S, S, C, [0], [0], alpha=scale, batch=B,
+                    stride_a=S * C, stride_w=S * C, stride_c=S * S)
+        lib.call("siss_softmax_fwd", sc, p, B * S, S)
+        ops.gemm_nt(lib.ptr(p), S, vT, lib.ptr(o), C, S, C, S, [0], [0], batch=B,
+                    stride_a=S * S, stride_w=C * S, stride_c=S * C)
+        lin(o, pre + ".to_out.0", y, rows)
+        out = self._act(nm + ".out", B, x.h, x.w, C)
+        lib.call("siss_compact_add_to_pad", y, x.data, out.data, B, x.h, x.w, C)
+
+        def bwd():
+            nb, gb, ns, si = self.nb, self.gbase, self.nsets, self.set_images
+            rows2 = nb * S
+            dout = self._take(out)
+            tb = lambda s, shape, dt=torch.bfloat16: self._buf("attn" + s, shape, dt)
+            dy = tb(".dy", (rows2, C))
+            lib.call("siss_pad_to_compact", dout.data, dy, nb, x.h, x.w, C)
+            zp = ops.zero_page(self.device)
+
+            def lin_bwd(dyt, xin, wname, dx_out, accumulate):
+                """dyt [rows2,C] cotangent of y = xin W^T + b (xin has B*S rows shared by the sets)."""
+                lib.call("siss_colsum", dyt, si * S, C, ns, ps.total, ps.g(wname + ".bias", gb), None)
+                dW = ps.grads[gb:, ps.specs[wname + ".weight"].off:]
+                lib.call("siss_gemm_tn", dyt, C, xin, C, dW, ps.total, C, C, 1, lib.int_array([0]),
+                         lib.int_array([0]), ns, si * S, si * S if B == nb else 0,
+                         0, si * S, 1, zp)
+                if dx_out is not None:
+                    ops.gemm_nt(lib.ptr(dyt), C, self.wT[wname + ".weight"], lib.ptr(dx_out), C, rows2, C, C,
+                                [0], [0], res_ptr=lib.ptr(dx_out) if accumulate else None, ldr=C)
+            do = tb(".do", (rows2, C))
+            lin_bwd(dy, o, pre + ".to_out.0", do, False)
+            dp, ds = tb(".dp", (nb, S, S)), tb(".ds", (nb, S, S))
+            dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (rows2, C)), tb(".dv", (rows2, C))
+            dkf, dvf = tb(".dkf", (nb, S, C), torch.float32), tb(".dvf", (nb, S, C), torch.float32)
+            kT = tb(".kT", (B, C, S))
+            lib.call("siss_transpose_bf16", k, kT, B, S, C)
+            dkf.zero_(); dvf.zero_()
+            for g in range(nb // B):      # cotangent groups that share the B forward samples
+                sl = slice(g * B, (g + 1) * B)
+                # dP = dO V^T
+                ops.gemm_nt(lib.ptr(do[g * B * S:]), C, v, lib.ptr(dp[sl]), S, S, S, C, [0], [0], batch=B,
+                            stride_a=S * C, stride_w=S * C, stride_c=S * S)
+                # dV[key][c] = sum_q P[q][key] dO[q][c]
+                lib.call("siss_gemm_tn", p, S, do[g * B * S:], C, dvf[sl], S * C, S, C, 1, lib.int_array([0]),
+                         lib.int_array([0]), B, S, S, 0, S, 1, zp)
+            lib.call("siss_softmax_bwd", p, dp, ds, nb * S, B * S, S, float(scale))
+            for g in range(nb // B):
+                sl = slice(g * B, (g + 1) * B)
+                # dQ = dS K
+                ops.gemm_nt(lib.ptr(ds[sl]), S, kT, lib.ptr(dq[g * B * S:]), C, S, C, S, [0], [0], batch=B,
+                            stride_a=S * S, stride_w=C * S, stride_c=S * C)
+                # dK[key][c] = sum_q dS[q][key] Q[q][c]
+                lib.call("siss_gemm_tn", ds[sl], S, q, C, dkf[sl], S * C, S, C, 1, lib.int_array([0]),
+                         lib.int_array([0]), B, S, S, 0, S, 1, zp)
+            lib.call("siss_cast_f32_bf16", dkf, dk, dkf.numel())
+            lib.call("siss_cast_f32_bf16", dvf, dv, dvf.numel())
+            dhn = tb(".dhn", (rows2, C))
+            lin_bwd(dq, hn, pre + ".to_q", dhn, False)
+            lin_bwd(dk, hn, pre + ".to_k", dhn, True)
+            lin_bwd(dv, hn, pre + ".to_v", dhn, True)
+            dx = gn_b(dhn, accum=dout)        # residual path: d_out passes straight through
+            self._give(x, dx)
+        self.tape.append(bwd)
+        return out
+
+    def downsample(self, x: Act, pre):
+        """3x3 stride-2 conv (Downsample2D) as nine row-shifted panels over a space-to-depth copy."""
+        ps, cfg = self.ps, self.cfg
+        C, B, Ho, Wo = x.c, x.n, x.h // 2, x.w // 2
+        z = self._act(self._name(pre + ".z"), B, Ho, Wo, 4 * C)
+        lib.call("siss_space_to_depth", x.data, z.data, B, x.h, x.w, C)
+        wp = Wo + 2
+        shifts, coffs = [], []
+        for ky in range(3):
+            for kx in range(3):
+                if cfg.downsample_padding == 0:      # F.pad (0,1,0,1) then stride-2, pad 0
+                    dy_, py, dx_, px = ky >> 1, ky & 1, kx >> 1, kx & 1
+                else:                                # stride-2, pad 1
+                    dy_, py, dx_, px = (ky - 1) >> 1, (ky - 1) & 1, (kx - 1) >> 1, (kx - 1) & 1
+                shifts.append(dy_ * wp + dx_)
+                coffs.append((py * 2 + px) * C)
+        w = ps.sh(pre + ".conv.weight")
+        y = self._act(self._name(pre + ".y"), B, Ho, Wo, C)
+        ops.gemm_nt(lib.ptr(z.data), 4 * C, w, lib.ptr(y.data), C, z.rows, C, C, shifts, coffs,
+                    bias=ps.p(pre + ".conv.bias"), rows_per_image=z.rows_per_image, hp=z.hp, wp=z.wp)
+
+        def bwd():
+            nb, gb = self.nb, self.gbase
+            dy = self._take(y)
+            lib.call("siss_colsum", dy.data, self.set_images * dy.rows_per_image, C, self.nsets, ps.total,
+                     ps.g(pre + ".conv.bias", gb), None)
+            dW = ps.grads[gb:, ps.specs[pre + ".conv.weight"].off:]
+            self._wgrad(dy, z, dW, C, C, 3, shifts=shifts, coffs=coffs, ldx=4 * C)
+            dz = self._get(nb, Ho, Wo, 4 * C)
+            wT = self.wT[pre + ".conv.weight"]          # [9][Ci][Co], index 8 - tap holds W[tap]^T
+            seen = set()
+            for tap in range(9):
+                plane = coffs[tap] // C
+                cptr = lib.ptr(dz.data[:, plane * C:])
+                ops.gemm_nt(lib.ptr(dy.data), C, wT[8 - tap:], cptr, 4 * C, dy.rows, C, C, [-shifts[tap]], [0],
+                            res_ptr=cptr if plane in seen else None, ldr=4 * C,
+                            rows_per_image=dy.rows_per_image, hp=dy.hp, wp=dy.wp)
+                seen.add(plane)
+            self._put(dy)
+            acc = self.gmap.get(id(x))
+            dx = acc if acc is not None else self._get(nb, x.h, x.w, C)
+            lib.call("siss_depth_to_space", dz.data, dx.data, int(acc is not None), nb, x.h, x.w, C)
+            self.gmap[id(x)] = dx
+            self._put(dz)
+        self.tape.append(bwd)
+        return y
+
+    def upsample(self, x: Act, pre):
+        ps = self.ps
+        C, B = x.c, x.n
+        u = self._act(self._name(pre + ".u"), B, 2 * x.h, 2 * x.w, C)
+        lib.call("siss_upsample2x", x.data, u.data, B, x.h, x.w, C)
+        y, c_b = self.conv(u, pre + ".conv")
+
+        def bwd():
+            dy = self._take(y)
+            du = c_b(dy)
+            self._put(dy)
+            dx = self._get(self.nb, x.h, x.w, C)
+            lib.call("siss_upsample2x_bwd", du.data, dx.data, self.nb, x.h, x.w, C)
+            self._put(du)
+            self._give(x, dx)
+        self.tape.append(bwd)
+        return y
+
+    def concat(self, a: Act, b: Act):
+        out = self._act(self._name("cat"), a.n, a.h, a.w, a.c + b.c)
+        lib.call("siss_concat", a.data, b.data, out.data, a.n, a.h, a.w, a.c, b.c)
+
+        def bwd():
+            nb = self.nb
+            dcat = self._take(out)
+            da = self._get(nb, a.h, a.w, a.c)
+            accb = self.gmap.get(id(b))
+            db = accb if accb is not None else self._get(nb, b.h, b.w, b.c)
+            lib.call("siss_concat_bwd", dcat.data, da.data, db.data, int(accb is not None), nb, a.h, a.w, a.c, b.c)
+            self.gmap[id(b)] = db
+            self._put(dcat)
+            self._give(a, da)
+        self.tape.append(bwd)
+        return out
+
+    # ------------------------------------------------------------------ whole network
+    def forward(self, x, t):
+        """x: [N, Cin, H, W] f32/bf16 NCHW (device), t: [N] int64.  Returns pred [N, Cout, H, W] f32."""
+        cfg, ps = self.cfg, self.ps
+        assert x.is_cuda and x.dim() == 4 and x.is_contiguous()
+        N, cin, H, W = x.shape
+        assert cin == cfg.in_channels
+        self.tape, self.gmap, self._uid = [], {}, 0
+        self.nf = N
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        self.time_embed(t)
+        # conv_in: im2col rows (K = 9*Cin padded to 64) then a one-panel GEMM
+        kp = ps.specs["conv_in.weight"].native_shape[1]
+        col = self._act("conv_in.col", N, H, W, kp)
+        lib.call("siss_im2col3x3", x, int(x.dtype == torch.bfloat16), col.data, N, cin, H, W, kp)
+        c0 = cfg.block_out_channels[0]
+        h = self._act("conv_in.out", N, H, W, c0)
+        ops.gemm_nt(lib.ptr(col.data), kp, ps.sh("conv_in.weight"), lib.ptr(h.data), c0, col.rows, c0, kp, [0], [0],
+                    bias=ps.p("conv_in.bias"), rows_per_image=col.rows_per_image, hp=col.hp, wp=col.wp)
+        h0 = h
+
+        def conv_in_bwd():
+            dh = self._take(h0)
+            lib.call("siss_colsum", dh.data, self.set_images * dh.rows_per_image, c0, self.nsets, ps.total,
+                     ps.g("conv_in.bias", self.gbase), None)
+            dW = ps.grads[self.gbase:, ps.specs["conv_in.weight"].off:]
+            self._wgrad(dh, col, dW, c0, kp, 1)
+            self._put(dh)
+        self.tape.append(conv_in_bwd)
+
+        skips = [h]
+        for (i, cin_b, cout_b, attn, down) in self.plan_down:
+            for j in range(cfg.layers_per_block):
+                h = self.resnet(h, f"down_blocks.{i}.resnets.{j}")
+                if attn:
+                    h = self.attention(h, f"down_blocks.{i}.attentions.{j}")
+                skips.append(h)
+            if down:
+                h = self.downsample(h, f"down_blocks.{i}.downsamplers.0")
+                skips.append(h)
+        h = self.resnet(h, "mid_block.resnets.0")
+        h = self.attention(h, "mid_block.attentions.0")
+        h = self.resnet(h, "mid_block.resnets.1")
+        for (i, cout_b, attn, up, rs) in self.plan_up:
+            for j in range(len(rs)):
+                h = self.concat(h, skips.pop())
+                h = self.resnet(h, f"up_blocks.{i}.resnets.{j}")
+                if attn:
+                    h = self.attention(h, f"up_blocks.{i}.attentions.{j}")
+            if up:
+                h = self.upsample(h, f"up_blocks.{i}.upsamplers.0")
+        assert not skips
+        a, gn_b = self.gn(h, "conv_norm_out", True)
+        co = cfg.out_channels
+        pred = self._buf("pred", (N, co, H, W))
+        lib.call("siss_conv_out_fprop", a.data, ps.p("conv_out.weight"), ps.p("conv_out.bias"), pred, N, H, W, c0, co)
+        hl = h
+
+        def head_bwd():
+            c = self.cot
+            nb = self.nb
+            gb = self.gbase
+            off = ps.specs["conv_out.weight"].off
+            lib.call("siss_conv_out_wgrad", c, a.data, ps.grads[gb:, off:], ps.g("conv_out.bias", gb), self.nsets,
+                     self.set_images, a.n, ps.total, ps.total, H, W, c0, co)
+            da = self._get(nb, H, W, c0)
+            lib.call("siss_conv_out_dgrad", c, ps.p("conv_out.weight"), da.data, nb, H, W, c0, co)
+            dh = gn_b(da)
+            self._put(da)
+            self._give(hl, dh)
+        self.tape.append(head_bwd)
+        return pred
+
+    def zero_grad(self):
+        self.ps.grads.zero_()
+
+    def backward(self, cot, nsets=2, grad_base_set=0):
+        """cot: [nb, Cout, H, W] f32 cotangent of pred, nb = nsets * set_images.  With the shared
+        forward (SISS) nb = 2*N: rows [0,N) seed g_x and rows [N,2N) seed g_a.  Gradients are
+        ACCUMULATED into ps.grads[grad_base_set + set] (call zero_grad() at the start of a step)."""
+        assert cot.is_cuda and cot.dtype == torch.float32 and cot.is_contiguous()
+        nb = cot.shape[0]
+        assert nb % nsets == 0 and nb % self.nf == 0
+        self.nb, self.nsets, self.set_images, self.gbase, self.cot = nb, nsets, nb // nsets, grad_base_set, cot
+        d_s = self._buf("temb.d_s", (nb, self.temb_dim))
+        d_s.zero_()
+        for fn in reversed(self.tape):
+            fn()
+        assert not self.gmap, f"{len(self.gmap)} dangling cotangents"
