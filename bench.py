@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""SISS unlearning-step benchmark (BASELINE.json metric: unlearning-steps/sec + samples/sec,
+CelebA-HQ 256x256 DDPM, SISS lambd=0.5, bf16, bs=16 per GPU, 1/2/4/8 GPUs).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one optimizer update of delete_celeb.py:557-773 with gradient accumulation 1:
+fused mixture/IS-weight kernel -> UNet forward -> fused loss-seed kernel -> dual-cotangent UNet
+backward -> (N>1: ONE all-reduce of [g_x ; g_a]) -> norm-fix + clip + AdamW.  Inputs are synthetic
+(x0 ~ U[-1,1], a0 = one image repeated, noise ~ N(0,1), t = 999, u ~ U[0,1)), resident in HBM
+before the timed region; weights are random-init at the exact google/ddpm-celebahq-256 shapes.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_GFLOP_PER_SAMPLE = 498.35          # SURVEY.md §8d (2*MAC: conv + linear + attention matmuls + GN)
+PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE: 16)")
+    ap.add_argument("--config", default="celebahq256", choices=["celebahq256", "small"])
+    ap.add_argument("--loss-fn", default="importance_sampling_with_mixture")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("SISS_GRAPH", "1")),
+                    help="replay the step from a captured hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+CPU_SAMPLE_BATCH = 2
+
+
+def cpu_baseline(cfg_kw, seed):
+    """The oracle (CPU restatement pinned by the reference's golden vectors) timed on the host cores
+    on a bounded sample: ONE optimizer step at batch CPU_SAMPLE_BATCH (1/8 of the GPU workload), fp32."""
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    from oracle.unet import OracleUNet2D, UNetConfig
+    # usable cores: the affinity mask (a container may expose far fewer than os.cpu_count()), capped at
+    # 32 threads -- beyond that torch's CPU convolutions stop scaling and oversubscription can stall.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:                                   # cgroup v2 CPU quota ("max" or "<quota> <period>")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            avail = min(avail, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    cores = max(1, min(avail, 32))
+    torch.set_num_threads(cores)
+    net = OracleUNet2D(UNetConfig(**cfg_kw))
+    g = torch.Generator().manual_seed(seed)
+    hw = cfg_kw["sample_size"]
+    c = cfg_kw["in_channels"]
+    nb = CPU_SAMPLE_BATCH
+    x0 = torch.rand(nb, c, hw, hw, generator=g) * 2 - 1
+    a0 = (torch.rand(1, c, hw, hw, generator=g) * 2 - 1).repeat(nb, 1, 1, 1)
+    noise = torch.randn(nb, c, hw, hw, generator=g)
+    t = torch.full((nb,), 999, dtype=torch.long)
+    u = torch.rand(nb, generator=g)
+    ac = S.alphas_cumprod()
+    opt = torch.optim.AdamW(net.parameters(), lr=5e-6, betas=(0.95, 0.999), weight_decay=1e-6)
+    L = OracleDeletionLoss(*S.gamma_sigma(ac))
+    t0 = time.perf_counter()
+    unlearning_step(net, opt, L, "importance_sampling_with_mixture", ac,
+                    [dict(x0=x0, a0=a0, noise=noise, t=t, u=u)], train_batch_size=nb, scaling_norm=500.0,
+                    loss_params={"lambd": 0.5})
+    dt = time.perf_counter() - t0
+    return dt, cores
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" IS RCCL on ROCm
+        pg = dist.group.WORLD
+
+    from siss_amd import lib
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.step import SISSStepper
+    from siss_amd.unet import UNetEngine
+
+    if a.config == "celebahq256":
+        cfg = UNet2DConfig.celebahq256()
+    else:
+        cfg = UNet2DConfig(sample_size=64, block_out_channels=(128, 128, 256),
+                           down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D"))
+    B, hw, cin = a.batch, cfg.sample_size, cfg.in_channels
+    eng = UNetEngine(cfg, dev)
+    eng.init_random(seed=42)                       # same weights on every rank (config/delete_celeb.yaml:4)
+    ac = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, 1000, dtype=torch.float32), 0)
+    st = SISSStepper(eng, ac, lr=5e-6, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,   # delete_celeb.yaml:127-133
+                     scaling_norm=500.0, lambd=0.5, train_batch_size=B, grad_accum=1, loss_fn=a.loss_fn,
+                     process_group=pg, mixed_precision="bf16")
+    g = torch.Generator(device=dev).manual_seed(42 + rank)      # per-rank shard of the synthetic stream
+    x0 = (torch.rand(B, cin, hw, hw, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+    a0 = (torch.rand(1, cin, hw, hw, generator=g, device=dev) * 2 - 1).repeat(B, 1, 1, 1).to(torch.bfloat16)
+    noise = torch.randn(B, cin, hw, hw, generator=g, device=dev).to(torch.bfloat16)
+    t = torch.full((B,), 999, dtype=torch.long, device=dev)
+    u = torch.rand(B, generator=g, device=dev)
+
+    def one_step():
+        st.step(x0, a0, noise, t, u)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 1)):
+        one_step()
+    sync()
+    graph = None
+    if a.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            one_step()                              # settle allocations on the capture stream
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                one_step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        sync()
+    run = graph.replay if graph is not None else one_step
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / a.steps * 1e3
+    stats = st.stats()
+
+    # ---- per-kernel timing of the dominant kernels (eager, HIP events on the launch stream) ----
+    roof = None
+    kern = {}
+    if not a.no_kernel_timing and rank == 0:
+        lib.PROF = []
+        ksteps = min(a.steps, 3)
+        for _ in range(ksteps):
+            one_step()
+        torch.cuda.synchronize()
+        prof, lib.PROF = lib.PROF, None
+        for name, s, e, work in prof:
+            d = kern.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1; d[1] += s.elapsed_time(e); d[2] += work
+        tot_ms = sum(v[1] for v in kern.values())
+        dom = max(("siss_gemm_nt", "siss_gemm_tn"), key=lambda k: kern.get(k, [0, 0, 0])[1])
+        n, tms, work = kern[dom]
+        ach = work / (tms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n // ksteps, "avg_launch_us": round(tms / n * 1e3, 2),
+                "share_of_step_kernel_time": round(tms / tot_ms, 3)}
+        other = "siss_gemm_tn" if dom == "siss_gemm_nt" else "siss_gemm_nt"
+        if other in kern:
+            n2, t2, w2 = kern[other]
+            roof["second"] = {"kernel": other, "achieved": round(w2 / (t2 * 1e-3) / 1e12, 2),
+                              "share_of_step_kernel_time": round(t2 / tot_ms, 3)}
+
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        cfg_kw = {k: getattr(cfg, k) for k in ("sample_size", "in_channels", "out_channels", "block_out_channels",
+                                                "down_block_types", "up_block_types", "layers_per_block",
+                                                "attention_head_dim", "norm_num_groups", "norm_eps",
+                                                "downsample_padding", "flip_sin_to_cos", "freq_shift")}
+        cdt, cores = cpu_baseline(cfg_kw, 42)
+        cpu = {"value": round(CPU_SAMPLE_BATCH / cdt, 5), "unit": "samples/sec", "cores": cores, "kind": "port",
+               "sample": f"1 optimizer step at batch {CPU_SAMPLE_BATCH} ({CPU_SAMPLE_BATCH}/{B} of the per-GPU "
+                         f"batch) of the same UNet/resolution, fp32 torch CPU oracle, {cdt:.1f} s",
+               "steps_per_sec_at_bs%d" % B: round(CPU_SAMPLE_BATCH / (cdt * B), 6)}
+
+    if rank == 0:
+        steps_per_sec = 1e3 / ms
+        step_tflop = 5 * FWD_GFLOP_PER_SAMPLE * B / 1e3 if a.config == "celebahq256" else None
+        out = {
+            "metric": "unlearning samples/sec (= unlearning-steps/sec x batch x gpus), CelebA-HQ-256 DDPM SISS",
+            "value": round(steps_per_sec * B * world, 3), "unit": "samples/sec", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "steps_per_sec": round(steps_per_sec, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "delete_celeb.yaml: CelebA-HQ 256x256 DDPM UNet (113.7M params), SISS lambd=0.5, "
+                                   "t=999, bf16, bs=%d/GPU, GA=1, scaling_norm=500, AdamW lr 5e-6" % B
+                       if a.config == "celebahq256" else "small 64x64 dev config",
+                       "loss_fn": a.loss_fn, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "hipgraph": bool(a.graph)},
+            "step_tflop_algorithmic": step_tflop,
+            "step_mfma_frac": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if step_tflop else None,
+            "roofline": roof, "cpu_baseline": cpu,
+            "step_scalars": {k: stats[k] for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm")},
+            "kernel_ms_per_step": {k: round(v[1] / max(min(a.steps, 3), 1), 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

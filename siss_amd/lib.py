@@ -93,12 +93,33 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-launch timing (bench.py): when PROF is a list, every call is bracketed by events on
+# the launch stream and (name, start, end, work) is appended.  work = algorithmic flops of the launch
+# for the two MFMA GEMM kernels, 0 otherwise.
+PROF = None
+
+
+def _work(name, a):
+    if name == "siss_gemm_nt":      # 2 * M * N * Kp * npanels * batch
+        return 2.0 * a[9] * a[10] * a[11] * a[12] * a[19]
+    if name == "siss_gemm_tn":      # 2 * N * C * npanels * nsets * rows
+        return 2.0 * a[6] * a[7] * a[8] * a[11] * (a[15] - a[14])
+    return 0.0
+
+
 def call(name, *args):
     """Call a launcher on torch's current stream; tensors are passed as raw pointers."""
     lib = load()
     fn = getattr(lib, name)
     conv = [ptr(a) if (torch.is_tensor(a) or a is None) else a for a in args]
-    rc = fn(*conv, stream_ptr())
+    if PROF is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*conv, stream_ptr())
+        e.record()
+        PROF.append((name, s, e, _work(name, args)))
+    else:
+        rc = fn(*conv, stream_ptr())
     if rc != 0:
         raise RuntimeError(f"{name} failed with status {rc} "
                            f"({'bad argument' if rc == 1 else 'launch error'})")
