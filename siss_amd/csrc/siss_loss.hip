@@ -139,6 +139,36 @@ __global__ __launch_bounds__(kThreads) void mixture_main_kernel(
     }
 }
 
+// Class-surface variant: the caller already holds both noisy batches (the reference's
+// all_samples_dict / deletion_samples_dict 'noisy_latents'); only the row select + distances remain.
+template <bool BF16>
+__global__ __launch_bounds__(kThreads) void mixture_select_kernel(
+    const void* __restrict__ nk, const void* __restrict__ nf, const void* __restrict__ x0,
+    const void* __restrict__ a0, const int64_t* __restrict__ t, const float* __restrict__ u,
+    const float* __restrict__ gamma_tab, float lambd, long chw, void* __restrict__ x_mix,
+    double* __restrict__ partials) {
+    __shared__ double sh[2 * kThreads / 64];
+    const int n = blockIdx.y;
+    const float gamma = gamma_tab[t[n]];
+    const bool keep = u[n] > lambd;
+    const long base = (long)n * chw;
+    double sx = 0, sa = 0;
+    for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < chw; k += (long)gridDim.x * kThreads) {
+        const long e = base + k;
+        const float m = keep ? Ld<BF16>::load1(nk, e) : Ld<BF16>::load1(nf, e);
+        const float x = Ld<BF16>::load1(x0, e), a = Ld<BF16>::load1(a0, e);
+        const float rx = __fsub_rn(m, __fmul_rn(gamma, x)), ra = __fsub_rn(m, __fmul_rn(gamma, a));
+        sx += (double)__fmul_rn(rx, rx);
+        sa += (double)__fmul_rn(ra, ra);
+        Ld<BF16>::store1(x_mix, e, m);
+    }
+    block_reduce2(sx, sa, sh);
+    if (threadIdx.x == 0) {
+        double* p = partials + ((long)n * gridDim.x + blockIdx.x) * 2;
+        p[0] = sx; p[1] = sa;
+    }
+}
+
 // One thread per sample: fold the partial slab, then ddpm_deletion_loss.py:33-45 literally.
 __global__ void mixture_finalize_kernel(const double* __restrict__ partials, int nblk,
                                         const int64_t* __restrict__ t, const float* __restrict__ gamma_tab,
@@ -269,6 +299,26 @@ int siss_mixture_fwd(const void* x0, const void* a0, const void* noise, int in_b
         mixture_main_kernel<true><<<grid, kThreads, 0, s>>>(x0, a0, noise, t, u, alphas_cumprod, gamma_tab, lambd, chw, x_mix, partials);
     else
         mixture_main_kernel<false><<<grid, kThreads, 0, s>>>(x0, a0, noise, t, u, alphas_cumprod, gamma_tab, lambd, chw, x_mix, partials);
+    mixture_finalize_kernel<<<cdiv(B, 64), 64, 0, s>>>(partials, nblk, t, gamma_tab, sigma_tab, lambd, B,
+                                                       gamma_t, sigma_t, dist_x, dist_a, iw_x, iw_a);
+    SISS_LAUNCH_RET();
+}
+
+// Same outputs as siss_mixture_fwd, but from caller-provided noisy batches (DDPMDeletionLoss surface).
+int siss_mixture_select(const void* noisy_keep, const void* noisy_forget, const void* x0, const void* a0,
+                        int in_bf16, const int64_t* t, const float* u, const float* gamma_tab,
+                        const float* sigma_tab, float lambd, int B, long chw, void* x_mix, float* gamma_t,
+                        float* sigma_t, float* dist_x, float* dist_a, float* iw_x, float* iw_a,
+                        double* partials, void* stream) {
+    SISS_CHECK_ARG(noisy_keep && noisy_forget && x0 && a0 && t && u && gamma_tab && sigma_tab && x_mix);
+    SISS_CHECK_ARG(gamma_t && sigma_t && dist_x && dist_a && iw_x && iw_a && partials && B > 0 && chw > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = blocks_for(chw);
+    dim3 grid(nblk, B);
+    if (in_bf16)
+        mixture_select_kernel<true><<<grid, kThreads, 0, s>>>(noisy_keep, noisy_forget, x0, a0, t, u, gamma_tab, lambd, chw, x_mix, partials);
+    else
+        mixture_select_kernel<false><<<grid, kThreads, 0, s>>>(noisy_keep, noisy_forget, x0, a0, t, u, gamma_tab, lambd, chw, x_mix, partials);
     mixture_finalize_kernel<<<cdiv(B, 64), 64, 0, s>>>(partials, nblk, t, gamma_tab, sigma_tab, lambd, B,
                                                        gamma_t, sigma_t, dist_x, dist_a, iw_x, iw_a);
     SISS_LAUNCH_RET();

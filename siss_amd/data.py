@@ -1,0 +1,127 @@
+"""Input side of the hot path: transforms, datasets, samplers.
+
+Restates data/utils/infinite_sampler.py:4-35 and data/utils/repeat_sampler.py:4-21 with the
+rank / num_replicas arguments actually wired (the reference never passes them, so all of its
+ranks read identical batches -- SURVEY.md §5), plus a synthetic source for benchmarking.
+"""
+import os
+
+import numpy as np
+import torch
+
+
+class ToTensor:
+    def __call__(self, img):
+        a = np.asarray(img, dtype=np.float32) / 255.0
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return torch.from_numpy(a).permute(2, 0, 1).contiguous()
+
+
+class Normalize:
+    def __init__(self, mean, std):
+        self.mean, self.std = list(mean), list(std)
+
+    def __call__(self, x):
+        m = torch.tensor(self.mean, dtype=x.dtype).view(-1, 1, 1)
+        s = torch.tensor(self.std, dtype=x.dtype).view(-1, 1, 1)
+        return (x - m) / s
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+class CelebAHQ(torch.utils.data.Dataset):
+    """Directory of jpgs with filter in {all, deletion, nondeletion} (data/src/celeb_dataset.py:5-36)."""
+
+    def __init__(self, filter, data_path, remove_img_names, transform=None):
+        from PIL import Image
+        self._open = Image.open
+        names = sorted(f for f in os.listdir(data_path) if f.lower().endswith((".jpg", ".png")))
+        remove = set(remove_img_names)
+        if filter == "deletion":
+            names = [n for n in names if n in remove]
+        elif filter == "nondeletion":
+            names = [n for n in names if n not in remove]
+        elif filter != "all":
+            raise ValueError(filter)
+        self.paths = [os.path.join(data_path, n) for n in names]
+        self.transform = transform
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, i):
+        img = self._open(self.paths[i]).convert("RGB")
+        return self.transform(img) if self.transform else img
+
+
+class SyntheticImages(torch.utils.data.Dataset):
+    """x ~ U[-1,1] images of a fixed shape (ToTensor+Normalize(0.5,0.5) range); deterministic per index."""
+
+    def __init__(self, n, shape, seed=0):
+        self.n, self.shape, self.seed = n, tuple(shape), seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1_000_003 + int(i))
+        return torch.rand(self.shape, generator=g) * 2 - 1
+
+
+class InfiniteSampler(torch.utils.data.Sampler):
+    """Infinite windowed shuffle; rank r of R takes every R-th index."""
+
+    def __init__(self, dataset, rank=0, num_replicas=1, shuffle=True, seed=0, window_size=0.5):
+        assert len(dataset) > 0 and num_replicas > 0 and 0 <= rank < num_replicas and 0 <= window_size <= 1
+        self.dataset, self.rank, self.num_replicas = dataset, rank, num_replicas
+        self.shuffle, self.seed, self.window_size = shuffle, seed, window_size
+
+    def __iter__(self):
+        order = np.arange(len(self.dataset))
+        rnd, window = None, 0
+        if self.shuffle:
+            rnd = np.random.RandomState(self.seed)
+            rnd.shuffle(order)
+            window = int(np.rint(order.size * self.window_size))
+        idx = 0
+        while True:
+            i = idx % order.size
+            if idx % self.num_replicas == self.rank:
+                yield int(order[i])
+            if window >= 2:
+                j = (i - rnd.randint(window)) % order.size
+                order[i], order[j] = order[j], order[i]
+            idx += 1
+
+
+class RepeatedSampler(torch.utils.data.Sampler):
+    """Each index num_repeats times, in order (the celeb forget set is one image repeated)."""
+
+    def __init__(self, data_source, num_repeats):
+        self.data_source, self.num_repeats = data_source, num_repeats
+
+    def __len__(self):
+        return len(self.data_source) * self.num_repeats
+
+    def __iter__(self):
+        return iter(torch.arange(len(self.data_source)).repeat_interleave(self.num_repeats).tolist())
+
+
+def batches(dataset, sampler, batch_size):
+    """Endless batch iterator (stack of dataset[i])."""
+    buf = []
+    while True:
+        for i in sampler:
+            buf.append(dataset[i])
+            if len(buf) == batch_size:
+                yield torch.stack(buf)
+                buf = []

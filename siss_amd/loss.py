@@ -93,3 +93,119 @@ def mse_bwd_seed(pred, target, scale, want_loss=False, partials=None):
     lib.call("siss_mse_bwd_seed", pred, target.contiguous(), int(target.dtype == torch.bfloat16), float(scale),
              B, chw, c, loss, sums, partials)
     return c, loss, sums
+
+
+# --------------------------------------------------------------------------------------------
+# Drop-in class surface of the reference (losses/ddpm_deletion_loss.py:3-122)
+# --------------------------------------------------------------------------------------------
+def mixture_select(noisy_keep, noisy_forget, x0, a0, t, u, gamma_tab, sigma_tab, lambd):
+    assert noisy_keep.is_cuda and noisy_keep.shape == noisy_forget.shape == x0.shape == a0.shape
+    dt = noisy_keep.dtype
+    nk, nf, x0, a0 = (v.to(dt).contiguous() for v in (noisy_keep, noisy_forget, x0, a0))
+    B, chw, dev = nk.shape[0], nk[0].numel(), nk.device
+    f = lambda: torch.empty(B, dtype=torch.float32, device=dev)
+    m = Mixture(torch.empty_like(nk), f(), f(), f(), f(), f(), f())
+    lib.call("siss_mixture_select", nk, nf, x0, a0, int(dt == torch.bfloat16),
+             t.to(device=dev, dtype=torch.int64).contiguous(), u.to(device=dev, dtype=torch.float32).contiguous(),
+             gamma_tab, sigma_tab, float(lambd), B, chw, m.x_mix, m.gamma_t, m.sigma_t, m.dist_x, m.dist_a,
+             m.iw_x, m.iw_a, _partials(B, chw, dev))
+    return m
+
+
+class _SissTerms(torch.autograd.Function):
+    """(loss_x, loss_a) = ((pred-eps_x)^2, (pred-eps_a)^2) from the fused HIP kernel; autograd-connected to pred."""
+
+    @staticmethod
+    def forward(ctx, pred, m, x0, a0):
+        pred32 = pred.float().contiguous()
+        one = torch.ones_like(m.iw_x)
+        unit = Mixture(m.x_mix, m.gamma_t, m.sigma_t, m.dist_x, m.dist_a, one, one)
+        s = loss_bwd_seed(pred32, unit, x0, a0, scale=1.0, want_losses=True)
+        ctx.save_for_backward(s.c_x, s.c_a)          # = 2 (pred - eps_x), 2 (pred - eps_a)
+        return s.loss_x, s.loss_a
+
+    @staticmethod
+    def backward(ctx, gx, ga):
+        cx, ca = ctx.saved_tensors
+        return gx * cx + ga * ca, None, None, None
+
+
+class _MseTerm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        c, loss, _ = mse_bwd_seed(pred.float().contiguous(), target, scale=1.0, want_loss=True)
+        ctx.save_for_backward(c)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.saved_tensors[0], None
+
+
+def _b(v, like):
+    return v.reshape(-1, *([1] * (like.dim() - 1)))
+
+
+class DDPMDeletionLoss:
+    """Same constructor, method names, parameter names and 7-tuple returns as the reference class.
+    ``unet`` is any callable with the diffusers contract (``siss_amd.model.UNet2DModel`` for the HIP
+    network).  The elementwise math runs in the fused HIP kernels; results are autograd-connected."""
+
+    def __init__(self, gamma, sigma):
+        self.all_gamma = gamma
+        self.all_sigma = sigma
+
+    def _keep_uniforms(self, batch_size):
+        return torch.rand(batch_size)        # CPU default generator, as ddpm_deletion_loss.py:18 / :101
+
+    def importance_sampling_with_mixture(self, unet, timesteps, noise, conditioning, all_samples_dict,
+                                         deletion_samples_dict, lambd):
+        nk, nf = all_samples_dict["noisy_latents"], deletion_samples_dict["noisy_latents"]
+        u = self._keep_uniforms(nk.shape[0])
+        dev = nk.device
+        m = mixture_select(nk, nf, all_samples_dict["og_latents"], deletion_samples_dict["og_latents"], timesteps,
+                           u, self.all_gamma.to(dev).float().contiguous(), self.all_sigma.to(dev).float().contiguous(),
+                           lambd)
+        pred = unet(m.x_mix, timesteps, **conditioning, return_dict=False)[0]
+        dt = m.x_mix.dtype
+        loss_x, loss_a = _SissTerms.apply(pred, m, all_samples_dict["og_latents"].to(dt).contiguous(),
+                                          deletion_samples_dict["og_latents"].to(dt).contiguous())
+        return (None, loss_x, loss_a, m.iw_x, m.iw_a, _b(m.iw_x, loss_x) * loss_x, _b(m.iw_a, loss_a) * loss_a)
+
+    def double_forward_with_neg_del(self, unet, timesteps, noise, conditioning, all_samples_dict,
+                                    deletion_samples_dict):
+        lx = _MseTerm.apply(unet(all_samples_dict["noisy_latents"], timesteps, **conditioning, return_dict=False)[0], noise)
+        la = _MseTerm.apply(unet(deletion_samples_dict["noisy_latents"], timesteps, **conditioning, return_dict=False)[0], noise)
+        return None, lx, la, None, None, lx, la
+
+    def erasediff(self, unet, timesteps, noise, conditioning, all_samples_dict, deletion_samples_dict):
+        lx = _MseTerm.apply(unet(all_samples_dict["noisy_latents"], timesteps, **conditioning, return_dict=False)[0], noise)
+        pa = unet(deletion_samples_dict["noisy_latents"], timesteps, **conditioning, return_dict=False)[0]
+        la = _MseTerm.apply(pa, torch.rand_like(pa))
+        return None, lx, la, None, None, lx, la
+
+    def simple_neg_del(self, unet, timesteps, noise, conditioning, all_samples_dict, deletion_samples_dict,
+                       superfactor):
+        la = _MseTerm.apply(unet(deletion_samples_dict["noisy_latents"], timesteps, **conditioning, return_dict=False)[0], noise)
+        return -superfactor * la, None, la, None, None, None, None
+
+    def naive_del(self, unet, timesteps, noise, conditioning, all_samples_dict, deletion_samples_dict):
+        lx = _MseTerm.apply(unet(all_samples_dict["noisy_latents"], timesteps, **conditioning, return_dict=False)[0], noise)
+        return lx, lx, None, None, None, None, None
+
+    def subscore_bernoulli(self, unet, timesteps, noise, conditioning, all_samples_dict, deletion_samples_dict,
+                           lambd):
+        nk, nf = all_samples_dict["noisy_latents"], deletion_samples_dict["noisy_latents"]
+        keep = (self._keep_uniforms(nk.shape[0]) > lambd).to(nk.device)
+        x = torch.where(_b(keep, nk), nk, nf)
+        loss = _MseTerm.apply(unet(x, timesteps, **conditioning, return_dict=False)[0], noise)
+        loss_x = (1 / (1 - lambd)) * loss[keep]
+        loss_a = loss[~keep]
+        if len(loss_x) == 0:
+            print("no nondeletion samples")
+            loss_x = torch.zeros(1, 1, 1, 1, requires_grad=True)
+            loss_a = torch.zeros(1, 1, 1, 1, requires_grad=True)
+        if len(loss_a) == 0:
+            print("no deletion samples")
+            loss_a = torch.zeros(1, 1, 1, 1, requires_grad=True)
+        return None, loss_x, loss_a, None, None, loss_x, loss_a

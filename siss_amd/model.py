@@ -1,0 +1,128 @@
+"""Drop-in ``UNet2DModel`` object over the HIP engine (the ``unet`` contract of SURVEY.md §8b):
+callable ``unet(sample, timesteps, return_dict=False)[0]`` with an autograd-connected output,
+``named_parameters() / parameters() / train() / eval() / device / config``,
+``from_pretrained`` / ``save_pretrained`` in the diffusers on-disk format
+(``config.json`` + ``diffusion_pytorch_model.safetensors``; delete_celeb.py:137-147, :181-186).
+
+This is the compatibility surface: the reference's own loop (two ``backward`` calls with
+``retain_graph=True``, per-parameter ``.grad`` bookkeeping, torch.optim) runs against it
+unchanged.  The fast path is ``siss_amd.step.SISSStepper`` (one dual-cotangent backward).
+"""
+import json
+import os
+
+import torch
+
+from .config import UNet2DConfig
+from .unet import UNetEngine
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, sample, timesteps):
+        ctx.model = model
+        ctx.token = model._fwd_token = object()
+        return model.engine.forward(sample.contiguous(), timesteps).clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        m = ctx.model
+        if ctx.token is not m._fwd_token:
+            raise RuntimeError("UNet2DModel: backward through a stale forward (another forward ran since)")
+        eng = m.engine
+        eng.ps.grads[0].zero_()
+        eng.backward(gout.contiguous().float(), nsets=1)
+        m._accumulate_param_grads()
+        return None, None, None, None
+
+
+class UNet2DModel:
+    def __init__(self, config=None, device="cuda", **kwargs):
+        if config is None:
+            config = UNet2DConfig.from_dict(kwargs) if kwargs else UNet2DConfig.celebahq256()
+        self.config = config
+        self.engine = UNetEngine(config, device)
+        self.device = self.engine.device
+        self.dtype = torch.float32
+        self.training = True
+        self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        self._fwd_token = None
+        ps = self.engine.ps
+        self._params = {n: torch.nn.Parameter(ps.p(n)) for n in ps.specs}   # views of the flat master (native layout)
+
+    # ---- nn.Module-like surface -------------------------------------------------
+    def named_parameters(self):
+        return iter(self._params.items())
+
+    def parameters(self):
+        return iter(self._params.values())
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *a, **k):
+        return self
+
+    def requires_grad_(self, flag=True):
+        for p in self._params.values():
+            p.requires_grad_(flag)
+        return self
+
+    def _accumulate_param_grads(self):
+        ps = self.engine.ps
+        for n, p in self._params.items():
+            sp = ps.specs[n]
+            g = ps.grads[0, sp.off:sp.off + sp.numel].view(sp.native_shape)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad += g
+
+    def __call__(self, sample, timestep, return_dict=False, **unused):
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.long)
+        t = t.to(self.device).reshape(-1).expand(sample.shape[0]) if t.numel() == 1 else t.to(self.device)
+        # master weights may have been updated in place by an external optimizer: refresh operand copies
+        self.engine.refresh_weights(cast_shadow=True)
+        sample = sample.to(self.device)
+        if sample.dtype not in (torch.float32, torch.bfloat16):
+            sample = sample.float()
+        if torch.is_grad_enabled():
+            out = _UNetFn.apply(self._anchor, self, sample, t)
+        else:
+            out = self.engine.forward(sample.contiguous(), t).clone()
+        if return_dict:
+            return type("UNet2DOutput", (), {"sample": out})()
+        return (out,)
+
+    # ---- checkpoints ------------------------------------------------------------
+    def state_dict(self):
+        return self.engine.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.engine.load_state_dict(sd, strict)
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, device="cuda", **unused):
+        from safetensors.torch import load_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        if not os.path.exists(os.path.join(d, "config.json")) and os.path.exists(os.path.join(path, "unet")):
+            d = os.path.join(path, "unet")
+        m = cls(UNet2DConfig.from_json(os.path.join(d, "config.json")), device=device)
+        m.load_state_dict(load_file(os.path.join(d, "diffusion_pytorch_model.safetensors")))
+        return m
+
+    def save_pretrained(self, d):
+        from safetensors.torch import save_file
+        os.makedirs(d, exist_ok=True)
+        cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self.config).items()}
+        cfg["_class_name"] = "UNet2DModel"
+        with open(os.path.join(d, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=2)
+        save_file({k: v.contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(d, "diffusion_pytorch_model.safetensors"))

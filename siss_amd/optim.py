@@ -51,3 +51,11 @@ class FlatAdamW:
     def step(self, grads, **kw):
         self.launch(grads, **kw)
         return self.stats()
+
+
+class AdamWSpec:
+    """What ``_target_: torch.optim.AdamW`` resolves to (hydra_lite.TARGET_REMAP): the hyper-parameters of
+    config/delete_celeb.yaml:127-133, consumed by the fused flat-buffer optimizer."""
+
+    def __init__(self, params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **unused):
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(float(b) for b in betas), float(eps), float(weight_decay)

@@ -20,6 +20,7 @@ the single-process step on the concatenated batch.
 import torch
 
 from . import lib
+from .dp import allreduce_flat_grads
 from .loss import loss_bwd_seed, mixture_fwd, mse_bwd_seed
 from .optim import FlatAdamW
 from .unet import UNetEngine
@@ -95,7 +96,7 @@ class SISSStepper:
         g = self.e.ps.grads
         if self.pg is not None and self.world > 1:
             # the ONE collective of the step: sum of [g_x ; g_a] over ranks (RCCL over xGMI)
-            torch.distributed.all_reduce(g, group=self.pg)
+            allreduce_flat_grads(g, self.pg)
         self.opt.launch(g, scaling_norm=self.scaling_norm, eta=self.eta, inf_guard=self.inf_guard)
         self.e.refresh_weights()
 

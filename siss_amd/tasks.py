@@ -1,0 +1,145 @@
+"""Task classes behind the reference's entry points (main.py:9-35): ``Task.run()``,
+``delete_celeb.DeleteCeleb(cfg)``, ``delete_tshirt.DeleteTShirt(cfg)``.
+
+The loop is the hot path of delete_celeb.py:557-773 / delete_tshirt.py:501-717 driven through
+``SISSStepper`` (fused kernels, one dual-cotangent backward, one collective per optimizer step).
+Evaluation / sampling / wandb (log_metrics, delete_celeb.py:484-545) are outside this path; the
+per-step scalars the reference logs are returned by ``stepper.stats()`` and written as JSON lines.
+"""
+import json
+import os
+import time
+from abc import ABC, abstractmethod
+
+import torch
+
+from . import hydra_lite
+from .config import UNet2DConfig
+from .data import InfiniteSampler, RepeatedSampler, SyntheticImages, batches
+from .scheduler import DDPMScheduler
+from .step import SISSStepper
+
+
+class Task(ABC):
+    @abstractmethod
+    def run(self):
+        pass
+
+
+def _dist():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        pg = dist.group.WORLD
+    return world, rank, local, pg
+
+
+class _DeleteBase(Task):
+    timestep_low = 999          # delete_celeb.py:593 hard-codes randint(999, 1000)
+    inf_guard = False
+    default_unet = staticmethod(UNet2DConfig.celebahq256)
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    # -- pieces a subclass may override --------------------------------------------------------
+    def load_unet(self, device):
+        from .model import UNet2DModel
+        cfg = self.cfg
+        path = cfg.get("checkpoint_path")
+        if path and os.path.isdir(str(path)):
+            sub = (cfg.get("subfolders") or {}).get("unet")
+            return UNet2DModel.from_pretrained(path, subfolder=sub, device=device)
+        ucfg = {k: v for k, v in (cfg.get("unet") or {}).items() if not k.startswith("_")}
+        m = UNet2DModel(UNet2DConfig.from_dict(ucfg) if ucfg else self.default_unet(), device=device)
+        m.engine.init_random(seed=int(cfg.random_seed))
+        print(f"[siss_amd] checkpoint {path!r} not found on disk: random-init weights of the same architecture")
+        return m
+
+    def load_scheduler(self):
+        sc = self.cfg.get("scheduler") or {}
+        kw = {k: sc[k] for k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "prediction_type")
+              if k in sc}
+        return DDPMScheduler(**kw)
+
+    def datasets(self, shape):
+        cfg = self.cfg
+        try:
+            transform = hydra_lite.instantiate(cfg.transform)
+            ds_all = hydra_lite.instantiate(cfg.dataset_all, transform=transform)
+            ds_del = hydra_lite.instantiate(cfg.dataset_deletion, transform=transform)
+            return ds_all, ds_del
+        except Exception as e:      # datasets are not in the repo (reference .gitignore:7): synthetic stand-in
+            print(f"[siss_amd] dataset unavailable ({type(e).__name__}: {e}); using synthetic images")
+            return SyntheticImages(4096, shape, seed=1), SyntheticImages(1, shape, seed=2)
+
+    # -- the loop ------------------------------------------------------------------------------
+    def run(self):
+        cfg = self.cfg
+        world, rank, local, pg = _dist()
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        torch.manual_seed(int(cfg.random_seed) + rank)
+        unet = self.load_unet(device)
+        eng = unet.engine
+        sched = self.load_scheduler()
+        opt = hydra_lite.instantiate(cfg.optimizer)
+        d = cfg.deletion
+        B, ga = int(cfg.train_batch_size), int(cfg.gradient_accumulation_steps)
+        stepper = SISSStepper(
+            eng, sched.alphas_cumprod, lr=opt.lr, betas=opt.betas, eps=opt.eps, weight_decay=opt.weight_decay,
+            scaling_norm=float(d.scaling_norm) if d.loss_fn != "erasediff" else None,
+            eta=float(d.eta) if d.loss_fn == "erasediff" else None,
+            lambd=float((d.loss_params or {}).get("lambd", 0.5)), train_batch_size=B, grad_accum=ga,
+            loss_fn=d.loss_fn, inf_guard=self.inf_guard, process_group=pg,
+            mixed_precision=cfg.get("mixed_precision"))
+        shape = (unet.config.in_channels, unet.config.sample_size, unet.config.sample_size)
+        ds_all, ds_del = self.datasets(shape)
+        it_all = batches(ds_all, InfiniteSampler(ds_all, rank=rank, num_replicas=world), B)
+        it_del = batches(ds_del, self.deletion_sampler(ds_del, B), B)
+        n_steps = int(cfg.training_steps) * max(1, len(d.get("img_name") or [1]))
+        os.makedirs(cfg.output_dir, exist_ok=True)
+        log = open(os.path.join(cfg.output_dir, f"train_log_rank{rank}.jsonl"), "a")
+        g = torch.Generator(device=device).manual_seed(int(cfg.random_seed) + rank)
+        T = sched.config.num_train_timesteps
+        t0 = time.perf_counter()
+        for step in range(n_steps):
+            for _ in range(ga):
+                x0 = next(it_all).to(device, non_blocking=True)
+                a0 = next(it_del).to(device, non_blocking=True)
+                noise = torch.randn(x0.shape, device=device, generator=g)           # SAME noise for both batches
+                t = torch.randint(self.timestep_low, T, (B,), device=device, generator=g)
+                u = torch.rand(B, device=device, generator=g)
+                stepper.micro_step(x0, a0, noise, t, u)
+            st = stepper.stats()
+            st["global_step"] = step + 1
+            st["elapsed_s"] = time.perf_counter() - t0
+            log.write(json.dumps(st) + "\n")
+            log.flush()
+            if rank == 0:
+                print(f"step {step + 1}/{n_steps}  |g_x| {st['norm_loss_x']:.4g}  |g_a| {st['norm_loss_a']:.4g}  "
+                      f"s {st['scaling_factor']:.4g}")
+        if rank == 0:
+            unet.save_pretrained(os.path.join(cfg.output_dir, "unet"))
+        return stepper
+
+    def deletion_sampler(self, ds, B):
+        return InfiniteSampler(ds, shuffle=False) if len(ds) >= B else RepeatedSampler(ds, 1 << 30)
+
+
+class DeleteCeleb(_DeleteBase):
+    """config/delete_celeb.yaml -- CelebA-HQ 256, forget set = listed jpgs repeated (RepeatedSampler)."""
+
+
+class DeleteTShirt(_DeleteBase):
+    """config/delete_tshirt.yaml -- MNIST + T-shirt: t ~ U{0..999} (delete_tshirt.py:535-540) and the
+    inf guard on the scaling factor (:688-690)."""
+    timestep_low = 0
+    inf_guard = True
+    default_unet = staticmethod(UNet2DConfig.mnist_tshirt)
