@@ -22,14 +22,18 @@ class _UNetFn(torch.autograd.Function):
     def forward(ctx, anchor, model, sample, timesteps):
         ctx.model = model
         ctx.token = model._fwd_token = object()
-        return model.engine.forward(sample.contiguous(), timesteps).clone()
+        ctx.inputs = (sample.contiguous(), timesteps)
+        return model.engine.forward(ctx.inputs[0], timesteps).clone()
 
     @staticmethod
     def backward(ctx, gout):
         m = ctx.model
-        if ctx.token is not m._fwd_token:
-            raise RuntimeError("UNet2DModel: backward through a stale forward (another forward ran since)")
         eng = m.engine
+        if ctx.token is not m._fwd_token:
+            # another forward ran since (e.g. double_forward_with_neg_del): the engine keeps ONE set of saved
+            # activations, so recompute this forward before differentiating it (checkpoint-style).
+            eng.forward(*ctx.inputs)
+            m._fwd_token = ctx.token
         eng.ps.grads[0].zero_()
         eng.backward(gout.contiguous().float(), nsets=1)
         m._accumulate_param_grads()

@@ -72,4 +72,8 @@ def test_save_and_reload_pretrained(tmp_path):
     t = torch.tensor([999, 3])
     with torch.no_grad():
         a, b = m(x, t)[0], m2(x, t)[0]
-    assert torch.equal(a, b)
+    # same weights after the safetensors round trip; the forward itself is not bitwise reproducible
+    # (GroupNorm statistics fold through LDS float atomics), so compare at bf16 resolution
+    assert (a - b).abs().max() <= 2e-2 * a.abs().max()
+    sd1, sd2 = m.state_dict(), m2.state_dict()
+    assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
