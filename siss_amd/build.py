@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libsiss_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# bit-exact-vs-torch kernels (q_sample, AdamW) must not contract a*b+c into fma
+EXACT = {"siss_loss.hip", "optimizer.hip"}
 
 
 def sources():
@@ -38,7 +40,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, f[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append(["hipcc", *FLAGS, "-c", src, "-o", obj])
+            jobs.append(["hipcc", *FLAGS, *(["-ffp-contract=off"] if f in EXACT else []), "-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -33,7 +33,7 @@ constexpr int kMaxPanels = 9;
 struct NTParams {
     const bf16_t* A; const bf16_t* W; bf16_t* C;
     const float* bias; const float* rowbias; const bf16_t* R;
-    long lda, ldc, ldr;
+    long lda, ldc, ldr, ldrb;
     long strideA, strideW, strideC;   // per blockIdx.z batch (elements)
     int M, N, Kp, npanels;
     int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
@@ -114,16 +114,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
         w_off[i] = BM * 128 + rw * 128 + ((fq ^ ((rw >> 1) & 7)) << 4);
     }
 
+    // One barrier per K-step: the barrier at the top of step s orders (a) every wave's counted wait for
+    // its own step-s DMA (RAW on buf) and (b) every wave's last read of buf^1 in step s-1 (WAR for the
+    // restage issued right after it).
     stage(0, 0);
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < steps) {
-            stage(buf ^ 1, s + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // step s landed; s+1 stays in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA landed, own LDS reads retired
         __builtin_amdgcn_s_barrier();
+        if (s + 1 < steps) stage(buf ^ 1, s + 1);
         const char* sb = smem + buf * kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -139,8 +138,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_s_barrier();   // everyone done reading buf before it is restaged
     }
+    __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: f32 through LDS, then coalesced bf16 rows ----
     // acc[i][j][r]: channel n = wn*64 + i*16 + fq*4 + r, pixel m = wm*64 + j*16 + frow
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
             if (p.rowbias) {
-                const float* rb = p.rowbias + (long)(r / rpi) * p.N + nc;
+                const float* rb = p.rowbias + (long)(r / rpi) * p.ldrb + nc;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (nc + e < p.N) v[e] += rb[e];
             }
@@ -216,7 +215,7 @@ extern "C" {
 // Flat argument list (ctypes-friendly).  shifts/coffs are HOST arrays of npanels ints.
 // Returns SISS_ERR_ARG for shapes the kernel does not cover (Kp % 64, alignment, panel count).
 int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
-                 const float* rowbias, const void* R, long ldr, int M, int N, int Kp, int npanels,
+                 const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
                  const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
                  int batch, long strideA, long strideW, long strideC, void* stream) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
@@ -228,7 +227,7 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     NTParams p;
     p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = (bf16_t*)C;
     p.bias = bias; p.rowbias = rowbias; p.R = (const bf16_t*)R;
-    p.lda = lda; p.ldc = ldc; p.ldr = ldr;
+    p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
     p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
     p.M = M; p.N = N; p.Kp = Kp; p.npanels = npanels;
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;

@@ -53,11 +53,23 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const TNParams p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w >> 1, wc = w & 1;
-    const int tiles_c = (p.C + BC - 1) / BC;
-    const int tn = blockIdx.x / tiles_c, tc = blockIdx.x - tn * tiles_c;
+    // Grid is 1-D.  Logical order: panel (tap) fastest, then tile, then split, then set -- and each XCD
+    // (blocks b, b+8, ... share an L2) gets a CONTIGUOUS run of logical blocks, so the nine taps that
+    // stream the same Y / X rows run together on one XCD and eight of the nine re-reads hit in L2
+    // (measured before this remap: 5 % L2 hit rate, 9x the operand bytes from HBM).
+    const int tiles_c = (p.C + BC - 1) / BC, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int pn = bid % p.npanels; bid /= p.npanels;
+    const int tile = bid % (tiles_c * tiles_n); bid /= tiles_c * tiles_n;
+    const int split = bid % p.nsplits;
+    const int set = bid / p.nsplits;
+    const int tn = tile / tiles_c, tc = tile - tn * tiles_c;
     const int n0 = tn * BN, c0 = tc * BC;
-    const int pn = blockIdx.y;
-    const int set = blockIdx.z / p.nsplits, split = blockIdx.z - set * p.nsplits;
     const int r0 = p.row_begin + split * p.rows_per_split;
     int r1 = r0 + p.rows_per_split; r1 = r1 < p.row_end ? r1 : p.row_end;
     if (r0 >= r1) return;
@@ -111,16 +123,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const TNParams p) 
         x_off[h] = kTile + row * 256 + ((((wc * 8) | (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
     }
 
+    // One barrier per K-step: the barrier at the top of step s orders (a) every wave's counted wait for
+    // its own step-s DMA (RAW on buf) and (b) every wave's last read of buf^1 in step s-1 (WAR for the
+    // restage issued right after it).
     stage(0, 0);
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < steps) {
-            stage(buf ^ 1, s + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA landed, own LDS reads retired
         __builtin_amdgcn_s_barrier();
+        if (s + 1 < steps) stage(buf ^ 1, s + 1);
         const char* sb = smem + buf * kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -140,7 +151,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const TNParams p) 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
         }
-        __builtin_amdgcn_s_barrier();
     }
 
     // acc[i][j][r]: n = n0 + wn*64 + i*16 + (lane>>4)*4 + r, c = c0 + wc*64 + j*16 + (lane&15)
@@ -173,7 +183,6 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
     SISS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && N % 8 == 0 && C % 8 == 0);
     SISS_CHECK_ARG(((uintptr_t)Y | (uintptr_t)X | (uintptr_t)zero_page) % 16 == 0 && (uintptr_t)dW % 4 == 0);
     SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set);
-    SISS_CHECK_ARG((long)nsets * nsplits <= 65535);
     TNParams p;
     p.Y = (const bf16_t*)Y; p.X = (const bf16_t*)X; p.dW = dW; p.zero_page = (const bf16_t*)zero_page;
     p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.x_set_rows = x_set_rows;
@@ -190,7 +199,7 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
             return SISS_ERR_LAUNCH;
         attr_set = true;
     }
-    dim3 grid(cdiv(N, BN) * cdiv(C, BC), npanels, nsets * nsplits);
+    dim3 grid(cdiv(N, BN) * cdiv(C, BC) * npanels * nsets * nsplits);
     gemm_tn_kernel<<<grid, kThreads, kSmemBytes, (hipStream_t)stream>>>(p);
     SISS_LAUNCH_RET();
 }

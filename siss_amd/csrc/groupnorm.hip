@@ -27,10 +27,6 @@ struct GNShape {
     int chunk_px, nchunks;             // interior pixels per block, blocks per sample
 };
 
-__device__ __forceinline__ long padded_row(int n, int pi, int H, int W) {
-    const int y = pi / W, x = pi - y * W;
-    return ((long)n * (H + 2) + (y + 1)) * (W + 2) + (x + 1);
-}
 __device__ __forceinline__ long compact_row(int n, int pi, int H, int W) { return (long)n * H * W + pi; }
 
 __device__ __forceinline__ void unpack8(u32x4_t r, float (&v)[8]) {
@@ -44,6 +40,25 @@ __device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
     return u32x4_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
 }
 
+// Walks the interior pixels pi = p0+slot, +ppi, ... of one image; keeps (y, x) incrementally so the
+// hot loop has no integer division.  row() = padded row index within the image.
+struct PixelWalk {
+    int pi, p1, y, x, W, ppi, dy, dx;
+    __device__ __forceinline__ PixelWalk(const GNShape& s, int chunk, int slot) {
+        const int p0 = chunk * s.chunk_px;
+        p1 = p0 + s.chunk_px; p1 = p1 < s.H * s.W ? p1 : s.H * s.W;
+        pi = p0 + slot; W = s.W; ppi = s.ppi;
+        y = pi / W; x = pi - y * W;
+        dy = ppi / W; dx = ppi - dy * W;
+    }
+    __device__ __forceinline__ bool ok() const { return pi < p1; }
+    __device__ __forceinline__ long row() const { return (long)(y + 1) * (W + 2) + (x + 1); }
+    __device__ __forceinline__ void next() {
+        pi += ppi; y += dy; x += dx;
+        if (x >= W) { x -= W; ++y; }
+    }
+};
+
 // ---------------------------------------------------------------- forward: partial statistics
 __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const bf16_t* __restrict__ x, GNShape s,
                                                             float* __restrict__ partial) {
@@ -54,11 +69,10 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const bf16_t* __rest
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
     float a[8] = {}, b[8] = {};
     if (slot < s.ppi) {
-        const int p0 = chunk * s.chunk_px;
-        int p1 = p0 + s.chunk_px; p1 = p1 < s.H * s.W ? p1 : s.H * s.W;
-        for (int pi = p0 + slot; pi < p1; pi += s.ppi) {
+        const bf16_t* base = x + (long)n * (s.H + 2) * (s.W + 2) * s.C + cc * 8;
+        for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
             float v[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(x + padded_row(n, pi, s.H, s.W) * s.C + cc * 8), v);
+            unpack8(*reinterpret_cast<const u32x4_t*>(base + w.row() * s.C), v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a[e] += v[e]; b[e] += v[e] * v[e]; }
         }
@@ -73,18 +87,31 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const bf16_t* __rest
     if (tid < 2 * s.G) partial[((long)n * s.nchunks + chunk) * 2 * s.G + tid] = sh[tid];
 }
 
-// fold the partial slab for sample n: mean / rstd per group into LDS (and out to global once)
+// Sum the [nchunks][2G] partial slab of one sample with ALL 256 threads: thread (j = tid>>6, e = tid&63)
+// adds chunks j, j+4, ... of entry e (coalesced 256-B rows, independent loads), then the four partial
+// sums meet in LDS.  (A one-thread-per-group serial walk over the chunks cost ~60 us of dependent L2
+// latency in every block.)  Result: red[e] for e < 2G.
+__device__ __forceinline__ void fold_slab(const float* __restrict__ slab, int nchunks, int G, float (*red)[64]) {
+    const int tid = threadIdx.x, j = tid >> 6, e = tid & 63;
+    float a = 0.f;
+    if (e < 2 * G) {
+#pragma unroll 4
+        for (int c = j; c < nchunks; c += 4) a += slab[(long)c * 2 * G + e];
+    }
+    red[j][e] = a;
+    __syncthreads();
+}
+
 __device__ __forceinline__ void fold_stats(const float* __restrict__ partial, const GNShape& s, int n,
                                            float eps, float* sh_mean, float* sh_rstd,
                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                            bool write) {
+    __shared__ float red[4][64];
+    fold_slab(partial + (long)n * s.nchunks * 2 * s.G, s.nchunks, s.G, red);
     const int tid = threadIdx.x;
     if (tid < s.G) {
-        double a = 0, b = 0;
-        for (int c = 0; c < s.nchunks; ++c) {
-            const float* q = partial + ((long)n * s.nchunks + c) * 2 * s.G + 2 * tid;
-            a += q[0]; b += q[1];
-        }
+        const double a = (double)red[0][2 * tid] + red[1][2 * tid] + red[2][2 * tid] + red[3][2 * tid];
+        const double b = (double)red[0][2 * tid + 1] + red[1][2 * tid + 1] + red[2][2 * tid + 1] + red[3][2 * tid + 1];
         const double cnt = (double)s.H * s.W * s.cpg;
         const double m = a / cnt;
         double var = b / cnt - m * m;
@@ -113,150 +140,189 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
         sc[e] = sh_rstd[g] * gamma[c];
         sf[e] = beta[c] - sh_mean[g] * sc[e];
     }
-    const int p0 = chunk * s.chunk_px;
-    int p1 = p0 + s.chunk_px; p1 = p1 < s.H * s.W ? p1 : s.H * s.W;
-    for (int pi = p0 + slot; pi < p1; pi += s.ppi) {
+    const long img = (long)n * (s.H + 2) * (s.W + 2);
+    const bf16_t* base = x + img * s.C + cc * 8;
+    for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
         float v[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(x + padded_row(n, pi, s.H, s.W) * s.C + cc * 8), v);
+        unpack8(*reinterpret_cast<const u32x4_t*>(base + w.row() * s.C), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float z = v[e] * sc[e] + sf[e];
             v[e] = SILU ? silu_f(z) : z;
         }
-        const long orow = out_compact ? compact_row(n, pi, s.H, s.W) : padded_row(n, pi, s.H, s.W);
+        const long orow = out_compact ? compact_row(n, w.pi, s.H, s.W) : img + w.row();
         *reinterpret_cast<u32x4_t*>(y + orow * s.C + cc * 8) = pack8(v);
     }
 }
 
-// ---------------------------------------------------------------- backward: partial sums
-template <bool SILU>
+// ---------------------------------------------------------------- backward
+// grid.y = nx (saved samples); each block handles the SETS cotangent samples n2 = set*nx + n that share
+// saved sample n, so x is read once for both gradient sets.
+template <bool SILU, int SETS>
 __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
     GNShape s, int nx, int dy_compact, int set_images, long set_stride, float* __restrict__ partial,
     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float sh[2 * kMaxG];
-    __shared__ float shg[kMaxC], shb[kMaxC];
-    const int n2 = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const int n = n2 % nx;
-    if (tid < 2 * kMaxG) sh[tid] = 0.f;
-    for (int i = tid; i < s.C; i += kThreads) { shg[i] = 0.f; shb[i] = 0.f; }
+    __shared__ float sh[SETS][2 * kMaxG];
+    __shared__ float shg[SETS][kMaxC], shb[SETS][kMaxC];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < SETS * 2 * kMaxG; i += kThreads) (&sh[0][0])[i] = 0.f;
+    for (int k = 0; k < SETS; ++k)
+        for (int i = tid; i < s.C; i += kThreads) { shg[k][i] = 0.f; shb[k][i] = 0.f; }
     __syncthreads();
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
     if (slot < s.ppi) {
-        float mu[8], rs[8], ga[8], be[8], a1[8] = {}, a2[8] = {};
+        float mr[8], rs[8], ga[8], be[8], a1[SETS][8], a2[SETS][8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cc * 8 + e, g = c / s.cpg;
-            mu[e] = mean[(long)n * s.G + g]; rs[e] = rstd[(long)n * s.G + g];
+            rs[e] = rstd[(long)n * s.G + g]; mr[e] = mean[(long)n * s.G + g] * rs[e];
             ga[e] = gamma[c]; be[e] = beta[c];
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) { a1[k][e] = 0.f; a2[k][e] = 0.f; }
         }
-        const int p0 = chunk * s.chunk_px;
-        int p1 = p0 + s.chunk_px; p1 = p1 < s.H * s.W ? p1 : s.H * s.W;
-        for (int pi = p0 + slot; pi < p1; pi += s.ppi) {
-            float v[8], d[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(x + padded_row(n, pi, s.H, s.W) * s.C + cc * 8), v);
-            const long drow = dy_compact ? compact_row(n2, pi, s.H, s.W) : padded_row(n2, pi, s.H, s.W);
-            unpack8(*reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8), d);
+        const long rpi = (long)(s.H + 2) * (s.W + 2);
+        const bf16_t* xb = x + (long)n * rpi * s.C + cc * 8;
+        for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
+            float v[8], xh[8], dsl[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C), v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xh = (v[e] - mu[e]) * rs[e];
-                const float dz = SILU ? d[e] * dsilu_f(xh * ga[e] + be[e]) : d[e];
-                a1[e] += dz; a2[e] += dz * xh;
+                xh[e] = v[e] * rs[e] - mr[e];
+                dsl[e] = SILU ? dsilu_f(xh[e] * ga[e] + be[e]) : 1.f;
+            }
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) {
+                const int n2 = k * nx + n;
+                const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : (long)n2 * rpi + w.row();
+                float d[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8), d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float dz = d[e] * dsl[e];
+                    a1[k][e] += dz; a2[k][e] += dz * xh[e];
+                }
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = cc * 8 + e, g = c / s.cpg;
-            atomicAdd(&sh[2 * g], a1[e] * ga[e]);
-            atomicAdd(&sh[2 * g + 1], a2[e] * ga[e]);
-            atomicAdd(&shb[c], a1[e]);
-            atomicAdd(&shg[c], a2[e]);
-        }
+        for (int k = 0; k < SETS; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = cc * 8 + e, g = c / s.cpg;
+                atomicAdd(&sh[k][2 * g], a1[k][e] * ga[e]);
+                atomicAdd(&sh[k][2 * g + 1], a2[k][e] * ga[e]);
+                atomicAdd(&shb[k][c], a1[k][e]);
+                atomicAdd(&shg[k][c], a2[k][e]);
+            }
     }
     __syncthreads();
-    if (tid < 2 * s.G) partial[((long)n2 * s.nchunks + chunk) * 2 * s.G + tid] = sh[tid];
-    const long so = (long)(n2 / set_images) * set_stride;
-    for (int i = tid; i < s.C; i += kThreads) {
-        atomicAdd(dgamma + so + i, shg[i]);
-        atomicAdd(dbeta + so + i, shb[i]);
+    for (int k = 0; k < SETS; ++k) {
+        const int n2 = k * nx + n;
+        if (tid < 2 * s.G) partial[((long)n2 * s.nchunks + chunk) * 2 * s.G + tid] = sh[k][tid];
+        const long so = (long)(n2 / set_images) * set_stride;
+        for (int i = tid; i < s.C; i += kThreads) {
+            atomicAdd(dgamma + so + i, shg[k][i]);
+            atomicAdd(dbeta + so + i, shb[k][i]);
+        }
     }
 }
 
-template <bool SILU>
+template <bool SILU, int SETS>
 __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ partial, GNShape s, int nx, int dy_compact, const bf16_t* __restrict__ accum,
-    bf16_t* __restrict__ dx, float* __restrict__ colsum) {
-    __shared__ float sh_s1[kMaxG], sh_s2[kMaxG];
-    __shared__ float shc[kMaxC];
-    const int n2 = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const int n = n2 % nx;
-    if (tid < s.G) {
-        double a = 0, b = 0;
-        for (int c = 0; c < s.nchunks; ++c) {
-            const float* q = partial + ((long)n2 * s.nchunks + c) * 2 * s.G + 2 * tid;
-            a += q[0]; b += q[1];
-        }
+    bf16_t* __restrict__ dx, float* __restrict__ colsum, long colsum_ld) {
+    __shared__ float sh_s1[SETS][kMaxG], sh_s2[SETS][kMaxG];
+    __shared__ float shc[SETS][kMaxC];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    {
+        __shared__ float red[4][64];
         const double cnt = (double)s.H * s.W * s.cpg;
-        sh_s1[tid] = (float)(a / cnt); sh_s2[tid] = (float)(b / cnt);
+        for (int k = 0; k < SETS; ++k) {
+            const int n2 = k * nx + n;
+            fold_slab(partial + (long)n2 * s.nchunks * 2 * s.G, s.nchunks, s.G, red);
+            if (tid < s.G) {
+                sh_s1[k][tid] = (float)(((double)red[0][2 * tid] + red[1][2 * tid] + red[2][2 * tid] + red[3][2 * tid]) / cnt);
+                sh_s2[k][tid] = (float)(((double)red[0][2 * tid + 1] + red[1][2 * tid + 1] + red[2][2 * tid + 1] + red[3][2 * tid + 1]) / cnt);
+            }
+            __syncthreads();
+        }
     }
-    if (colsum) for (int i = tid; i < s.C; i += kThreads) shc[i] = 0.f;
+    if (colsum)
+        for (int k = 0; k < SETS; ++k)
+            for (int i = tid; i < s.C; i += kThreads) shc[k][i] = 0.f;
     __syncthreads();
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
     if (slot < s.ppi) {
-        float mu[8], rs[8], ga[8], be[8], m1[8], m2[8], cs[8] = {};
+        float mr[8], rs[8], ga[8], be[8], m1[SETS][8], m2[SETS][8], cs[SETS][8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cc * 8 + e, g = c / s.cpg;
-            mu[e] = mean[(long)n * s.G + g]; rs[e] = rstd[(long)n * s.G + g];
-            ga[e] = gamma[c]; be[e] = beta[c]; m1[e] = sh_s1[g]; m2[e] = sh_s2[g];
+            rs[e] = rstd[(long)n * s.G + g]; mr[e] = mean[(long)n * s.G + g] * rs[e];
+            ga[e] = gamma[c]; be[e] = beta[c];
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) { m1[k][e] = sh_s1[k][g]; m2[k][e] = sh_s2[k][g]; cs[k][e] = 0.f; }
         }
-        const int p0 = chunk * s.chunk_px;
-        int p1 = p0 + s.chunk_px; p1 = p1 < s.H * s.W ? p1 : s.H * s.W;
-        for (int pi = p0 + slot; pi < p1; pi += s.ppi) {
-            float v[8], d[8], o[8];
-            const long xrow = padded_row(n, pi, s.H, s.W);
-            const long orow = padded_row(n2, pi, s.H, s.W);
-            unpack8(*reinterpret_cast<const u32x4_t*>(x + xrow * s.C + cc * 8), v);
-            const long drow = dy_compact ? compact_row(n2, pi, s.H, s.W) : orow;
-            unpack8(*reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8), d);
+        const long rpi = (long)(s.H + 2) * (s.W + 2);
+        const bf16_t* xb = x + (long)n * rpi * s.C + cc * 8;
+        for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
+            float v[8], xh[8], dsl[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C), v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xh = (v[e] - mu[e]) * rs[e];
-                const float dz = SILU ? d[e] * dsilu_f(xh * ga[e] + be[e]) : d[e];
-                o[e] = rs[e] * (dz * ga[e] - m1[e] - xh * m2[e]);
-                cs[e] += o[e];
+                xh[e] = v[e] * rs[e] - mr[e];
+                dsl[e] = (SILU ? dsilu_f(xh[e] * ga[e] + be[e]) : 1.f) * ga[e];
             }
-            if (accum) {
-                float r[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(accum + orow * s.C + cc * 8), r);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] += r[e];
+            for (int k = 0; k < SETS; ++k) {
+                const int n2 = k * nx + n;
+                const long orow = (long)n2 * rpi + w.row();
+                const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : orow;
+                float d[8], o[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8), d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = rs[e] * (d[e] * dsl[e] - m1[k][e] - xh[e] * m2[k][e]);
+                    cs[k][e] += o[e];
+                }
+                if (accum) {
+                    float r[8];
+                    unpack8(*reinterpret_cast<const u32x4_t*>(accum + orow * s.C + cc * 8), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
+                *reinterpret_cast<u32x4_t*>(dx + orow * s.C + cc * 8) = pack8(o);
             }
-            *reinterpret_cast<u32x4_t*>(dx + orow * s.C + cc * 8) = pack8(o);
         }
         if (colsum) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(&shc[cc * 8 + e], cs[e]);
+            for (int k = 0; k < SETS; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(&shc[k][cc * 8 + e], cs[k][e]);
         }
     }
     if (colsum) {
         __syncthreads();
-        for (int i = tid; i < s.C; i += kThreads) atomicAdd(colsum + (long)n2 * s.C + i, shc[i]);
+        for (int k = 0; k < SETS; ++k)
+            for (int i = tid; i < s.C; i += kThreads) atomicAdd(colsum + (long)(k * nx + n) * colsum_ld + i, shc[k][i]);
     }
 }
 
-bool make_shape(int H, int W, int C, int G, GNShape& s) {
+bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16) {
     if (H <= 0 || W <= 0 || C <= 0 || G <= 0 || G > kMaxG || C % G || C % 8 || C > kMaxC) return false;
     s.H = H; s.W = W; s.C = C; s.G = G; s.cpg = C / G;
     s.lpp = C / 8;
     if (s.lpp > kThreads) return false;
     s.ppi = kThreads / s.lpp;
     const int px = H * W;
-    int nch = (px + 1023) / 1024;            // >= 1024 pixels per block unless the image is small
-    if (nch > 64) nch = 64;
+    // ~3 blocks per CU, and >= 16 pixel iterations per thread so that the per-block prologue (slab fold)
+    // and epilogue (LDS + global atomics) are amortised
+    int nch = (768 + N - 1) / N;
+    const int max_by_work = (px + 16 * s.ppi - 1) / (16 * s.ppi);
+    if (nch > max_by_work) nch = max_by_work;
+    if (nch > 256) nch = 256;
     if (nch < 1) nch = 1;
     s.chunk_px = (px + nch - 1) / nch;
     s.nchunks = (px + s.chunk_px - 1) / s.chunk_px;
@@ -270,7 +336,7 @@ extern "C" {
 // floats needed in `partial` for n samples
 long siss_gn_partial_words(int n, int H, int W, int C, int G) {
     GNShape s;
-    if (!make_shape(H, W, C, G, s)) return -1;
+    if (!make_shape(H, W, C, G, s, 1)) return -1;   // N = 1 gives the largest chunk count -> upper bound
     return (long)n * s.nchunks * 2 * G;
 }
 
@@ -280,7 +346,7 @@ int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, voi
                        int silu, int out_compact, void* stream) {
     GNShape s;
     SISS_CHECK_ARG(x && gamma && beta && y && mean && rstd && partial && N > 0);
-    SISS_CHECK_ARG(make_shape(H, W, C, G, s));
+    SISS_CHECK_ARG(make_shape(H, W, C, G, s, N));
     SISS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, N);
@@ -295,25 +361,28 @@ int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, voi
 // dx (padded, n2 samples) from dy (n2 samples, padded or compact) and the saved x (nx samples,
 // x index = n2 % nx).  dgamma/dbeta: [sets][...] accumulated atomically at set = n2 / set_images
 // with `set_stride` floats between sets.  accum (optional, padded like dx) is added to dx;
-// colsum (optional, [n2][C] f32, pre-zeroed) receives the per-sample channel sums of dx.
+// colsum (optional, f32 rows of colsum_ld floats, pre-zeroed) receives the per-sample channel sums of dx.
 int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                        const float* mean, const float* rstd, void* dx, const void* accum, float* dgamma,
-                       float* dbeta, float* colsum, float* partial, int n2, int nx, int set_images,
+                       float* dbeta, float* colsum, long colsum_ld, float* partial, int n2, int nx, int set_images,
                        long set_stride, int H, int W, int C, int G, int silu, int dy_compact, void* stream) {
     GNShape s;
     SISS_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && partial);
     SISS_CHECK_ARG(n2 > 0 && nx > 0 && set_images > 0 && n2 % set_images == 0);
-    SISS_CHECK_ARG(make_shape(H, W, C, G, s));
+    SISS_CHECK_ARG(n2 == nx || n2 == 2 * nx);     // cotangent sets per saved sample: 1 or 2
+    SISS_CHECK_ARG(make_shape(H, W, C, G, s, nx));
     SISS_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)accum) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(s.nchunks, n2);
-    if (silu) {
-        gn_bwd_stats_kernel<true><<<grid, kThreads, 0, st>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, s, nx, dy_compact, set_images, set_stride, partial, dgamma, dbeta);
-        gn_bwd_apply_kernel<true><<<grid, kThreads, 0, st>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, partial, s, nx, dy_compact, (const bf16_t*)accum, (bf16_t*)dx, colsum);
-    } else {
-        gn_bwd_stats_kernel<false><<<grid, kThreads, 0, st>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, s, nx, dy_compact, set_images, set_stride, partial, dgamma, dbeta);
-        gn_bwd_apply_kernel<false><<<grid, kThreads, 0, st>>>((const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean, rstd, partial, s, nx, dy_compact, (const bf16_t*)accum, (bf16_t*)dx, colsum);
-    }
+    dim3 grid(s.nchunks, nx);
+    const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;
+#define GN_BWD(SILU, SETS)                                                                                          \
+    gn_bwd_stats_kernel<SILU, SETS><<<grid, kThreads, 0, st>>>(dyp, xp, gamma, beta, mean, rstd, s, nx, dy_compact, \
+                                                               set_images, set_stride, partial, dgamma, dbeta);    \
+    gn_bwd_apply_kernel<SILU, SETS><<<grid, kThreads, 0, st>>>(dyp, xp, gamma, beta, mean, rstd, partial, s, nx,    \
+                                                               dy_compact, (const bf16_t*)accum, (bf16_t*)dx, colsum, colsum_ld)
+    if (n2 == nx) { if (silu) { GN_BWD(true, 1); } else { GN_BWD(false, 1); } }
+    else          { if (silu) { GN_BWD(true, 2); } else { GN_BWD(false, 2); } }
+#undef GN_BWD
     SISS_LAUNCH_RET();
 }
 

@@ -100,6 +100,83 @@ __global__ void linear_bwd_dw_kernel(const float* __restrict__ dy, const float* 
     }
 }
 
+
+// ---- all time_emb_proj layers of the network as ONE problem --------------------------------------
+// Output column n of the concatenated [M][Ntot] matrix belongs to some resnet; woff[n] is the offset
+// (floats, into the flat parameter buffer) of its weight ROW, boff[n] of its bias element.
+__global__ __launch_bounds__(kThreads) void multi_fwd_kernel(const float* __restrict__ x, const float* __restrict__ P,
+                                                             const long* __restrict__ woff, const long* __restrict__ boff,
+                                                             float* __restrict__ y, int M, int Ntot, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (n >= Ntot) return;
+    const float* W = P + woff[n];
+    for (int m0 = 0; m0 < M; m0 += 8) {
+        float acc[8] = {};
+        for (int k = lane; k < K; k += 64) {
+            const float w = W[k];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (m0 + i < M) acc[i] += silu_f(x[(long)(m0 + i) * K + k]) * w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float s = wave_sum(acc[i]);
+            if (lane == 0 && m0 + i < M) y[(long)(m0 + i) * Ntot + n] = s + P[boff[n]];
+        }
+    }
+}
+
+// dW[set][woff[n] + k] += sum_{m in set} dy[m][n] * silu(x[m % Mx][k]) ; db / db2 likewise (k == 0)
+__global__ void multi_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ G,
+                                    const long* __restrict__ woff, const long* __restrict__ boff,
+                                    const long* __restrict__ boff2, int M2, int Mx, int set_rows, long set_stride,
+                                    int Ntot, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nsets = M2 / set_rows;
+    if (i >= (long)nsets * Ntot * K) return;
+    const int set = i / ((long)Ntot * K);
+    const long rem = i - (long)set * Ntot * K;
+    const int n = rem / K, k = rem - (long)n * K;
+    float acc = 0.f, bsum = 0.f;
+    for (int j = 0; j < set_rows; ++j) {
+        const int m = set * set_rows + j;
+        const float d = dy[(long)m * Ntot + n];
+        acc += d * silu_f(x[(long)(m % Mx) * K + k]);
+        bsum += d;
+    }
+    float* g = G + (long)set * set_stride;
+    g[woff[n] + k] += acc;
+    if (k == 0) { g[boff[n]] += bsum; g[boff2[n]] += bsum; }
+}
+
+// dx[m][k] += sum_n dy[m][n] * W_n[k]     grid: (K / 256, Ntot / 64); thread = one k, 64 columns per block
+__global__ __launch_bounds__(256) void multi_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ P,
+                                                           const long* __restrict__ woff, float* __restrict__ dx,
+                                                           int M2, int Ntot, int K) {
+    __shared__ float shd[64][65];   // [m][col]
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < M2 * 64; i += 256) {
+        const int m = i / 64, c = i - m * 64;
+        shd[m][c] = (n0 + c < Ntot) ? dy[(long)m * Ntot + n0 + c] : 0.f;
+    }
+    __syncthreads();
+    if (k >= K) return;
+    float acc[64];
+#pragma unroll
+    for (int m = 0; m < 64; ++m) acc[m] = 0.f;
+    for (int c = 0; c < 64 && n0 + c < Ntot; ++c) {
+        const float w = P[woff[n0 + c] + k];
+#pragma unroll
+        for (int m = 0; m < 64; ++m)
+            if (m < M2) acc[m] += shd[m][c] * w;
+    }
+#pragma unroll
+    for (int m = 0; m < 64; ++m)
+        if (m < M2) atomicAdd(dx + (long)m * K + k, acc[m]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -126,6 +203,30 @@ int siss_linear_small_bwd(const float* dy, const float* yact, const float* x, co
     if (dx) linear_bwd_dx_kernel<<<cdiv((long)M2 * K, 256), 256, 0, st>>>(dy, yact, W, dx, M2, Mx, N, K, accumulate_dx);
     const long tot = (long)(M2 / set_rows) * N * K;
     linear_bwd_dw_kernel<<<cdiv(tot, 256), 256, 0, st>>>(dy, yact, x, dW, db, db2, M2, Mx, set_rows, set_stride_w, set_stride_b, N, K, act_in_silu);
+    SISS_LAUNCH_RET();
+}
+
+// y[m][n] = silu(x[m]) . P[woff[n] .. +K] + P[boff[n]]   for all Ntot concatenated output columns
+int siss_linear_multi_fwd(const float* x, const float* params, const long* woff, const long* boff, float* y, int M,
+                          int Ntot, int K, void* stream) {
+    SISS_CHECK_ARG(x && params && woff && boff && y && M > 0 && M <= kMaxM && Ntot > 0 && K > 0);
+    multi_fwd_kernel<<<cdiv(Ntot, kThreads / 64), kThreads, 0, (hipStream_t)stream>>>(x, params, woff, boff, y, M, Ntot, K);
+    SISS_LAUNCH_RET();
+}
+
+// Backward of the above for M2 cotangent rows (row m uses saved input row m % Mx):
+// grads[set][woff[n]+k], grads[set][boff[n]], grads[set][boff2[n]] are accumulated (+=); dx[M2][K] is
+// accumulated atomically (zero it first).
+int siss_linear_multi_bwd(const float* dy, const float* x, const float* params, float* grads, const long* woff,
+                          const long* boff, const long* boff2, float* dx, int M2, int Mx, int set_rows,
+                          long set_stride, int Ntot, int K, void* stream) {
+    SISS_CHECK_ARG(dy && x && params && grads && woff && boff && boff2 && dx);
+    SISS_CHECK_ARG(M2 > 0 && M2 <= 64 && Mx > 0 && set_rows > 0 && M2 % set_rows == 0 && Ntot > 0 && K > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const long tot = (long)(M2 / set_rows) * Ntot * K;
+    multi_bwd_dw_kernel<<<cdiv(tot, 256), 256, 0, st>>>(dy, x, grads, woff, boff, boff2, M2, Mx, set_rows, set_stride, Ntot, K);
+    dim3 grid(cdiv(K, 256), cdiv(Ntot, 64));
+    multi_bwd_dx_kernel<<<grid, 256, 0, st>>>(dy, params, woff, dx, M2, Ntot, K);
     SISS_LAUNCH_RET();
 }
 

@@ -27,11 +27,11 @@ SIGNATURES = {
     "siss_recombine_clip_adamw": [P, P, P, P, P, P, P, L, F, F, F, F, F, P, P],
     "siss_cast_f32_bf16": [P, P, L, P],
     "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],
-    "siss_gemm_nt": [P, L, P, P, L, P, P, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
+    "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
-    "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, L, I, I, I, I, I, I, P],
+    "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],
     "siss_upsample2x": [P, P, I, I, I, I, P],
     "siss_upsample2x_bwd": [P, P, I, I, I, I, P],
     "siss_concat": [P, P, P, I, I, I, I, I, P],
@@ -51,6 +51,8 @@ SIGNATURES = {
     "siss_softmax_bwd": [P, P, P, L, L, I, F, P],
     "siss_timestep_sincos": [P, P, I, I, I, F, P],
     "siss_linear_small_fwd": [P, P, P, P, I, I, I, I, P],
+    "siss_linear_multi_fwd": [P, P, P, P, P, I, I, I, P],
+    "siss_linear_multi_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, I, I, P],
     "siss_linear_small_bwd": [P, P, P, P, P, I, P, P, P, I, I, I, L, L, I, I, I, P],
 }
 _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words",
@@ -102,7 +104,7 @@ PROF = None
 
 def _work(name, a):
     if name == "siss_gemm_nt":      # 2 * M * N * Kp * npanels * batch
-        return 2.0 * a[9] * a[10] * a[11] * a[12] * a[19]
+        return 2.0 * a[10] * a[11] * a[12] * a[13] * a[20]
     if name == "siss_gemm_tn":      # 2 * N * C * npanels * nsets * rows
         return 2.0 * a[6] * a[7] * a[8] * a[11] * (a[15] - a[14])
     return 0.0

@@ -41,15 +41,15 @@ def dgrad_weight(w_native_f32):
 
 
 # ---------------------------------------------------------------- panelled NT GEMM
-def gemm_nt(a_ptr, lda, w, c_ptr, ldc, M, N, Kp, shifts, coffs, *, bias=None, rowbias=None,
+def gemm_nt(a_ptr, lda, w, c_ptr, ldc, M, N, Kp, shifts, coffs, *, bias=None, rowbias=None, ldrb=None,
             res_ptr=None, ldr=0, rows_per_image=1, hp=0, wp=0, alpha=1.0, batch=1,
             stride_a=0, stride_w=0, stride_c=0):
-    lib.call("siss_gemm_nt", a_ptr, lda, w, c_ptr, ldc, bias, rowbias, res_ptr, ldr, M, N, Kp,
+    lib.call("siss_gemm_nt", a_ptr, lda, w, c_ptr, ldc, bias, rowbias, ldrb if ldrb is not None else N, res_ptr, ldr, M, N, Kp,
              len(shifts), lib.int_array(shifts), lib.int_array(coffs), rows_per_image, hp, wp,
              float(alpha), batch, stride_a, stride_w, stride_c)
 
 
-def conv_fprop(x: Act, w_bf16, out: Act, bias=None, rowbias=None, residual: Act = None, ksize=3):
+def conv_fprop(x: Act, w_bf16, out: Act, bias=None, rowbias=None, residual: Act = None, ksize=3, ldrb=None):
     """out = conv(x) (+bias +rowbias[img] +residual); w_bf16 [T][Co][Ci] bf16."""
     t, co, ci = w_bf16.shape
     assert ci == x.c and co == out.c and (x.n, x.h, x.w) == (out.n, out.h, out.w)
@@ -59,7 +59,7 @@ def conv_fprop(x: Act, w_bf16, out: Act, bias=None, rowbias=None, residual: Act 
         shifts, coffs = [0], [0]
     assert t == len(shifts)
     gemm_nt(lib.ptr(x.data), x.c, w_bf16, lib.ptr(out.data), out.c, x.rows, co, ci, shifts, coffs,
-            bias=bias, rowbias=rowbias, res_ptr=lib.ptr(residual.data) if residual is not None else None,
+            bias=bias, rowbias=rowbias, ldrb=ldrb, res_ptr=lib.ptr(residual.data) if residual is not None else None,
             ldr=residual.c if residual is not None else 0,
             rows_per_image=x.rows_per_image, hp=x.hp, wp=x.wp)
     return out

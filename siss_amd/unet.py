@@ -142,6 +142,7 @@ class UNetEngine:
         self.ps = ParamStore()
         self._declare_params()
         self.ps.allocate(self.device)
+        self._build_temb_tables()
         self.wT = {}
         self._acts = {}
         self._bufs = {}
@@ -153,6 +154,10 @@ class UNetEngine:
     # ------------------------------------------------------------------ parameters
     def _declare_resnet(self, pre, cin, cout, temb):
         a = self.ps.add
+        if not hasattr(self, "temb_cols"):
+            self.temb_cols, self.temb_ntot = {}, 0
+        self.temb_cols[pre] = (self.temb_ntot, cout)          # column range in the batched time_emb_proj GEMM
+        self.temb_ntot += cout
         a(f"{pre}.norm1.weight", "vec", (cin,)); a(f"{pre}.norm1.bias", "vec", (cin,))
         a(f"{pre}.conv1.weight", "conv3", (cout, cin, 3, 3)); a(f"{pre}.conv1.bias", "vec", (cout,))
         a(f"{pre}.time_emb_proj.weight", "mat", (cout, temb)); a(f"{pre}.time_emb_proj.bias", "vec", (cout,))
@@ -160,6 +165,19 @@ class UNetEngine:
         a(f"{pre}.conv2.weight", "conv3", (cout, cout, 3, 3)); a(f"{pre}.conv2.bias", "vec", (cout,))
         if cin != cout:
             a(f"{pre}.conv_shortcut.weight", "conv1", (cout, cin, 1, 1)); a(f"{pre}.conv_shortcut.bias", "vec", (cout,))
+
+    def _build_temb_tables(self):
+        """Per output column of the concatenated time_emb_proj problem: offsets (floats into the flat
+        parameter buffer) of its weight row, its bias, and the conv1 bias that shares its gradient."""
+        ps = self.ps
+        woff = torch.empty(self.temb_ntot, dtype=torch.int64)
+        boff, boff2 = torch.empty_like(woff), torch.empty_like(woff)
+        for pre, (c0, cout) in self.temb_cols.items():
+            cols = torch.arange(cout)
+            woff[c0:c0 + cout] = ps.specs[pre + ".time_emb_proj.weight"].off + cols * self.temb_dim
+            boff[c0:c0 + cout] = ps.specs[pre + ".time_emb_proj.bias"].off + cols
+            boff2[c0:c0 + cout] = ps.specs[pre + ".conv1.bias"].off + cols
+        self.temb_woff, self.temb_boff, self.temb_boff2 = (v.to(self.device) for v in (woff, boff, boff2))
 
     def _declare_attn(self, pre, ch):
         a = self.ps.add
@@ -322,20 +340,20 @@ class UNetEngine:
         lib.call("siss_groupnorm_fwd", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
                  self._gn_partial(x.n, x.h, x.w, x.c), x.n, x.h, x.w, x.c, G, float(eps), int(silu), int(compact_out))
 
-        def bwd(dy, colsum=None, accum: Act = None):
+        def bwd(dy, colsum=None, accum: Act = None, colsum_ld=0):
             """dy: Act (padded) or compact tensor, nb samples.  Returns dx Act (nb samples)."""
             nb = self.nb
             dx = accum if accum is not None else self._get(nb, x.h, x.w, x.c)
             dyp = dy.data if isinstance(dy, Act) else dy
             lib.call("siss_groupnorm_bwd", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
                      dx.data, accum.data if accum is not None else None,
-                     ps.g(pre + ".weight", self.gbase), ps.g(pre + ".bias", self.gbase), colsum,
+                     ps.g(pre + ".weight", self.gbase), ps.g(pre + ".bias", self.gbase), colsum, colsum_ld,
                      self._gn_partial(nb, x.h, x.w, x.c), nb, x.n, self.set_images, ps.total,
                      x.h, x.w, x.c, G, int(silu), int(not isinstance(dy, Act)))
             return dx
         return y, bwd
 
-    def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None):
+    def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None, ldrb=None):
         """stride-1 'same' conv (3x3 or 1x1) with fused bias / time-embedding row bias / residual."""
         ps = self.ps
         w = ps.sh(pre + ".weight")
@@ -343,7 +361,7 @@ class UNetEngine:
             w = w.view(1, *w.shape)
         co = w.shape[1]
         y = self._act(self._name(out_name or pre), x.n, x.h, x.w, co)
-        ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize)
+        ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
 
         def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None):
             if bias_grad:
@@ -393,12 +411,19 @@ class UNetEngine:
         lib.call("siss_linear_small_fwd", h1, ps.p("time_embedding.linear_2.weight"),
                  ps.p("time_embedding.linear_2.bias"), emb, B, self.temb_dim, self.temb_dim, 1)
         self.emb = emb
+        # every resnet's time_emb_proj(silu(emb)) in ONE launch: tp_all[:, c0:c0+cout] is its row bias
+        self.tp_all = self._buf("temb.tp_all", (B, self.temb_ntot))
+        lib.call("siss_linear_multi_fwd", emb, ps.flat, self.temb_woff, self.temb_boff, self.tp_all, B,
+                 self.temb_ntot, self.temb_dim)
 
         def bwd():
             nb, T = self.nb, self.temb_dim
-            d_s = self._buf("temb.d_s", (nb, T))           # grad wrt silu(emb), accumulated by the resnets
+            d_s = self._buf("temb.d_s", (nb, T))           # grad wrt silu(emb)
             d_s1 = self._buf("temb.d_s1", (nb, T))
             gb = self.gbase
+            # all time_emb_proj weight/bias grads (+ the conv1 biases that share them) and d_s, batched
+            lib.call("siss_linear_multi_bwd", self.dtp_all, emb, ps.flat, ps.grads[gb:], self.temb_woff,
+                     self.temb_boff, self.temb_boff2, d_s, nb, B, self.set_images, ps.total, self.temb_ntot, T)
             lib.call("siss_linear_small_bwd", d_s, emb, h1, ps.p("time_embedding.linear_2.weight"), d_s1, 0,
                      ps.g("time_embedding.linear_2.weight", gb), ps.g("time_embedding.linear_2.bias", gb), None,
                      nb, B, self.set_images, ps.total, ps.total, T, T, 1)
@@ -414,10 +439,8 @@ class UNetEngine:
         cout = ps.specs[pre + ".conv1.weight"].ref_shape[0]
         B = x.n
         a1, gn1_b = self.gn(x, pre + ".norm1", True)
-        tp = self._buf(self._name(pre + ".tp"), (B, cout))
-        lib.call("siss_linear_small_fwd", self.emb, ps.p(pre + ".time_emb_proj.weight"),
-                 ps.p(pre + ".time_emb_proj.bias"), tp, B, cout, self.temb_dim, 1)
-        h, c1_b = self.conv(a1, pre + ".conv1", rowbias=tp)
+        col0, _ = self.temb_cols[pre]
+        h, c1_b = self.conv(a1, pre + ".conv1", rowbias=self.tp_all[:, col0:], ldrb=self.temb_ntot)
         a2, gn2_b = self.gn(h, pre + ".norm2", True)
         has_sc = cin != cout
         if has_sc:
@@ -433,16 +456,10 @@ class UNetEngine:
             gb = self.gbase
             # conv2 (its bias gradient equals the shortcut conv's bias gradient: same pre-activation)
             da2 = c2_b(dout, bias_grad2=ps.g(pre + ".conv_shortcut.bias", gb) if has_sc else None)
-            dtp = self._buf("dtp", (nb, cout))
-            dtp.zero_()
-            dh = gn2_b(da2, colsum=dtp, accum=None)
+            # column sums of dh = cotangent of time_emb_proj's output (and of conv1's bias); the weight
+            # gradients of ALL time_emb_proj layers are formed in one batched launch at the end
+            dh = gn2_b(da2, colsum=self.dtp_all[:, col0:], accum=None, colsum_ld=self.temb_ntot)
             self._put(da2)
-            # time_emb_proj (+ conv1 bias: same sums)
-            d_s = self._buf("temb.d_s", (nb, self.temb_dim))
-            lib.call("siss_linear_small_bwd", dtp, None, self.emb, ps.p(pre + ".time_emb_proj.weight"), d_s, 1,
-                     ps.g(pre + ".time_emb_proj.weight", gb), ps.g(pre + ".time_emb_proj.bias", gb),
-                     ps.g(pre + ".conv1.bias", gb), nb, B, self.set_images, ps.total, ps.total, cout,
-                     self.temb_dim, 1)
             da1 = c1_b(dh, bias_grad=False)
             self._put(dh)
             if has_sc:
@@ -707,6 +724,8 @@ class UNetEngine:
         self.nb, self.nsets, self.set_images, self.gbase, self.cot = nb, nsets, nb // nsets, grad_base_set, cot
         d_s = self._buf("temb.d_s", (nb, self.temb_dim))
         d_s.zero_()
+        self.dtp_all = self._buf("temb.dtp_all", (nb, self.temb_ntot))
+        self.dtp_all.zero_()
         for fn in reversed(self.tape):
             fn()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"
