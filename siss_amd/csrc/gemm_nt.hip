@@ -20,14 +20,12 @@
 // CONSECUTIVE output channels of one pixel: the epilogue stages f32 through LDS (528-B padded
 // rows) and writes 16-B coalesced bf16 rows.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kThreads = 256;
-constexpr int kStageBytes = (BM + BN) * BK * 2;          // 32 KiB per stage
+constexpr int BN = 128, BK = 64;
 constexpr int kCRow = BN * 4 + 16;                       // f32 epilogue row, padded (bank spread)
-constexpr int kSmemBytes = (2 * kStageBytes > BM * kCRow) ? 2 * kStageBytes : BM * kCRow;
 constexpr int kMaxPanels = 9;
 
 struct NTParams {
@@ -49,7 +47,25 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) {
+// Two instantiations:
+//   <256, 8 waves, 3 stages>  big layers: one 512-thread block per CU (2 waves / SIMD), 144 KiB LDS ring,
+//                             the DMA of K-step s+2 is issued while step s computes (counted vmcnt), so an
+//                             L2 / Infinity-Cache round trip has two compute phases to land;
+//   <128, 4 waves, 2 stages>  small layers (few tiles): two 256-thread blocks per CU.
+template <int BM, int NW, int STAGES>
+struct Cfg {
+    static constexpr int kThreads = NW * 64;
+    static constexpr int kStageBytes = (BM + BN) * BK * 2;
+    static constexpr int kRing = STAGES * kStageBytes;
+    static constexpr int kSmemBytes = kRing > BM * kCRow ? kRing : BM * kCRow;
+    static constexpr int kAPieces = BM / 8 / NW;        // 8-row DMA pieces per wave
+    static constexpr int kWPieces = BN / 8 / NW;
+    static constexpr int kPerStage = kAPieces + kWPieces;
+};
+
+template <int BM, int NW, int STAGES>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void gemm_nt_kernel(const NTParams p) {
+    using C_ = Cfg<BM, NW, STAGES>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,16 +86,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
     const bf16_t* A = p.A + (long)bz * p.strideA;
     const bf16_t* W = p.W + (long)bz * p.strideW;
 
-    // per-lane staging sources: 4 pieces of 8 rows for A and for W
-    const bf16_t* asrc[4];
-    const bf16_t* wsrc[4];
+    // per-lane staging sources (8 rows x 128 B per wave-instruction)
+    const bf16_t* asrc[C_::kAPieces];
+    const bf16_t* wsrc[C_::kWPieces];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = w * 32 + j * 8 + (lane >> 3);
+    for (int j = 0; j < C_::kAPieces; ++j) {
+        const int row = (w * C_::kAPieces + j) * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
-        int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
         asrc[j] = A + (long)gr * p.lda + lc * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < C_::kWPieces; ++j) {
+        const int row = (w * C_::kWPieces + j) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
         wsrc[j] = W + (long)gn * p.Kp + lc * 8;
     }
     const int kchunks = p.Kp / BK;
@@ -90,11 +111,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
         const int pn = step / kchunks, kc = step - pn * kchunks;
         const long aoff = (long)p.shift[pn] * p.lda + p.coff[pn] + kc * BK;
         const long woff = pn * wpanel + kc * BK;
-        char* base = smem + buf * kStageBytes + (w * 32) * 128;
+        char* base = smem + buf * C_::kStageBytes;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(asrc[j] + aoff, base + j * 1024);
+        for (int j = 0; j < C_::kAPieces; ++j) glds16(asrc[j] + aoff, base + (w * C_::kAPieces + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(wsrc[j] + woff, base + BM * 128 + j * 1024);
+        for (int j = 0; j < C_::kWPieces; ++j) glds16(wsrc[j] + woff, base + BM * 128 + (w * C_::kWPieces + j) * 1024);
     };
 
     f32x4_t acc[4][4];   // [n-tile][m-tile]
@@ -114,16 +135,22 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
         w_off[i] = BM * 128 + rw * 128 + ((fq ^ ((rw >> 1) & 7)) << 4);
     }
 
-    // One barrier per K-step: the barrier at the top of step s orders (a) every wave's counted wait for
-    // its own step-s DMA (RAW on buf) and (b) every wave's last read of buf^1 in step s-1 (WAR for the
-    // restage issued right after it).
-    stage(0, 0);
+    // Ring of STAGES buffers, ONE barrier per K-step.  At the top of step s every wave waits for its own
+    // step-s DMA (a counted vmcnt leaves the younger stages in flight) and for its LDS reads of step s-1;
+    // the barrier then makes (a) all of step s visible and (b) buffer (s-1) % STAGES free, which is
+    // exactly the buffer the DMA of step s + STAGES - 1 is issued into right after it.
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < steps) stage(s, s);
+    int buf = 0, nbuf = STAGES - 1;
     for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA landed, own LDS reads retired
+        if (STAGES == 3 && s + 1 < steps)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C_::kPerStage) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (s + 1 < steps) stage(buf ^ 1, s + 1);
-        const char* sb = smem + buf * kStageBytes;
+        if (s + STAGES - 1 < steps) stage(nbuf, s + STAGES - 1);
+        const char* sb = smem + buf * C_::kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t af[4], wf[4];
@@ -138,7 +165,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: f32 through LDS, then coalesced bf16 rows ----
@@ -161,9 +191,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = (p.bias && nc + e < p.N) ? p.bias[nc + e] : 0.f;
     const int rpi = p.rows_per_image;
+    constexpr int kRowsPerIt = C_::kThreads / 16;
 #pragma unroll 2
-    for (int it = 0; it < BM / 16; ++it) {
-        const int row = it * 16 + (tid >> 4);
+    for (int it = 0; it < BM / kRowsPerIt; ++it) {
+        const int row = it * kRowsPerIt + (tid >> 4);
         const int r = m0 + row;
         if (r >= p.M || nc >= p.N) continue;
         bool halo = false;
@@ -208,6 +239,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const NTParams p) 
     }
 }
 
+template <int BM, int NW, int STAGES>
+int launch_nt(const NTParams& p, int batch, hipStream_t st) {
+    using C_ = Cfg<BM, NW, STAGES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, NW, STAGES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, C_::kSmemBytes) != hipSuccess)
+            return SISS_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, batch);
+    gemm_nt_kernel<BM, NW, STAGES><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
@@ -233,16 +279,14 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
     for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
-            return SISS_ERR_LAUNCH;
-        attr_set = true;
-    }
-    const int tiles = cdiv(M, BM) * cdiv(N, BN);
-    dim3 grid(tiles, 1, batch);
-    gemm_nt_kernel<<<grid, kThreads, kSmemBytes, (hipStream_t)stream>>>(p);
-    SISS_LAUNCH_RET();
+    // big problems: 256-row tiles (one 8-wave block per CU, 3-stage ring); otherwise 128-row tiles
+    const long big_tiles = (long)cdiv(M, 256) * cdiv(N, BN) * batch;
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("SISS_NT_TILE"); force = e ? atoi(e) : 0; }
+    // measured (tools/bench_kernels.py, round 1): the 8-wave / 3-stage variant is 5-15 % SLOWER than two
+    // co-resident 4-wave blocks at every CelebA-HQ layer shape, so it is opt-in (SISS_NT_TILE=256)
+    const bool big = force == 256 && big_tiles >= 1;
+    return big ? launch_nt<256, 8, 3>(p, batch, (hipStream_t)stream) : launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
 }
 
 }  // extern "C"

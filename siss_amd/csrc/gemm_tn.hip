@@ -17,14 +17,12 @@
 // Split-K over row ranges; partial tiles are accumulated with f32 global atomics (no-return
 // global_atomic_add_f32; 16 consecutive floats per lane group).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BN = 128, BC = 128, BR = 64;   // output tile 128(n) x 128(c); 64 reduction rows / step
-constexpr int kThreads = 256;
-constexpr int kTile = BR * 256;              // 16 KiB per operand tile
-constexpr int kStageBytes = 2 * kTile;
-constexpr int kSmemBytes = 2 * kStageBytes;
+constexpr int kYTile = BR * 256;             // 16 KiB
 constexpr int kMaxPanels = 9;
 
 struct TNParams {
@@ -47,24 +45,45 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 __device__ __forceinline__ s16x4_t tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const TNParams p) {
+// TAPS = 1: one panel per block (1x1 convs, linears, stride-2 panels with channel offsets).
+// TAPS = 3: the three kx taps of one filter row share the block: their X rows are the SAME rows shifted
+//           by one, so the X tile is staged once with two extra rows and read at row offsets 0/1/2, and
+//           the Y tile is staged once for three products -- a third of the DMA instructions, HBM/L2 bytes
+//           and barriers per MFMA, and two thirds of the LDS reads.
+template <int TAPS>
+struct TCfg {
+    static constexpr int kWaves = TAPS == 3 ? 8 : 4;              // 3 taps: 8 waves of 64(n) x 32(c) keep 96 acc VGPRs
+    static constexpr int kThreads = kWaves * 64;
+    static constexpr int kCT = TAPS == 3 ? 2 : 4;                 // 16-wide c-tiles per wave
+    static constexpr int kPieces = 16 / kWaves;                   // 4-row DMA pieces per wave and operand
+    static constexpr int kXRows = BR + (TAPS == 3 ? 4 : 0);       // 64 (+ one extra 4-row DMA piece)
+    static constexpr int kStageBytes = kYTile + kXRows * 256;
+    static constexpr int kSmemBytes = 2 * kStageBytes;
+};
+
+template <int TAPS>
+__global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const TNParams p) {
+    using C_ = TCfg<TAPS>;
+    constexpr int NP = C_::kPieces, CT = C_::kCT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = w >> 1, wc = w & 1;
-    // Grid is 1-D.  Logical order: panel (tap) fastest, then tile, then split, then set -- and each XCD
-    // (blocks b, b+8, ... share an L2) gets a CONTIGUOUS run of logical blocks, so the nine taps that
-    // stream the same Y / X rows run together on one XCD and eight of the nine re-reads hit in L2
+    const int wn = TAPS == 3 ? w >> 2 : w >> 1, wc = TAPS == 3 ? w & 3 : w & 1;   // wave tile 64(n) x (CT*16)(c)
+    // Grid is 1-D.  Logical order: panel group fastest, then tile, then split, then set -- and each XCD
+    // (blocks b, b+8, ... share an L2) gets a CONTIGUOUS run of logical blocks, so the blocks that
+    // stream the same Y / X rows run together on one XCD and their re-reads hit in L2
     // (measured before this remap: 5 % L2 hit rate, 9x the operand bytes from HBM).
     const int tiles_c = (p.C + BC - 1) / BC, tiles_n = (p.N + BN - 1) / BN;
+    const int ngroups = p.npanels / TAPS;
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int pn = bid % p.npanels; bid /= p.npanels;
+    const int pn = (bid % ngroups) * TAPS; bid /= ngroups;
     const int tile = bid % (tiles_c * tiles_n); bid /= tiles_c * tiles_n;
     const int split = bid % p.nsplits;
     const int set = bid / p.nsplits;
@@ -75,97 +94,139 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const TNParams p) 
     if (r0 >= r1) return;
     const int steps = (r1 - r0 + BR - 1) / BR;
 
-    // staging: 4 pieces of 4 rows (256 B each) per wave and operand
-    const bf16_t* ysrc[4];
-    const bf16_t* xsrc[4];
+    // staging: 4 pieces of 4 rows (256 B each) per wave and operand (+ one extra X piece on wave 0)
+    const bf16_t* ysrc[NP];
+    const bf16_t* xsrc[NP];
+    const bf16_t* xsrc_extra = nullptr;
     const bf16_t* zsrc = p.zero_page + (lane & 15) * 8;
-    int trow[4];
+    int trow[NP];
+    const long xrow0 = (long)set * p.x_set_rows + r0 + p.shift[pn];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = w * 16 + j * 4 + (lane >> 4);
-        const int lc = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    for (int j = 0; j < NP; ++j) {
+        const int row = (w * NP + j) * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ swz(row);
         trow[j] = row;
         const long ry = (long)set * p.rows_per_set + r0 + row;
-        const long rx = (long)set * p.x_set_rows + r0 + row + p.shift[pn];
         ysrc[j] = p.Y + ry * p.ldy + n0 + lc * 8;
-        xsrc[j] = p.X + rx * p.ldx + p.coff[pn] + c0 + lc * 8;
+        xsrc[j] = p.X + (xrow0 + row) * p.ldx + p.coff[pn] + c0 + lc * 8;
     }
+    if (TAPS == 3) {
+        const int row = BR + (lane >> 4);
+        xsrc_extra = p.X + (xrow0 + row) * p.ldx + p.coff[pn] + c0 + ((lane & 15) ^ swz(row)) * 8;
+    }
+    const long ystep = (long)BR * p.ldy, xstep = (long)BR * p.ldx;
     auto stage = [&](int buf, int step) {
-        char* base = smem + buf * kStageBytes + (w * 16) * 256;
+        char* base = smem + buf * C_::kStageBytes + (w * NP * 4) * 256;
         const int rbase = r0 + step * BR;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const bool ok = rbase + trow[j] < r1;
-            glds16(ok ? ysrc[j] + (long)step * BR * p.ldy : zsrc, base + j * 1024);
+            glds16(ok ? ysrc[j] + step * ystep : zsrc, base + j * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = rbase + trow[j] < r1;
-            glds16(ok ? xsrc[j] + (long)step * BR * p.ldx : zsrc, base + kTile + j * 1024);
+        for (int j = 0; j < NP; ++j) {
+            // an X row matters only if one of the (up to TAPS) Y rows it meets is in range; everything
+            // else comes from the zero page (never read past the operand; 0 * garbage could be NaN)
+            const bool ok = rbase + trow[j] - (TAPS - 1) < r1;
+            glds16(ok ? xsrc[j] + step * xstep : zsrc, base + kYTile + j * 1024);
+        }
+        if (TAPS == 3 && w == 0) {
+            const bool ok = rbase + BR + (lane >> 4) - (TAPS - 1) < r1;
+            glds16(ok ? xsrc_extra + step * xstep : zsrc, smem + buf * C_::kStageBytes + kYTile + BR * 256);
         }
     };
 
-    f32x4_t acc[4][4];   // [n-tile][c-tile]
+    f32x4_t acc[TAPS][4][CT];   // [tap][n-tile][c-tile]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // transposed-read addresses: 16-lane group g covers reduction rows 8g..8g+7 of a 32-row
     // k-step in two 4-row blocks (h); lane 4q+pp of the group addresses row q, columns 4pp..4pp+3.
+    // For tap t the X rows are shifted by t; the swizzle is a function of the PHYSICAL row, and
+    // (row + 32) has the same swizzle, so kk adds a plain 8192 bytes.
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    int y_off[2], x_off[2];
+    int y_off[2], x_off[TAPS][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int row = 8 * g + 4 * h + q;
-        const int sw = (q << 2) | ((2 * g + h) & 3);
-        y_off[h] = row * 256 + ((((wn * 8) | (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
-        x_off[h] = kTile + row * 256 + ((((wc * 8) | (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
+        y_off[h] = row * 256 + ((((wn * 8) | (pp >> 1)) ^ swz(row)) << 4) + 8 * (pp & 1);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int xr = row + t;
+            x_off[t][h] = kYTile + xr * 256 + ((((wc * CT * 2) | (pp >> 1)) ^ swz(xr)) << 4) + 8 * (pp & 1);
+        }
     }
 
-    // One barrier per K-step: the barrier at the top of step s orders (a) every wave's counted wait for
-    // its own step-s DMA (RAW on buf) and (b) every wave's last read of buf^1 in step s-1 (WAR for the
-    // restage issued right after it).
+    // One barrier per K-step (see gemm_nt.hip): wait own DMA + own LDS reads, barrier, restage, compute.
     stage(0, 0);
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA landed, own LDS reads retired
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (s + 1 < steps) stage(buf ^ 1, s + 1);
-        const char* sb = smem + buf * kStageBytes;
+        const char* sb = smem + buf * C_::kStageBytes;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t yf[4], xf[4];
+            bf16x8_t yf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 s16x4_t a0 = tr_read(sb + ((y_off[0] ^ (i << 5)) + kk * 8192));
                 s16x4_t a1 = tr_read(sb + ((y_off[1] ^ (i << 5)) + kk * 8192));
-                s16x4_t b0 = tr_read(sb + ((x_off[0] ^ (i << 5)) + kk * 8192));
-                s16x4_t b1 = tr_read(sb + ((x_off[1] ^ (i << 5)) + kk * 8192));
                 yf[i] = bf16x8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                xf[i] = bf16x8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int t = 0; t < TAPS; ++t) {
+                bf16x8_t xf[CT];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < CT; ++i) {
+                    s16x4_t b0 = tr_read(sb + ((x_off[t][0] ^ (i << 5)) + kk * 8192));
+                    s16x4_t b1 = tr_read(sb + ((x_off[t][1] ^ (i << 5)) + kk * 8192));
+                    xf[i] = bf16x8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < CT; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[t][i][j], 0, 0, 0);
+            }
         }
     }
 
-    // acc[i][j][r]: n = n0 + wn*64 + i*16 + (lane>>4)*4 + r, c = c0 + wc*64 + j*16 + (lane&15)
-    float* out = p.dW + (long)set * p.set_stride + (long)pn * p.N * p.C;
+    // acc[t][i][j][r]: n = n0 + wn*64 + i*16 + (lane>>4)*4 + r, c = c0 + wc*64 + j*16 + (lane&15)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int t = 0; t < TAPS; ++t) {
+        float* out = p.dW + (long)set * p.set_stride + (long)(pn + t) * p.N * p.C;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = c0 + wc * 64 + j * 16 + (lane & 15);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
-                if (n < p.N && c < p.C) atomicAdd(out + (long)n * p.C + c, acc[i][j][r]);
+            for (int j = 0; j < CT; ++j) {
+                const int c = c0 + wc * CT * 16 + j * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                    if (n < p.N && c < p.C) atomicAdd(out + (long)n * p.C + c, acc[t][i][j][r]);
+                }
             }
-        }
+    }
+}
+
+template <int TAPS>
+int launch_tn(const TNParams& p, hipStream_t st) {
+    using C_ = TCfg<TAPS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_tn_kernel<TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C_::kSmemBytes) != hipSuccess)
+            return SISS_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits);
+    gemm_tn_kernel<TAPS><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -193,15 +254,15 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
     p.rows_per_split = rps;
     for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes) != hipSuccess)
-            return SISS_ERR_LAUNCH;
-        attr_set = true;
-    }
-    dim3 grid(cdiv(N, BN) * cdiv(C, BC) * npanels * nsets * nsplits);
-    gemm_tn_kernel<<<grid, kThreads, kSmemBytes, (hipStream_t)stream>>>(p);
-    SISS_LAUNCH_RET();
+    // 3x3 filter rows: panels come in triples whose shifts are consecutive rows with equal channel offsets
+    bool triples = npanels % 3 == 0;
+    for (int g = 0; triples && g < npanels / 3; ++g)
+        triples = p.shift[3 * g + 1] == p.shift[3 * g] + 1 && p.shift[3 * g + 2] == p.shift[3 * g] + 2 &&
+                  p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
+    static int force1 = -1;
+    if (force1 < 0) { const char* e = getenv("SISS_TN_TAPS"); force1 = e ? atoi(e) : 0; }
+    if (triples && force1 != 1) return launch_tn<3>(p, (hipStream_t)stream);
+    return launch_tn<1>(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -81,9 +81,22 @@ def conv_dgrad(dy: Act, wT_bf16, out: Act, residual: Act = None, ksize=3):
     return out
 
 
-def _nsplits(base_blocks, rows):
-    want = max(1, -(-1024 // base_blocks))
-    return max(1, min(want, -(-rows // 512)))
+def _nsplits(tiles, npanels, nsets, rows, fused3):
+    """Split-K factor of the wgrad GEMM.  The fused 3-tap kernel runs ONE 8-wave block per CU and every
+    block does the same amount of work, so the grid must not spill into a second, mostly empty round:
+    choose the largest split count whose grid still fits one round of 256 CUs (two rounds of 2 blocks/CU
+    for the one-panel kernel), with at least 4 K-steps (256 rows) per block."""
+    groups = npanels // 3 if fused3 else npanels
+    base = tiles * groups * nsets
+    slots = 256 if fused3 else 512
+    ns = max(1, slots // base)
+    return max(1, min(ns, rows // 256))
+
+
+def is_conv3_panels(shifts, coffs):
+    return len(shifts) % 3 == 0 and all(
+        shifts[3 * g + 1] == shifts[3 * g] + 1 and shifts[3 * g + 2] == shifts[3 * g] + 2
+        and coffs[3 * g] == coffs[3 * g + 1] == coffs[3 * g + 2] for g in range(len(shifts) // 3))
 
 
 def conv_wgrad(dy: Act, x: Act, dW, nsets, ksize=3):
@@ -102,7 +115,7 @@ def conv_wgrad(dy: Act, x: Act, dW, nsets, ksize=3):
     x_set_rows = 0 if x.n == b else rows_per_set
     rb, re = dy.wp + 1, rows_per_set - (dy.wp + 1)
     tiles = (-(-co // 128)) * (-(-ci // 128))
-    ns = _nsplits(tiles * t * nsets, re - rb)
+    ns = _nsplits(tiles, t, nsets, re - rb, is_conv3_panels(shifts, coffs))
     lib.call("siss_gemm_tn", dy.data, dy.c, x.data, x.c, dW, t * co * ci, co, ci, t,
              lib.int_array(shifts), lib.int_array(coffs), nsets, rows_per_set, x_set_rows, rb, re, ns,
              zero_page(dy.buf.device))

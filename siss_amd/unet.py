@@ -392,7 +392,7 @@ class UNetEngine:
         x_set_rows = rows_per_set if x.n == dy.n else 0      # 0: every set reads the same saved rows
         rb, re = dy.wp + 1, rows_per_set - (dy.wp + 1)
         tiles = (-(-co // 128)) * (-(-ci // 128))
-        ns = ops._nsplits(tiles * t * self.nsets, re - rb)
+        ns = ops._nsplits(tiles, t, self.nsets, re - rb, ops.is_conv3_panels(shifts, coffs))
         lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or x.c, dW_view, ps.total, co, ci, t,
                  lib.int_array(shifts), lib.int_array(coffs), self.nsets, rows_per_set, x_set_rows, rb, re, ns,
                  ops.zero_page(self.device))
