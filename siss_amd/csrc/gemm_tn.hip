@@ -27,6 +27,7 @@ constexpr int kMaxPanels = 9;
 
 struct TNParams {
     const bf16_t* Y; const bf16_t* X; float* dW; const bf16_t* zero_page;
+    float* dbias; float* dbias2;          // optional: column sums of Y per set (bias gradients)
     long ldy, ldx, set_stride;
     long x_set_rows;
     int N, C, npanels, nsets, nsplits;
@@ -144,6 +145,14 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
 #pragma unroll
             for (int j = 0; j < CT; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // Bias gradient for free: column sums of Y are one more product, Y^T . 1, taken by the waves that own
+    // c-tile 0 of panel group 0 (every (set, split, n-tile) exactly once).
+    const bool do_bias = p.dbias != nullptr && pn == 0 && tc == 0 && wc == 0;
+    f32x4_t bacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
     // transposed-read addresses: 16-lane group g covers reduction rows 8g..8g+7 of a 32-row
     // k-step in two 4-row blocks (h); lane 4q+pp of the group addresses row q, columns 4pp..4pp+3.
     // For tap t the X rows are shifted by t; the swizzle is a function of the PHYSICAL row, and
@@ -178,6 +187,10 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
                 s16x4_t a1 = tr_read(sb + ((y_off[1] ^ (i << 5)) + kk * 8192));
                 yf[i] = bf16x8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             }
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, bacc[i], 0, 0, 0);
+            }
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 bf16x8_t xf[CT];
@@ -196,6 +209,18 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
         }
     }
 
+    if (do_bias && (lane & 15) == 0) {      // every column of bacc holds the same sums; lane&15 == 0 keeps column 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                if (n < p.N) {
+                    atomicAdd(p.dbias + (long)set * p.set_stride + n, bacc[i][r]);
+                    if (p.dbias2) atomicAdd(p.dbias2 + (long)set * p.set_stride + n, bacc[i][r]);
+                }
+            }
+    }
     // acc[t][i][j][r]: n = n0 + wn*64 + i*16 + (lane>>4)*4 + r, c = c0 + wc*64 + j*16 + (lane&15)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
@@ -234,11 +259,12 @@ int launch_tn(const TNParams& p, hipStream_t st) {
 extern "C" {
 
 // dW must be zeroed (or hold the running sum for gradient accumulation) before the call.
+// dbias / dbias2 (optional): dbias[set*set_stride + n] += sum over the set's rows of Y[r][n].
 // Rows [row_begin, row_end) of every set are reduced; shifts/coffs are HOST arrays.
 int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
                  int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
                  long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
-                 void* stream) {
+                 float* dbias, float* dbias2, void* stream) {
     SISS_CHECK_ARG(Y && X && dW && shifts && coffs && zero_page);
     SISS_CHECK_ARG(N > 0 && C > 0 && npanels >= 1 && npanels <= kMaxPanels && nsets >= 1 && nsplits >= 1);
     SISS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && N % 8 == 0 && C % 8 == 0);
@@ -246,6 +272,7 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
     SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set);
     TNParams p;
     p.Y = (const bf16_t*)Y; p.X = (const bf16_t*)X; p.dW = dW; p.zero_page = (const bf16_t*)zero_page;
+    p.dbias = dbias; p.dbias2 = dbias ? dbias2 : nullptr;
     p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.x_set_rows = x_set_rows;
     p.N = N; p.C = C; p.npanels = npanels; p.nsets = nsets; p.nsplits = nsplits;
     p.rows_per_set = rows_per_set; p.row_begin = row_begin; p.row_end = row_end;

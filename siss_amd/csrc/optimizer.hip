@@ -153,6 +153,37 @@ __global__ void conv_weight_dgrad_kernel(const float* __restrict__ w, bf16_t* __
     }
 }
 
+
+// All dgrad weight copies in ONE launch.  job table (device): per weight {src off (floats), dst off (bf16
+// elements), taps, co, ci, first tile}; a block finds its job by binary search over `first tile`.
+struct WtJob { long src, dst; int taps, co, ci, tile0; };
+
+__global__ void conv_weight_dgrad_multi_kernel(const float* __restrict__ flat, bf16_t* __restrict__ wt_all,
+                                               const WtJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WtJob j = jobs[lo];
+    int t = blockIdx.x - j.tile0;
+    const int tc = (j.ci + 31) / 32, to = (j.co + 31) / 32;
+    const int tap = t / (tc * to); t -= tap * tc * to;
+    const int o0 = (t / tc) * 32, c0 = (t % tc) * 32;
+    const float* src = flat + j.src + (long)tap * j.co * j.ci;
+    bf16_t* dst = wt_all + j.dst + (long)(j.taps - 1 - tap) * j.co * j.ci;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int o = o0 + r, c = c0 + threadIdx.x;
+        tile[r][threadIdx.x] = (o < j.co && c < j.ci) ? src[(long)o * j.ci + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int c = c0 + r, o = o0 + threadIdx.x;
+        if (c < j.ci && o < j.co) dst[(long)c * j.co + o] = f2bf(tile[threadIdx.x][r]);
+    }
+}
+
 inline int grid_for(long n) {
     long b = (n / 4 + kThreads - 1) / kThreads;
     if (b < 1) b = 1;
@@ -203,6 +234,16 @@ int siss_conv_weight_dgrad_layout(const float* w, void* wt, int taps, int co, in
     SISS_CHECK_ARG(w && wt && taps > 0 && co > 0 && ci > 0);
     dim3 grid(cdiv(ci, 32), cdiv(co, 32), taps), block(32, 8);
     conv_weight_dgrad_kernel<<<grid, block, 0, (hipStream_t)stream>>>(w, reinterpret_cast<bf16_t*>(wt), taps, co, ci);
+    SISS_LAUNCH_RET();
+}
+
+// jobs: device array of njobs records {long src_off, long dst_off, int taps, int co, int ci, int tile0}
+// (tile0 = running sum of taps*ceil(co/32)*ceil(ci/32)); total_tiles = the grid size.
+int siss_conv_weight_dgrad_multi(const float* flat, void* wt_all, const void* jobs, int njobs, int total_tiles,
+                                 void* stream) {
+    SISS_CHECK_ARG(flat && wt_all && jobs && njobs > 0 && total_tiles > 0);
+    conv_weight_dgrad_multi_kernel<<<total_tiles, dim3(32, 8), 0, (hipStream_t)stream>>>(
+        flat, reinterpret_cast<bf16_t*>(wt_all), reinterpret_cast<const WtJob*>(jobs), njobs);
     SISS_LAUNCH_RET();
 }
 

@@ -27,8 +27,9 @@ SIGNATURES = {
     "siss_recombine_clip_adamw": [P, P, P, P, P, P, P, L, F, F, F, F, F, P, P],
     "siss_cast_f32_bf16": [P, P, L, P],
     "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],
+    "siss_conv_weight_dgrad_multi": [P, P, P, I, I, P],
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
-    "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P],
+    "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
     "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],

@@ -99,7 +99,7 @@ def is_conv3_panels(shifts, coffs):
         and coffs[3 * g] == coffs[3 * g + 1] == coffs[3 * g + 2] for g in range(len(shifts) // 3))
 
 
-def conv_wgrad(dy: Act, x: Act, dW, nsets, ksize=3):
+def conv_wgrad(dy: Act, x: Act, dW, nsets, ksize=3, dbias=None):
     """dW[set][T][Co][Ci] += dy^T x over each set's images (dy has nsets*B images; x has B or nsets*B)."""
     co, ci = dy.c, x.c
     assert dy.n % nsets == 0
@@ -118,5 +118,5 @@ def conv_wgrad(dy: Act, x: Act, dW, nsets, ksize=3):
     ns = _nsplits(tiles, t, nsets, re - rb, is_conv3_panels(shifts, coffs))
     lib.call("siss_gemm_tn", dy.data, dy.c, x.data, x.c, dW, t * co * ci, co, ci, t,
              lib.int_array(shifts), lib.int_array(coffs), nsets, rows_per_set, x_set_rows, rb, re, ns,
-             zero_page(dy.buf.device))
+             zero_page(dy.buf.device), dbias, None)
     return dW

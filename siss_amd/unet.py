@@ -263,17 +263,31 @@ class UNetEngine:
         ps = self.ps
         if cast_shadow:
             lib.call("siss_cast_f32_bf16", ps.flat, ps.shadow, ps.total)
+        if not self.wT:
+            self._build_wt_jobs()
+        lib.call("siss_conv_weight_dgrad_multi", ps.flat, self._wt_all, self._wt_jobs, self._wt_njobs,
+                 self._wt_tiles)
+
+    def _build_wt_jobs(self):
+        """One bf16 buffer holding every dgrad weight copy ([taps][Cin][Cout], tap order reversed) and the
+        job table of the batched transpose kernel."""
+        import numpy as np
+        ps = self.ps
+        jobs, off, tiles = [], 0, 0
         for n, sp in ps.specs.items():
             if sp.kind in ("conv3", "conv1", "mat") and n != "conv_out.weight" and "time_emb" not in n:
-                if sp.kind == "conv3":
-                    t, co, ci = sp.native_shape
-                else:
-                    t, (co, ci) = 1, sp.native_shape
-                wt = self.wT.get(n)
-                if wt is None:
-                    wt = torch.empty(t, ci, co, dtype=torch.bfloat16, device=self.device)
-                    self.wT[n] = wt
-                lib.call("siss_conv_weight_dgrad_layout", ps.p(n), wt, t, co, ci)
+                t, co, ci = sp.native_shape if sp.kind == "conv3" else (1, *sp.native_shape)
+                jobs.append((n, sp.off, off, t, co, ci, tiles))
+                off += -(-t * co * ci // 64) * 64
+                tiles += t * (-(-co // 32)) * (-(-ci // 32))
+        self._wt_all = torch.empty(off, dtype=torch.bfloat16, device=self.device)
+        rec = np.zeros(len(jobs), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("co", "<i4"),
+                                                   ("ci", "<i4"), ("tile0", "<i4")]))
+        for i, (n, src, dst, t, co, ci, t0) in enumerate(jobs):
+            rec[i] = (src, dst, t, co, ci, t0)
+            self.wT[n] = self._wt_all[dst:dst + t * co * ci].view(t, ci, co)
+        self._wt_jobs = torch.from_numpy(rec.view(np.uint8)).to(self.device)
+        self._wt_njobs, self._wt_tiles = len(jobs), tiles
 
     # ------------------------------------------------------------------ buffers
     def _act(self, name, n, h, w, c):
@@ -364,12 +378,10 @@ class UNetEngine:
         ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
 
         def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None):
-            if bias_grad:
-                lib.call("siss_colsum", dy.data, self.set_images * dy.rows_per_image, co, self.nsets, ps.total,
-                         ps.g(pre + ".bias", self.gbase), bias_grad2)
-            t = 9 if ksize == 3 else 1
             dW = ps.grads[self.gbase:, ps.specs[pre + ".weight"].off:]
-            self._wgrad(dy, x, dW, co, x.c, ksize)
+            # the bias gradient (column sums of dy) rides along in the wgrad GEMM as one more product
+            self._wgrad(dy, x, dW, co, x.c, ksize, dbias=ps.g(pre + ".bias", self.gbase) if bias_grad else None,
+                        dbias2=bias_grad2)
             if not need_dx:
                 return None
             dx = accum if accum is not None else self._get(dy.n, x.h, x.w, x.c)
@@ -377,7 +389,8 @@ class UNetEngine:
             return dx
         return y, bwd
 
-    def _wgrad(self, dy: Act, x: Act, dW_view, co, ci, ksize, shifts=None, coffs=None, ldx=None):
+    def _wgrad(self, dy: Act, x: Act, dW_view, co, ci, ksize, shifts=None, coffs=None, ldx=None, dbias=None,
+               dbias2=None):
         """dW_view: grads[gbase:, off:] -- a strided view whose [0,0] element is the target."""
         ps = self.ps
         if shifts is None:
@@ -395,7 +408,7 @@ class UNetEngine:
         ns = ops._nsplits(tiles, t, self.nsets, re - rb, ops.is_conv3_panels(shifts, coffs))
         lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or x.c, dW_view, ps.total, co, ci, t,
                  lib.int_array(shifts), lib.int_array(coffs), self.nsets, rows_per_set, x_set_rows, rb, re, ns,
-                 ops.zero_page(self.device))
+                 ops.zero_page(self.device), dbias, dbias2)
 
     # ------------------------------------------------------------------ time embedding
     def time_embed(self, t):
@@ -512,11 +525,10 @@ class UNetEngine:
 
             def lin_bwd(dyt, xin, wname, dx_out, accumulate):
                 """dyt [rows2,C] cotangent of y = xin W^T + b (xin has B*S rows shared by the sets)."""
-                lib.call("siss_colsum", dyt, si * S, C, ns, ps.total, ps.g(wname + ".bias", gb), None)
                 dW = ps.grads[gb:, ps.specs[wname + ".weight"].off:]
                 lib.call("siss_gemm_tn", dyt, C, xin, C, dW, ps.total, C, C, 1, lib.int_array([0]),
                          lib.int_array([0]), ns, si * S, si * S if B == nb else 0,
-                         0, si * S, 1, zp)
+                         0, si * S, 1, zp, ps.g(wname + ".bias", gb), None)
                 if dx_out is not None:
                     ops.gemm_nt(lib.ptr(dyt), C, self.wT[wname + ".weight"], lib.ptr(dx_out), C, rows2, C, C,
                                 [0], [0], res_ptr=lib.ptr(dx_out) if accumulate else None, ldr=C)
@@ -535,7 +547,7 @@ class UNetEngine:
                             stride_a=S * C, stride_w=S * C, stride_c=S * S)
                 # dV[key][c] = sum_q P[q][key] dO[q][c]
                 lib.call("siss_gemm_tn", p, S, do[g * B * S:], C, dvf[sl], S * C, S, C, 1, lib.int_array([0]),
-                         lib.int_array([0]), B, S, S, 0, S, 1, zp)
+                         lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
             lib.call("siss_softmax_bwd", p, dp, ds, nb * S, B * S, S, float(scale))
             for g in range(nb // B):
                 sl = slice(g * B, (g + 1) * B)
@@ -544,7 +556,7 @@ class UNetEngine:
                             stride_a=S * S, stride_w=C * S, stride_c=S * C)
                 # dK[key][c] = sum_q dS[q][key] Q[q][c]
                 lib.call("siss_gemm_tn", ds[sl], S, q, C, dkf[sl], S * C, S, C, 1, lib.int_array([0]),
-                         lib.int_array([0]), B, S, S, 0, S, 1, zp)
+                         lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
             lib.call("siss_cast_f32_bf16", dkf, dk, dkf.numel())
             lib.call("siss_cast_f32_bf16", dvf, dv, dvf.numel())
             dhn = tb(".dhn", (rows2, C))
@@ -580,10 +592,8 @@ class UNetEngine:
         def bwd():
             nb, gb = self.nb, self.gbase
             dy = self._take(y)
-            lib.call("siss_colsum", dy.data, self.set_images * dy.rows_per_image, C, self.nsets, ps.total,
-                     ps.g(pre + ".conv.bias", gb), None)
             dW = ps.grads[gb:, ps.specs[pre + ".conv.weight"].off:]
-            self._wgrad(dy, z, dW, C, C, 3, shifts=shifts, coffs=coffs, ldx=4 * C)
+            self._wgrad(dy, z, dW, C, C, 3, shifts=shifts, coffs=coffs, ldx=4 * C, dbias=ps.g(pre + ".conv.bias", gb))
             dz = self._get(nb, Ho, Wo, 4 * C)
             wT = self.wT[pre + ".conv.weight"]          # [9][Ci][Co], index 8 - tap holds W[tap]^T
             seen = set()
@@ -661,10 +671,8 @@ class UNetEngine:
 
         def conv_in_bwd():
             dh = self._take(h0)
-            lib.call("siss_colsum", dh.data, self.set_images * dh.rows_per_image, c0, self.nsets, ps.total,
-                     ps.g("conv_in.bias", self.gbase), None)
             dW = ps.grads[self.gbase:, ps.specs["conv_in.weight"].off:]
-            self._wgrad(dh, col, dW, c0, kp, 1)
+            self._wgrad(dh, col, dW, c0, kp, 1, dbias=ps.g("conv_in.bias", self.gbase))
             self._put(dh)
         self.tape.append(conv_in_bwd)
 
