@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int BN = 128, BK = 64;
-constexpr int kCRow = BN * 4 + 16;                       // f32 epilogue row, padded (bank spread)
+constexpr int kCRow = BN * 2 + 16;                       // bf16 epilogue row (256 B) + 16 B pad (bank spread, 16-B aligned)
 constexpr int kMaxPanels = 9;
 
 struct NTParams {
@@ -35,7 +35,8 @@ struct NTParams {
     long strideA, strideW, strideC;   // per blockIdx.z batch (elements)
     int M, N, Kp, npanels;
     int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
-    float alpha;
+    float alpha, inv_wp;
+    int ablate;
     int shift[kMaxPanels];
     int coff[kMaxPanels];
 };
@@ -64,7 +65,7 @@ struct Cfg {
 };
 
 template <int BM, int NW, int STAGES>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void gemm_nt_kernel(const NTParams p) {
+__global__ __launch_bounds__(NW * 64, (STAGES == 1 ? 4 : 2)) void gemm_nt_kernel(const NTParams p) {
     using C_ = Cfg<BM, NW, STAGES>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -107,8 +108,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void gemm_nt_kernel(con
     const int steps = p.npanels * kchunks;
     const long wpanel = (long)p.N * p.Kp;
 
+    int st_pn = 0, st_kc = 0;                  // (panel, k-chunk) of the NEXT stage() call: steps are staged in order
     auto stage = [&](int buf, int step) {
-        const int pn = step / kchunks, kc = step - pn * kchunks;
+        (void)step;
+        const int pn = st_pn, kc = st_kc;
+        if (++st_kc == kchunks) { st_kc = 0; ++st_pn; }
         const long aoff = (long)p.shift[pn] * p.lda + p.coff[pn] + kc * BK;
         const long woff = pn * wpanel + kc * BK;
         char* base = smem + buf * C_::kStageBytes;
@@ -144,13 +148,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void gemm_nt_kernel(con
         if (s < steps) stage(s, s);
     int buf = 0, nbuf = STAGES - 1;
     for (int s = 0; s < steps; ++s) {
-        if (STAGES == 3 && s + 1 < steps)
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C_::kPerStage) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (s + STAGES - 1 < steps) stage(nbuf, s + STAGES - 1);
+        if (STAGES == 1) {
+            // single buffer, two barriers per step: latency is hidden only by the OTHER resident blocks
+            // (34 KiB of LDS per block -> 4 blocks per CU)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!((p.ablate & 2) && s >= 2)) stage(0, s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            if (STAGES == 3 && s + 1 < steps)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C_::kPerStage) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + STAGES - 1 < steps && !((p.ablate & 2) && s >= 2)) stage(nbuf, s + STAGES - 1);
+        }
         const char* sb = smem + buf * C_::kStageBytes;
+        if (!(p.ablate & 4))
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t af[4], wf[4];
@@ -171,70 +186,82 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 2)) void gemm_nt_kernel(con
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue: f32 through LDS, then coalesced bf16 rows ----
-    // acc[i][j][r]: channel n = wn*64 + i*16 + fq*4 + r, pixel m = wm*64 + j*16 + frow
+    // ---- epilogue: bf16 tile through LDS (one 34 KiB image), then 16-B coalesced rows ----
+    // Registers: acc[i][j][r] = channel n = wn*64 + i*16 + fq*4 + r of pixel m = wm*64 + j*16 + frow.
+    // alpha, bias and the per-image row bias (time embedding) are applied in f32 BEFORE the one rounding to
+    // bf16; the residual (if any) is added after it, which is exactly the reference's autocast order
+    // (conv output is bf16, then `x + h` rounds again).
+    const int rpi = p.rows_per_image;
+    const int img0 = m0 / rpi;                       // tile rows span at most 3 images (rows_per_image >= 64)
+    const int b1 = (img0 + 1) * rpi - m0, b2 = b1 + rpi;
+    {
+        f32x4_t bias4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fq * 4;
+            bias4[i] = (p.bias && n + 4 <= p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = wm * 64 + j * 16 + frow, n = wn * 64 + i * 16 + fq * 4;
-            f32x4_t v = acc[i][j];
+            const int m = wm * 64 + j * 16 + frow;
+            const float* rb = nullptr;
+            if (p.rowbias) rb = p.rowbias + (long)(img0 + (m >= b1) + (m >= b2)) * p.ldrb;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-            *reinterpret_cast<f32x4_t*>(smem + m * kCRow + n * 4) = v;
+            for (int i = 0; i < 4; ++i) {
+                const int nl = wn * 64 + i * 16 + fq * 4;
+                f32x4_t v = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[i][r];
+                if (rb && n0 + nl + 4 <= p.N) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rb + n0 + nl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += t[r];
+                }
+                *reinterpret_cast<u32x2_t*>(smem + m * kCRow + nl * 2) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            }
         }
+    }
     __syncthreads();
+    if (p.ablate & 1) return;
     bf16_t* C = p.C + (long)bz * p.strideC;
     const int chunk = tid & 15;           // 8 channels per chunk
     const int nc = n0 + chunk * 8;
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && nc + e < p.N) ? p.bias[nc + e] : 0.f;
-    const int rpi = p.rows_per_image;
+    if (nc >= p.N) return;
     constexpr int kRowsPerIt = C_::kThreads / 16;
-#pragma unroll 2
+#pragma unroll 4
     for (int it = 0; it < BM / kRowsPerIt; ++it) {
         const int row = it * kRowsPerIt + (tid >> 4);
         const int r = m0 + row;
-        if (r >= p.M || nc >= p.N) continue;
-        bool halo = false;
+        if (r >= p.M) break;
+        u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * kCRow + chunk * 16);
         if (p.Hp > 0) {
-            const int rem = r % rpi, y = rem / p.Wp, x = rem - y * p.Wp;
-            halo = (y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1);
-        }
-        float v[8];
-        if (halo) {
+            const int rem = r - (img0 + (row >= b1) + (row >= b2)) * rpi;
+            const int y = (int)(((float)rem + 0.5f) * p.inv_wp), x = rem - y * p.Wp;   // exact: see header note
+            if ((y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1)) o = u32x4_t{0u, 0u, 0u, 0u};
+            else if (p.R && nc + 8 <= p.N) {
+                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        } else {
-            const f32x4_t* src = reinterpret_cast<const f32x4_t*>(smem + row * kCRow + chunk * 32);
-            f32x4_t lo = src[0], hi = src[1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
-            if (p.rowbias) {
-                const float* rb = p.rowbias + (long)(r / rpi) * p.ldrb + nc;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (nc + e < p.N) v[e] += rb[e];
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
+                                    __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
             }
-            if (p.R) {
-                if (nc + 8 <= p.N) {
-                    u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
+        } else if (p.R && nc + 8 <= p.N) {
+            const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __builtin_bit_cast(float, rr[e] << 16);
-                        v[2 * e + 1] += __builtin_bit_cast(float, rr[e] & 0xffff0000u);
-                    }
-                } else {
-                    for (int e = 0; e < 8 && nc + e < p.N; ++e) v[e] += bf2f(p.R[(long)bz * p.strideC + (long)r * p.ldr + nc + e]);
-                }
-            }
+            for (int e = 0; e < 4; ++e)
+                o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
+                                __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
         }
         bf16_t* dst = C + (long)r * p.ldc + nc;
         if (nc + 8 <= p.N) {
-            *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]),
-                                                        pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-        } else {
-            for (int e = 0; e < 8 && nc + e < p.N; ++e) dst[e] = f2bf(v[e]);
+            *reinterpret_cast<u32x4_t*>(dst) = o;
+        } else {        // ragged N tail (N % 8 != 0 never happens for channel counts; kept for safety)
+            for (int e = 0; e < 8 && nc + e < p.N; ++e) {
+                const uint32_t wv = o[e >> 1];
+                float v = (e & 1) ? __builtin_bit_cast(float, wv & 0xffff0000u) : __builtin_bit_cast(float, wv << 16);
+                if (p.R) v += bf2f(p.R[(long)bz * p.strideC + (long)r * p.ldr + nc + e]);
+                dst[e] = f2bf(v);
+            }
         }
     }
 }
@@ -277,6 +304,10 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
     p.M = M; p.N = N; p.Kp = Kp; p.npanels = npanels;
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
+    p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
+    { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+    SISS_CHECK_ARG((!rowbias && Hp == 0) || rows_per_image >= 64);   // <= 3 images per 128/256-row tile
+    SISS_CHECK_ARG(N % 8 == 0 && (!rowbias || ldrb % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0));
     for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
     // big problems: 256-row tiles (one 8-wave block per CU, 3-stage ring); otherwise 128-row tiles
@@ -286,7 +317,14 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     // measured (tools/bench_kernels.py, round 1): the 8-wave / 3-stage variant is 5-15 % SLOWER than two
     // co-resident 4-wave blocks at every CelebA-HQ layer shape, so it is opt-in (SISS_NT_TILE=256)
     const bool big = force == 256 && big_tiles >= 1;
-    return big ? launch_nt<256, 8, 3>(p, batch, (hipStream_t)stream) : launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
+    static int stages = -1;
+    if (stages < 0) { const char* e = getenv("SISS_NT_STAGES"); stages = e ? atoi(e) : 0; }
+    if (big) return launch_nt<256, 8, 3>(p, batch, (hipStream_t)stream);
+    // Large grids: single-buffered blocks at 4 per CU (latency hidden by the other three) measured 10-15 %
+    // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;
+    if (stages == 1 || (stages == 0 && tiles128 >= 2048)) return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
+    return launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
 }
 
 }  // extern "C"
