@@ -19,34 +19,10 @@
 // The MFMA takes the weight fragment as its A operand so that each lane ends up with four
 // CONSECUTIVE output channels of one pixel: the epilogue stages f32 through LDS (528-B padded
 // rows) and writes 16-B coalesced bf16 rows.
-#include "common.h"
+#include "nt_common.h"
 #include <stdlib.h>
 
 namespace {
-
-constexpr int BN = 128, BK = 64;
-constexpr int kCRow = BN * 2 + 16;                       // bf16 epilogue row (256 B) + 16 B pad (bank spread, 16-B aligned)
-constexpr int kMaxPanels = 9;
-
-struct NTParams {
-    const bf16_t* A; const bf16_t* W; bf16_t* C;
-    const float* bias; const float* rowbias; const bf16_t* R;
-    long lda, ldc, ldr, ldrb;
-    long strideA, strideW, strideC;   // per blockIdx.z batch (elements)
-    int M, N, Kp, npanels;
-    int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
-    float alpha, inv_wp;
-    int ablate;
-    int shift[kMaxPanels];
-    int coff[kMaxPanels];
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
-}
 
 // Two instantiations:
 //   <256, 8 waves, 3 stages>  big layers: one 512-thread block per CU (2 waves / SIMD), 144 KiB LDS ring,
@@ -62,11 +38,13 @@ struct Cfg {
     static constexpr int kAPieces = BM / 8 / NW;        // 8-row DMA pieces per wave
     static constexpr int kWPieces = BN / 8 / NW;
     static constexpr int kPerStage = kAPieces + kWPieces;
+    static constexpr int kMT = BM / (NW / 2) / 16;      // 16-row m-tiles per wave: 4 (64x64 wave tile) or 8 (128x64)
 };
 
 template <int BM, int NW, int STAGES>
-__global__ __launch_bounds__(NW * 64, (STAGES == 1 ? 4 : 2)) void gemm_nt_kernel(const NTParams p) {
+__global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void gemm_nt_kernel(const NTParams p) {
     using C_ = Cfg<BM, NW, STAGES>;
+    constexpr int MT = C_::kMT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,19 +100,22 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 ? 4 : 2)) void gemm_nt_kernel
         for (int j = 0; j < C_::kWPieces; ++j) glds16(wsrc[j] + woff, base + BM * 128 + (w * C_::kWPieces + j) * 1024);
     };
 
-    f32x4_t acc[4][4];   // [n-tile][m-tile]
+    f32x4_t acc[4][MT];   // [n-tile][m-tile]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets (bytes within a stage), kk = 0; kk = 1 flips chunk bit 2
     const int frow = lane & 15, fq = lane >> 4;
-    int a_off[4], w_off[4];
+    int a_off[MT], w_off[4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ra = wm * (MT * 16) + i * 16 + frow;
+        a_off[i] = ra * 128 + ((fq ^ ((ra >> 1) & 7)) << 4);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int ra = wm * 64 + i * 16 + frow;
-        a_off[i] = ra * 128 + ((fq ^ ((ra >> 1) & 7)) << 4);
         const int rw = wn * 64 + i * 16 + frow;
         w_off[i] = BM * 128 + rw * 128 + ((fq ^ ((rw >> 1) & 7)) << 4);
     }
@@ -168,16 +149,15 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 ? 4 : 2)) void gemm_nt_kernel
         if (!(p.ablate & 4))
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[4], wf[4];
+            bf16x8_t af[MT], wf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8_t*>(sb + (a_off[i] ^ (kk << 6)));
-                wf[i] = *reinterpret_cast<const bf16x8_t*>(sb + (w_off[i] ^ (kk << 6)));
-            }
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sb + (a_off[i] ^ (kk << 6)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(sb + (w_off[i] ^ (kk << 6)));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < MT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
@@ -186,84 +166,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 ? 4 : 2)) void gemm_nt_kernel
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue: bf16 tile through LDS (one 34 KiB image), then 16-B coalesced rows ----
-    // Registers: acc[i][j][r] = channel n = wn*64 + i*16 + fq*4 + r of pixel m = wm*64 + j*16 + frow.
-    // alpha, bias and the per-image row bias (time embedding) are applied in f32 BEFORE the one rounding to
-    // bf16; the residual (if any) is added after it, which is exactly the reference's autocast order
-    // (conv output is bf16, then `x + h` rounds again).
-    const int rpi = p.rows_per_image;
-    const int img0 = m0 / rpi;                       // tile rows span at most 3 images (rows_per_image >= 64)
-    const int b1 = (img0 + 1) * rpi - m0, b2 = b1 + rpi;
-    {
-        f32x4_t bias4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fq * 4;
-            bias4[i] = (p.bias && n + 4 <= p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = wm * 64 + j * 16 + frow;
-            const float* rb = nullptr;
-            if (p.rowbias) rb = p.rowbias + (long)(img0 + (m >= b1) + (m >= b2)) * p.ldrb;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nl = wn * 64 + i * 16 + fq * 4;
-                f32x4_t v = acc[i][j];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[i][r];
-                if (rb && n0 + nl + 4 <= p.N) {
-                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rb + n0 + nl);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += t[r];
-                }
-                *reinterpret_cast<u32x2_t*>(smem + m * kCRow + nl * 2) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            }
-        }
-    }
-    __syncthreads();
-    if (p.ablate & 1) return;
-    bf16_t* C = p.C + (long)bz * p.strideC;
-    const int chunk = tid & 15;           // 8 channels per chunk
-    const int nc = n0 + chunk * 8;
-    if (nc >= p.N) return;
-    constexpr int kRowsPerIt = C_::kThreads / 16;
-#pragma unroll 4
-    for (int it = 0; it < BM / kRowsPerIt; ++it) {
-        const int row = it * kRowsPerIt + (tid >> 4);
-        const int r = m0 + row;
-        if (r >= p.M) break;
-        u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * kCRow + chunk * 16);
-        if (p.Hp > 0) {
-            const int rem = r - (img0 + (row >= b1) + (row >= b2)) * rpi;
-            const int y = (int)(((float)rem + 0.5f) * p.inv_wp), x = rem - y * p.Wp;   // exact: see header note
-            if ((y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1)) o = u32x4_t{0u, 0u, 0u, 0u};
-            else if (p.R && nc + 8 <= p.N) {
-                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
-                                    __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
-            }
-        } else if (p.R && nc + 8 <= p.N) {
-            const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
-                                __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
-        }
-        bf16_t* dst = C + (long)r * p.ldc + nc;
-        if (nc + 8 <= p.N) {
-            *reinterpret_cast<u32x4_t*>(dst) = o;
-        } else {        // ragged N tail (N % 8 != 0 never happens for channel counts; kept for safety)
-            for (int e = 0; e < 8 && nc + e < p.N; ++e) {
-                const uint32_t wv = o[e >> 1];
-                float v = (e & 1) ? __builtin_bit_cast(float, wv & 0xffff0000u) : __builtin_bit_cast(float, wv << 16);
-                if (p.R) v += bf2f(p.R[(long)bz * p.strideC + (long)r * p.ldr + nc + e]);
-                dst[e] = f2bf(v);
-            }
-        }
-    }
+    nt_epilogue<BM, C_::kThreads, MT>(p, acc, smem, m0, n0, bz, tid, wm, wn, frow, fq);
 }
 
 template <int BM, int NW, int STAGES>
@@ -282,6 +185,8 @@ int launch_nt(const NTParams& p, int batch, hipStream_t st) {
 }
 
 }  // namespace
+
+int siss_launch_gemm_nt_conv3(const void* params, void* stream);   // gemm_nt_conv3.hip
 
 extern "C" {
 
@@ -310,6 +215,17 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     SISS_CHECK_ARG(N % 8 == 0 && (!rowbias || ldrb % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0));
     for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
+    // 3x3 filters on large grids: the fused-tap kernel (A tile shared by the three kx taps)
+    {
+        bool conv3 = npanels == 9 && batch == 1 && Kp % 32 == 0;
+        for (int g = 0; conv3 && g < 3; ++g)
+            conv3 = p.shift[3 * g + 1] == p.shift[3 * g] + 1 && p.shift[3 * g + 2] == p.shift[3 * g] + 2 &&
+                    p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
+        static int use3 = -1;
+        if (use3 < 0) { const char* e = getenv("SISS_NT_CONV3"); use3 = e ? atoi(e) : 0; }   // opt-in: measured a wash
+        const long tiles = (long)cdiv(M, 128) * cdiv(N, BN);
+        if (conv3 && (use3 == 1 || (use3 == 2 && tiles >= 1024))) return siss_launch_gemm_nt_conv3(&p, stream);
+    }
     // big problems: 256-row tiles (one 8-wave block per CU, 3-stage ring); otherwise 128-row tiles
     const long big_tiles = (long)cdiv(M, 256) * cdiv(N, BN) * batch;
     static int force = -1;
@@ -320,6 +236,8 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     static int stages = -1;
     if (stages < 0) { const char* e = getenv("SISS_NT_STAGES"); stages = e ? atoi(e) : 0; }
     if (big) return launch_nt<256, 8, 3>(p, batch, (hipStream_t)stream);
+    if (force == 2564) return launch_nt<256, 4, 1>(p, batch, (hipStream_t)stream);    // 128x64 wave tiles, 2 blocks / CU
+    if (force == 2562) return launch_nt<256, 4, 2>(p, batch, (hipStream_t)stream);
     // Large grids: single-buffered blocks at 4 per CU (latency hidden by the other three) measured 10-15 %
     // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;

@@ -1,0 +1,117 @@
+// Shared pieces of the NT GEMM kernels: parameter block, LDS-DMA helper and the epilogue.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BN = 128, BK = 64;
+constexpr int kCRow = BN * 2 + 16;                       // bf16 epilogue row (256 B) + 16 B pad (bank spread, 16-B aligned)
+constexpr int kMaxPanels = 9;
+
+struct NTParams {
+    const bf16_t* A; const bf16_t* W; bf16_t* C;
+    const float* bias; const float* rowbias; const bf16_t* R;
+    long lda, ldc, ldr, ldrb;
+    long strideA, strideW, strideC;   // per blockIdx.z batch (elements)
+    int M, N, Kp, npanels;
+    int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
+    float alpha, inv_wp;
+    int ablate;
+    int shift[kMaxPanels];
+    int coff[kMaxPanels];
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
+}
+
+
+// Epilogue of a BM x 128 output tile held as acc[i][j] (i = n-tile, j = m-tile of a 64x64 wave sub-tile).
+// MT = 16-row m-tiles per wave (4: 64-row wave tile, 8: 128-row wave tile); waves are laid out 2 (n) wide.
+template <int BM, int kThreads, int MT = 4>
+__device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4][MT], char* smem, int m0, int n0,
+                                            int bz, int tid, int wm, int wn, int frow, int fq) {
+    // ---- epilogue: bf16 tile through LDS (one 34 KiB image), then 16-B coalesced rows ----
+    // Registers: acc[i][j][r] = channel n = wn*64 + i*16 + fq*4 + r of pixel m = wm*64 + j*16 + frow.
+    // alpha, bias and the per-image row bias (time embedding) are applied in f32 BEFORE the one rounding to
+    // bf16; the residual (if any) is added after it, which is exactly the reference's autocast order
+    // (conv output is bf16, then `x + h` rounds again).
+    const int rpi = p.rows_per_image;
+    const int img0 = m0 / rpi;                       // tile rows span at most 3 images (rows_per_image >= 64)
+    const int b1 = (img0 + 1) * rpi - m0, b2 = b1 + rpi;
+    {
+        f32x4_t bias4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + fq * 4;
+            bias4[i] = (p.bias && n + 4 <= p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = wm * (MT * 16) + j * 16 + frow;
+            const float* rb = nullptr;
+            if (p.rowbias) rb = p.rowbias + (long)(img0 + (m >= b1) + (m >= b2)) * p.ldrb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nl = wn * 64 + i * 16 + fq * 4;
+                f32x4_t v = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[i][r];
+                if (rb && n0 + nl + 4 <= p.N) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rb + n0 + nl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += t[r];
+                }
+                *reinterpret_cast<u32x2_t*>(smem + m * kCRow + nl * 2) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            }
+        }
+    }
+    __syncthreads();
+    if (p.ablate & 1) return;
+    bf16_t* C = p.C + (long)bz * p.strideC;
+    const int chunk = tid & 15;           // 8 channels per chunk
+    const int nc = n0 + chunk * 8;
+    if (nc >= p.N) return;
+    constexpr int kRowsPerIt = kThreads / 16;
+#pragma unroll 4
+    for (int it = 0; it < BM / kRowsPerIt; ++it) {
+        const int row = it * kRowsPerIt + (tid >> 4);
+        const int r = m0 + row;
+        if (r >= p.M) break;
+        u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * kCRow + chunk * 16);
+        if (p.Hp > 0) {
+            const int rem = r - (img0 + (row >= b1) + (row >= b2)) * rpi;
+            const int y = (int)(((float)rem + 0.5f) * p.inv_wp), x = rem - y * p.Wp;   // exact: see header note
+            if ((y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1)) o = u32x4_t{0u, 0u, 0u, 0u};
+            else if (p.R && nc + 8 <= p.N) {
+                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
+                                    __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
+            }
+        } else if (p.R && nc + 8 <= p.N) {
+            const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
+                                __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
+        }
+        bf16_t* dst = C + (long)r * p.ldc + nc;
+        if (nc + 8 <= p.N) {
+            *reinterpret_cast<u32x4_t*>(dst) = o;
+        } else {        // ragged N tail (N % 8 != 0 never happens for channel counts; kept for safety)
+            for (int e = 0; e < 8 && nc + e < p.N; ++e) {
+                const uint32_t wv = o[e >> 1];
+                float v = (e & 1) ? __builtin_bit_cast(float, wv & 0xffff0000u) : __builtin_bit_cast(float, wv << 16);
+                if (p.R) v += bf2f(p.R[(long)bz * p.strideC + (long)r * p.ldr + nc + e]);
+                dst[e] = f2bf(v);
+            }
+        }
+    }
+}
+
+}  // namespace

@@ -26,6 +26,7 @@ from .config import UNet2DConfig
 from .layout import Act
 
 ALIGN = 64  # floats; keeps every bf16 shadow slice 128-B aligned
+_BUSY = {}   # id(buffer) -> event recorded on the side stream after the last wgrad that reads the buffer
 
 
 @dataclass
@@ -150,6 +151,10 @@ class UNetEngine:
         self.tape = []
         self.gmap = {}
         self._uid = 0
+        # weight-gradient GEMMs only feed the flat gradient buffer, so they run on a second HIP stream and
+        # overlap the dgrad -> GroupNorm-backward chain (MFMA-bound beside HBM-bound work)
+        import os
+        self.side = torch.cuda.Stream(device=self.device) if os.environ.get("SISS_SIDE_STREAM", "1") == "1" else None
 
     # ------------------------------------------------------------------ parameters
     def _declare_resnet(self, pre, cin, cout, temb):
@@ -310,7 +315,30 @@ class UNetEngine:
 
     def _get(self, n, h, w, c):
         lst = self._pool.setdefault((n, h, w, c), [])
-        return lst.pop() if lst else Act(n, h, w, c, self.device)
+        a = lst.pop() if lst else Act(n, h, w, c, self.device)
+        self._wsync(a)
+        return a
+
+    # -- side-stream bookkeeping: a buffer still being READ by a wgrad on the side stream carries the event
+    #    that marks the end of that read; anyone about to overwrite it waits for the event first.
+    def _wsync(self, a):
+        ev = _BUSY.pop(id(a.buf), None) if a is not None else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _on_side(self, fn, reads):
+        if self.side is None:
+            fn()
+            return
+        ready = torch.cuda.Event()
+        ready.record()                                   # everything the wgrad reads is complete at this point
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            fn()
+            done = torch.cuda.Event()
+            done.record(self.side)
+        for a in reads:
+            _BUSY[id(a.buf)] = done
 
     def _put(self, a):
         if a is not None:
@@ -326,6 +354,7 @@ class UNetEngine:
         if cur is None:
             self.gmap[id(act)] = g
         else:
+            self._wsync(cur)
             lib.call("siss_add_inplace", cur.data, g.data, cur.n, cur.h, cur.w, cur.c)
             self._put(g)
 
@@ -357,6 +386,8 @@ class UNetEngine:
         def bwd(dy, colsum=None, accum: Act = None, colsum_ld=0):
             """dy: Act (padded) or compact tensor, nb samples.  Returns dx Act (nb samples)."""
             nb = self.nb
+            if accum is not None:
+                self._wsync(accum)                      # written in place
             dx = accum if accum is not None else self._get(nb, x.h, x.w, x.c)
             dyp = dy.data if isinstance(dy, Act) else dy
             lib.call("siss_groupnorm_bwd", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
@@ -384,6 +415,8 @@ class UNetEngine:
                         dbias2=bias_grad2)
             if not need_dx:
                 return None
+            if accum is not None:
+                self._wsync(accum)
             dx = accum if accum is not None else self._get(dy.n, x.h, x.w, x.c)
             ops.conv_dgrad(dy, self.wT[pre + ".weight"], dx, residual=accum, ksize=ksize)
             return dx
@@ -406,9 +439,11 @@ class UNetEngine:
         rb, re = dy.wp + 1, rows_per_set - (dy.wp + 1)
         tiles = (-(-co // 128)) * (-(-ci // 128))
         ns = ops._nsplits(tiles, t, self.nsets, re - rb, ops.is_conv3_panels(shifts, coffs))
-        lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or x.c, dW_view, ps.total, co, ci, t,
-                 lib.int_array(shifts), lib.int_array(coffs), self.nsets, rows_per_set, x_set_rows, rb, re, ns,
-                 ops.zero_page(self.device), dbias, dbias2)
+        sh, cf, zp = lib.int_array(shifts), lib.int_array(coffs), ops.zero_page(self.device)
+        nsets = self.nsets
+        self._on_side(lambda: lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or x.c, dW_view, ps.total, co, ci, t,
+                                       sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2),
+                      reads=[dy])
 
     # ------------------------------------------------------------------ time embedding
     def time_embed(self, t):
@@ -606,6 +641,7 @@ class UNetEngine:
                 seen.add(plane)
             self._put(dy)
             acc = self.gmap.get(id(x))
+            self._wsync(acc)
             dx = acc if acc is not None else self._get(nb, x.h, x.w, C)
             lib.call("siss_depth_to_space", dz.data, dx.data, int(acc is not None), nb, x.h, x.w, C)
             self.gmap[id(x)] = dx
@@ -640,6 +676,7 @@ class UNetEngine:
             dcat = self._take(out)
             da = self._get(nb, a.h, a.w, a.c)
             accb = self.gmap.get(id(b))
+            self._wsync(accb)
             db = accb if accb is not None else self._get(nb, b.h, b.w, b.c)
             lib.call("siss_concat_bwd", dcat.data, da.data, db.data, int(accb is not None), nb, a.h, a.w, a.c, b.c)
             self.gmap[id(b)] = db
@@ -736,4 +773,7 @@ class UNetEngine:
         self.dtp_all.zero_()
         for fn in reversed(self.tape):
             fn()
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)     # join: every wgrad has landed in ps.grads
+            _BUSY.clear()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"

@@ -130,3 +130,109 @@ def test_siss_step_matches_oracle(setup):
         d_got = (new[n] - sd[n]).flatten()
         num += float((d_ref * d_got).sum()); den += float(d_ref.norm() ** 2)
     assert num / den > 0.9, num / den
+
+
+def _fresh(setup):
+    import copy
+    eng, net0, sd = setup
+    eng.load_state_dict(sd)
+    net = copy.deepcopy(net0)
+    net.load_state_dict(sd)
+    return eng, net, sd
+
+
+def _batch(g, B=4):
+    x0 = torch.rand(B, 3, 16, 16, generator=g) * 2 - 1
+    a0 = (torch.rand(1, 3, 16, 16, generator=g) * 2 - 1).repeat(B, 1, 1, 1)
+    noise = torch.randn(B, 3, 16, 16, generator=g)
+    return dict(x0=x0, a0=a0, noise=noise, t=torch.full((B,), 999, dtype=torch.long), u=torch.rand(B, generator=g))
+
+
+def _check_scalars(ref, got, tol=5e-2):
+    for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm"):
+        r, v = getattr(ref, k), got[k]
+        assert abs(v - r) <= tol * abs(r), (k, v, r)
+
+
+def test_no_is_fast_path_matches_oracle(setup):
+    """SISS-No-IS (double_forward_with_neg_del, ddpm_deletion_loss.py:60-67): ONE batch-2B forward + dual backward."""
+    from siss_amd.step import SISSStepper, NO_IS
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    eng, net, sd = _fresh(setup)
+    ac = S.alphas_cumprod()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6)
+    st = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0,
+                     train_batch_size=4, loss_fn=NO_IS, mixed_precision=None)
+    mb = _batch(torch.Generator().manual_seed(21))
+    ref, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), NO_IS, ac, [mb],
+                              train_batch_size=4, scaling_norm=5.0)
+    st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+    _check_scalars(ref, st.stats())
+
+
+def test_gradient_accumulation_two_micro_batches(setup):
+    """GA = 2: gradients of both micro-batches accumulate in the flat [g_x ; g_a] buffer (delete_celeb.py:705-711)."""
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    eng, net, sd = _fresh(setup)
+    ac = S.alphas_cumprod()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6)
+    st = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
+                     train_batch_size=4, grad_accum=2, mixed_precision=None)
+    g = torch.Generator().manual_seed(33)
+    mbs = [_batch(g), _batch(g)]
+    ref, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), "importance_sampling_with_mixture", ac,
+                              mbs, train_batch_size=4, scaling_norm=5.0, loss_params={"lambd": 0.5})
+    for mb in mbs:
+        st.micro_step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+    _check_scalars(ref, st.stats())
+
+
+def test_bf16_io_mode_and_graph_replay(setup):
+    """mixed_precision=bf16 (images/noise cast to bf16 first, delete_celeb.py:561-581) against the oracle fed the
+    same bf16-rounded inputs; then the captured hipGraph replays to the same scalars as the eager step."""
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    eng, net, sd = _fresh(setup)
+    ac = S.alphas_cumprod()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6)
+    mb = _batch(torch.Generator().manual_seed(5))
+    rb = {k: (v.to(torch.bfloat16).float() if v.dtype == torch.float32 and k != "u" else v) for k, v in mb.items()}
+    ref, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), "importance_sampling_with_mixture", ac,
+                              [rb], train_batch_size=4, scaling_norm=5.0, loss_params={"lambd": 0.5})
+    st = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
+                     train_batch_size=4, mixed_precision="bf16")
+    dev = eng.device
+    x0, a0, noise = (mb[k].to(dev).to(torch.bfloat16) for k in ("x0", "a0", "noise"))
+    t, u = mb["t"].to(dev), mb["u"].to(dev)
+    st.step(x0, a0, noise, t, u)
+    eager = st.stats()
+    _check_scalars(ref, eager, tol=8e-2)     # + bf16 noising / bf16 targets on top of bf16 compute
+    # graph: same inputs, parameters restored -> identical schedule replayed from a hipGraph
+    eng.load_state_dict(sd)
+    st2 = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
+                      train_batch_size=4, mixed_precision="bf16")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        st2.step(x0, a0, noise, t, u)                 # warm-up on the capture stream (allocations)
+        eng.load_state_dict(sd)
+        st2.opt.m.zero_(); st2.opt.v.zero_(); st2.opt.scalars.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            st2.step(x0, a0, noise, t, u)
+    torch.cuda.current_stream().wait_stream(side)
+    eng.load_state_dict(sd)
+    st2.opt.m.zero_(); st2.opt.v.zero_(); st2.opt.scalars.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    rep = st2.stats()
+    for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm"):
+        assert abs(rep[k] - eager[k]) <= 2e-2 * abs(eager[k]), (k, rep[k], eager[k])
+    assert rep["step"] == 1

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="nt,tn,gn")
+    ap.add_argument("--zeros", action="store_true", help="zero operands (clock / power probe; never quote)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib.load()
@@ -33,9 +34,10 @@ def main():
     B = 16
     shapes = [(256, 128, 128), (256, 256, 128), (128, 128, 128), (64, 256, 256), (32, 256, 256), (16, 512, 512), (8, 512, 512)]
     for (hw, ci, co) in shapes:
-        x = Act(B, hw, hw, ci, dev); x.interior().normal_()
-        dy = Act(2 * B, hw, hw, co, dev); dy.interior().normal_()
-        w = (torch.randn(9, co, ci, device=dev) / (3 * ci ** 0.5))
+        x = Act(B, hw, hw, ci, dev); dy = Act(2 * B, hw, hw, co, dev)
+        if not a.zeros:
+            x.interior().normal_(); dy.interior().normal_()
+        w = (torch.randn(9, co, ci, device=dev) / (3 * ci ** 0.5)) * (0.0 if a.zeros else 1.0)
         wb = w.to(torch.bfloat16)
         wT = ops.dgrad_weight(w)
         y = Act(B, hw, hw, co, dev)
