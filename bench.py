@@ -87,6 +87,23 @@ def cpu_baseline(cfg_kw, seed):
     return dt, cores
 
 
+def hbm_traffic(launcher):
+    """Average HBM bytes per launch of `launcher`'s kernels from the last committed PMC run
+    (profiles/latest_hbm_traffic.json, written by tools/pmc_traffic.sh: 2 x FETCH_SIZE + WRITE_SIZE in separate
+    --pmc passes).  PMC counters cannot be read from inside this process, so this is a recorded value of the
+    same command, or None when no profile is committed."""
+    fn = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
+    if not os.path.exists(fn):
+        return None
+    stem = launcher.replace("siss_", "") + "_kernel"
+    tot = n = 0.0
+    for k, v in json.load(open(fn)).items():
+        if k.startswith(stem):
+            tot += v["hbm_bytes_per_launch"] * v["launches"]
+            n += v["launches"]
+    return {"bytes_per_launch": round(tot / n), "source": "profiles/latest_hbm_traffic.json (rocprofv3 --pmc)"} if n else None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,7 +200,7 @@ def main():
         n, tms, work = kern[dom]
         ach = work / (tms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(dom),
                 "launches_per_step": n // ksteps, "avg_launch_us": round(tms / n * 1e3, 2),
                 "share_of_step_kernel_time": round(tms / tot_ms, 3)}
         other = "siss_gemm_tn" if dom == "siss_gemm_nt" else "siss_gemm_nt"
