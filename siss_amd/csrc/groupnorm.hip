@@ -59,32 +59,58 @@ struct PixelWalk {
     }
 };
 
+// Block-level reduction over the pixel slots WITHOUT atomics (deterministic): every active thread parks its
+// 8 per-channel partial sums in LDS as red[slot][C], then thread c < C adds the slots of channel c.
+// red must hold 2048 floats (ppi * C <= 256 * 8).  out[c] is valid for all threads after the call.
+__device__ __forceinline__ void reduce_slots(const float (&v)[8], bool active, int slot, int cc, const GNShape& s,
+                                             float* red, float* out) {
+    if (active) {
+        float* dst = red + slot * s.C + cc * 8;
+        *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4_t*>(dst + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < s.C; c += kThreads) {
+        float a = 0.f;
+        for (int sl = 0; sl < s.ppi; ++sl) a += red[sl * s.C + c];
+        out[c] = a;
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------- forward: partial statistics
 __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const bf16_t* __restrict__ x, GNShape s,
                                                             float* __restrict__ partial) {
-    __shared__ float sh[2 * kMaxG];
+    __shared__ __attribute__((aligned(16))) float red[2048];
+    __shared__ float ch_a[kMaxC], ch_b[kMaxC];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    if (tid < 2 * kMaxG) sh[tid] = 0.f;
-    __syncthreads();
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
+    const bool active = slot < s.ppi;
     float a[8] = {}, b[8] = {};
-    if (slot < s.ppi) {
+    if (active) {
         const bf16_t* base = x + (long)n * (s.H + 2) * (s.W + 2) * s.C + cc * 8;
-        for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
-            float v[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(base + w.row() * s.C), v);
+        PixelWalk w(s, chunk, slot);
+        while (w.ok()) {                       // two pixels per trip: both loads are in flight together
+            const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.C);
+            w.next();
+            const bool two = w.ok();
+            u32x4_t r1 = u32x4_t{0u, 0u, 0u, 0u};
+            if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.C); w.next(); }
+            float v[8], u[8];
+            unpack8(r0, v); unpack8(r1, u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { a[e] += v[e]; b[e] += v[e] * v[e]; }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = (cc * 8 + e) / s.cpg;
-            atomicAdd(&sh[2 * g], a[e]);
-            atomicAdd(&sh[2 * g + 1], b[e]);
+            for (int e = 0; e < 8; ++e) { a[e] += v[e] + u[e]; b[e] += v[e] * v[e] + u[e] * u[e]; }
         }
     }
-    __syncthreads();
-    if (tid < 2 * s.G) partial[((long)n * s.nchunks + chunk) * 2 * s.G + tid] = sh[tid];
+    reduce_slots(a, active, slot, cc, s, red, ch_a);
+    reduce_slots(b, active, slot, cc, s, red, ch_b);
+    if (tid < 2 * s.G) {
+        const int g = tid >> 1;
+        const float* src = (tid & 1) ? ch_b : ch_a;
+        float t = 0.f;
+        for (int c = g * s.cpg; c < (g + 1) * s.cpg; ++c) t += src[c];
+        partial[((long)n * s.nchunks + chunk) * 2 * s.G + tid] = t;
+    }
 }
 
 // Sum the [nchunks][2G] partial slab of one sample with ALL 256 threads: thread (j = tid>>6, e = tid&63)
@@ -142,16 +168,26 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
     }
     const long img = (long)n * (s.H + 2) * (s.W + 2);
     const bf16_t* base = x + img * s.C + cc * 8;
-    for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
-        float v[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(base + w.row() * s.C), v);
+    auto out_row = [&](const PixelWalk& w) { return out_compact ? compact_row(n, w.pi, s.H, s.W) : img + w.row(); };
+    PixelWalk w(s, chunk, slot);
+    while (w.ok()) {
+        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.C);
+        const long o0 = out_row(w);
+        w.next();
+        const bool two = w.ok();
+        u32x4_t r1 = u32x4_t{0u, 0u, 0u, 0u};
+        long o1 = 0;
+        if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.C); o1 = out_row(w); w.next(); }
+        float v[8], u[8];
+        unpack8(r0, v); unpack8(r1, u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float z = v[e] * sc[e] + sf[e];
-            v[e] = SILU ? silu_f(z) : z;
+            const float z0 = v[e] * sc[e] + sf[e], z1 = u[e] * sc[e] + sf[e];
+            v[e] = SILU ? silu_f(z0) : z0;
+            u[e] = SILU ? silu_f(z1) : z1;
         }
-        const long orow = out_compact ? compact_row(n, w.pi, s.H, s.W) : img + w.row();
-        *reinterpret_cast<u32x4_t*>(y + orow * s.C + cc * 8) = pack8(v);
+        *reinterpret_cast<u32x4_t*>(y + o0 * s.C + cc * 8) = pack8(v);
+        if (two) *reinterpret_cast<u32x4_t*>(y + o1 * s.C + cc * 8) = pack8(u);
     }
 }
 
@@ -164,29 +200,38 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
     GNShape s, int nx, int dy_compact, int set_images, long set_stride, float* __restrict__ partial,
     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float sh[SETS][2 * kMaxG];
-    __shared__ float shg[SETS][kMaxC], shb[SETS][kMaxC];
+    __shared__ __attribute__((aligned(16))) float red[2048];
+    __shared__ float ch1[kMaxC], ch2[kMaxC];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < SETS * 2 * kMaxG; i += kThreads) (&sh[0][0])[i] = 0.f;
-    for (int k = 0; k < SETS; ++k)
-        for (int i = tid; i < s.C; i += kThreads) { shg[k][i] = 0.f; shb[k][i] = 0.f; }
-    __syncthreads();
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
-    if (slot < s.ppi) {
-        float mr[8], rs[8], ga[8], be[8], a1[SETS][8], a2[SETS][8];
+    const bool active = slot < s.ppi;
+    float a1[SETS][8], a2[SETS][8];
+#pragma unroll
+    for (int k = 0; k < SETS; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a1[k][e] = 0.f; a2[k][e] = 0.f; }
+    if (active) {
+        float mr[8], rs[8], ga[8], be[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cc * 8 + e, g = c / s.cpg;
             rs[e] = rstd[(long)n * s.G + g]; mr[e] = mean[(long)n * s.G + g] * rs[e];
             ga[e] = gamma[c]; be[e] = beta[c];
-#pragma unroll
-            for (int k = 0; k < SETS; ++k) { a1[k][e] = 0.f; a2[k][e] = 0.f; }
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
         const bf16_t* xb = x + (long)n * rpi * s.C + cc * 8;
         for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
+            // all loads of this pixel (x + one dy per set) are issued before the first use
+            const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C);
+            u32x4_t rd[SETS];
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) {
+                const int n2 = k * nx + n;
+                const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : (long)n2 * rpi + w.row();
+                rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8);
+            }
             float v[8], xh[8], dsl[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C), v);
+            unpack8(rx, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 xh[e] = v[e] * rs[e] - mr[e];
@@ -194,10 +239,8 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
             }
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
-                const int n2 = k * nx + n;
-                const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : (long)n2 * rpi + w.row();
                 float d[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8), d);
+                unpack8(rd[k], d);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float dz = d[e] * dsl[e];
@@ -205,26 +248,24 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < SETS; ++k)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = cc * 8 + e, g = c / s.cpg;
-                atomicAdd(&sh[k][2 * g], a1[k][e] * ga[e]);
-                atomicAdd(&sh[k][2 * g + 1], a2[k][e] * ga[e]);
-                atomicAdd(&shb[k][c], a1[k][e]);
-                atomicAdd(&shg[k][c], a2[k][e]);
-            }
     }
-    __syncthreads();
     for (int k = 0; k < SETS; ++k) {
+        reduce_slots(a1[k], active, slot, cc, s, red, ch1);     // per channel: sum dz        (= dbeta partial)
+        reduce_slots(a2[k], active, slot, cc, s, red, ch2);     // per channel: sum dz * xhat (= dgamma partial)
         const int n2 = k * nx + n;
-        if (tid < 2 * s.G) partial[((long)n2 * s.nchunks + chunk) * 2 * s.G + tid] = sh[k][tid];
+        if (tid < 2 * s.G) {
+            const int g = tid >> 1;
+            const float* src = (tid & 1) ? ch2 : ch1;
+            float t = 0.f;
+            for (int c = g * s.cpg; c < (g + 1) * s.cpg; ++c) t += src[c] * gamma[c];
+            partial[((long)n2 * s.nchunks + chunk) * 2 * s.G + tid] = t;
+        }
         const long so = (long)(n2 / set_images) * set_stride;
         for (int i = tid; i < s.C; i += kThreads) {
-            atomicAdd(dgamma + so + i, shg[k][i]);
-            atomicAdd(dbeta + so + i, shb[k][i]);
+            atomicAdd(dgamma + so + i, ch2[i]);
+            atomicAdd(dbeta + so + i, ch1[i]);
         }
+        __syncthreads();
     }
 }
 
@@ -235,41 +276,54 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
     const float* __restrict__ partial, GNShape s, int nx, int dy_compact, const bf16_t* __restrict__ accum,
     bf16_t* __restrict__ dx, float* __restrict__ colsum, long colsum_ld) {
     __shared__ float sh_s1[SETS][kMaxG], sh_s2[SETS][kMaxG];
-    __shared__ float shc[SETS][kMaxC];
+    __shared__ __attribute__((aligned(16))) float red[2048];
+    __shared__ float chs[kMaxC];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     {
-        __shared__ float red[4][64];
+        __shared__ float fr[4][64];
         const double cnt = (double)s.H * s.W * s.cpg;
         for (int k = 0; k < SETS; ++k) {
             const int n2 = k * nx + n;
-            fold_slab(partial + (long)n2 * s.nchunks * 2 * s.G, s.nchunks, s.G, red);
+            fold_slab(partial + (long)n2 * s.nchunks * 2 * s.G, s.nchunks, s.G, fr);
             if (tid < s.G) {
-                sh_s1[k][tid] = (float)(((double)red[0][2 * tid] + red[1][2 * tid] + red[2][2 * tid] + red[3][2 * tid]) / cnt);
-                sh_s2[k][tid] = (float)(((double)red[0][2 * tid + 1] + red[1][2 * tid + 1] + red[2][2 * tid + 1] + red[3][2 * tid + 1]) / cnt);
+                sh_s1[k][tid] = (float)(((double)fr[0][2 * tid] + fr[1][2 * tid] + fr[2][2 * tid] + fr[3][2 * tid]) / cnt);
+                sh_s2[k][tid] = (float)(((double)fr[0][2 * tid + 1] + fr[1][2 * tid + 1] + fr[2][2 * tid + 1] + fr[3][2 * tid + 1]) / cnt);
             }
             __syncthreads();
         }
     }
-    if (colsum)
-        for (int k = 0; k < SETS; ++k)
-            for (int i = tid; i < s.C; i += kThreads) shc[k][i] = 0.f;
-    __syncthreads();
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
-    if (slot < s.ppi) {
-        float mr[8], rs[8], ga[8], be[8], m1[SETS][8], m2[SETS][8], cs[SETS][8];
+    const bool active = slot < s.ppi;
+    float cs[SETS][8];
+#pragma unroll
+    for (int k = 0; k < SETS; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[k][e] = 0.f;
+    if (active) {
+        float mr[8], rs[8], ga[8], be[8], m1[SETS][8], m2[SETS][8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cc * 8 + e, g = c / s.cpg;
             rs[e] = rstd[(long)n * s.G + g]; mr[e] = mean[(long)n * s.G + g] * rs[e];
             ga[e] = gamma[c]; be[e] = beta[c];
 #pragma unroll
-            for (int k = 0; k < SETS; ++k) { m1[k][e] = sh_s1[k][g]; m2[k][e] = sh_s2[k][g]; cs[k][e] = 0.f; }
+            for (int k = 0; k < SETS; ++k) { m1[k][e] = sh_s1[k][g]; m2[k][e] = sh_s2[k][g]; }
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
         const bf16_t* xb = x + (long)n * rpi * s.C + cc * 8;
         for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
+            const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C);
+            u32x4_t rd[SETS], ra[SETS];
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) {
+                const int n2 = k * nx + n;
+                const long orow = (long)n2 * rpi + w.row();
+                const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : orow;
+                rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8);
+                ra[k] = accum ? *reinterpret_cast<const u32x4_t*>(accum + orow * s.C + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+            }
             float v[8], xh[8], dsl[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C), v);
+            unpack8(rx, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 xh[e] = v[e] * rs[e] - mr[e];
@@ -277,36 +331,25 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
             }
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
-                const int n2 = k * nx + n;
-                const long orow = (long)n2 * rpi + w.row();
-                const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : orow;
-                float d[8], o[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8), d);
+                const long orow = (long)(k * nx + n) * rpi + w.row();
+                float d[8], r[8], o[8];
+                unpack8(rd[k], d); unpack8(ra[k], r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    o[e] = rs[e] * (d[e] * dsl[e] - m1[k][e] - xh[e] * m2[k][e]);
-                    cs[k][e] += o[e];
-                }
-                if (accum) {
-                    float r[8];
-                    unpack8(*reinterpret_cast<const u32x4_t*>(accum + orow * s.C + cc * 8), r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                    const float t = rs[e] * (d[e] * dsl[e] - m1[k][e] - xh[e] * m2[k][e]);
+                    cs[k][e] += t;
+                    o[e] = t + r[e];
                 }
                 *reinterpret_cast<u32x4_t*>(dx + orow * s.C + cc * 8) = pack8(o);
             }
         }
-        if (colsum) {
-#pragma unroll
-            for (int k = 0; k < SETS; ++k)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) atomicAdd(&shc[k][cc * 8 + e], cs[k][e]);
-        }
     }
     if (colsum) {
-        __syncthreads();
-        for (int k = 0; k < SETS; ++k)
-            for (int i = tid; i < s.C; i += kThreads) atomicAdd(colsum + (long)(k * nx + n) * colsum_ld + i, shc[k][i]);
+        for (int k = 0; k < SETS; ++k) {
+            reduce_slots(cs[k], active, slot, cc, s, red, chs);
+            for (int i = tid; i < s.C; i += kThreads) atomicAdd(colsum + (long)(k * nx + n) * colsum_ld + i, chs[i]);
+            __syncthreads();
+        }
     }
 }
 
