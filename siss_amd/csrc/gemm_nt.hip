@@ -62,6 +62,12 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int bz = blockIdx.z;
+    if (p.ablate & 8) {
+        // stagger probe: co-resident blocks run the same program with identical phase lengths; offset the
+        // blocks of dispatch round k (blockIdx / 256 ~ residency slot) by k * 512 cycles
+        const int slot = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     const bf16_t* A = p.A + (long)bz * p.strideA;
     const bf16_t* W = p.W + (long)bz * p.strideW;
 

@@ -1,0 +1,68 @@
+"""Worker for tests/test_hip_dp.py: 2 ranks (gloo, both on cuda:0 -- RCCL refuses two ranks on one device)
+run one SISS step each on its own shard through SISSStepper(process_group=WORLD); rank 0 also runs the
+single-process step on the concatenated global batch and compares the updated parameters."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, sys.argv[1])
+from siss_amd.config import UNet2DConfig      # noqa: E402
+from siss_amd.step import SISSStepper          # noqa: E402
+from siss_amd.unet import UNetEngine           # noqa: E402
+
+KW = dict(sample_size=16, in_channels=3, out_channels=3, block_out_channels=(64, 128),
+          down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"),
+          layers_per_block=1, attention_head_dim=None, norm_num_groups=32, norm_eps=1e-6,
+          downsample_padding=0, flip_sin_to_cos=False, freq_shift=1)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    dev = torch.device("cuda:0")
+    ac = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, 1000), 0)
+    g = torch.Generator().manual_seed(99)
+    Bg = 4
+    x0 = torch.rand(Bg, 3, 16, 16, generator=g) * 2 - 1
+    a0 = (torch.rand(1, 3, 16, 16, generator=g) * 2 - 1).repeat(Bg, 1, 1, 1)
+    noise = torch.randn(Bg, 3, 16, 16, generator=g)
+    t = torch.full((Bg,), 999, dtype=torch.long)
+    u = torch.rand(Bg, generator=g)
+    kw = dict(lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5, mixed_precision=None)
+
+    eng = UNetEngine(UNet2DConfig(**KW), dev)
+    sd = eng.init_random(seed=7)
+    per = Bg // world
+    sl = slice(rank * per, (rank + 1) * per)
+    st = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, **kw)
+    st.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
+    dp_stats = st.stats()
+    dp_params = eng.ps.flat.clone()
+
+    # replicas must hold identical parameters after the step
+    other = [torch.zeros_like(dp_params) for _ in range(world)]
+    dist.all_gather(other, dp_params)
+    assert all(torch.equal(other[0], o) for o in other), "replicas diverged"
+
+    if rank == 0:
+        eng.load_state_dict(sd)
+        ref = SISSStepper(eng, ac, train_batch_size=Bg, process_group=None, **kw)
+        ref.step(x0, a0, noise, t.to(dev), u)
+        rs = ref.stats()
+        for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm"):
+            assert abs(dp_stats[k] - rs[k]) <= 2e-2 * abs(rs[k]), (k, dp_stats[k], rs[k])
+        upd_ref = eng.ps.flat.clone()
+        eng.load_state_dict(sd)
+        base = eng.ps.flat.clone()
+        du_ref, du_dp = upd_ref - base, dp_params - base
+        cos = float((du_ref * du_dp).sum() / (du_ref.norm() * du_dp.norm()))
+        assert cos > 0.98, cos
+    dist.barrier()
+    dist.destroy_process_group()
+    print("dp gpu ok", rank)
+
+
+if __name__ == "__main__":
+    main()

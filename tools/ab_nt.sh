@@ -1,1 +1,1 @@
-for cfg in "SISS_NT_CONV3=0" "SISS_NT_CONV3=0 SISS_NT_TILE=2564" "SISS_NT_CONV3=0 SISS_NT_TILE=2562"; do echo "== $cfg"; env $cfg python tools/bench_kernels.py --iters 10 --only nt 2>&1 | grep -E "fprop|dgrad" | head -8; done
+for a in 0 8; do echo "== ABLATE $a"; SISS_NT_ABLATE=$a python tools/bench_kernels.py --iters 10 --only nt 2>&1 | grep -E "fprop|dgrad" | head -8; done
