@@ -274,7 +274,8 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ partial, GNShape s, int nx, int dy_compact, const bf16_t* __restrict__ accum,
-    bf16_t* __restrict__ dx, float* __restrict__ colsum, long colsum_ld) {
+    const bf16_t* __restrict__ accum2, bf16_t* __restrict__ dx, bf16_t* __restrict__ dx2, int split_c,
+    int accumulate2, float* __restrict__ colsum, long colsum_ld) {
     __shared__ float sh_s1[SETS][kMaxG], sh_s2[SETS][kMaxG];
     __shared__ __attribute__((aligned(16))) float red[2048];
     __shared__ float chs[kMaxC];
@@ -313,7 +314,14 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
         const bf16_t* xb = x + (long)n * rpi * s.C + cc * 8;
         for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
             const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C);
-            u32x4_t rd[SETS], ra[SETS];
+            // Output routing: one tensor of C channels, or (dx2 != null: the input was a channel concat)
+            // channels [0, split_c) -> dx (row stride split_c) and [split_c, C) -> dx2 (row stride C - split_c,
+            // optionally accumulated): the concat backward costs no extra pass.
+            const bool second = dx2 != nullptr && cc * 8 >= split_c;
+            bf16_t* const obase = second ? dx2 + (cc * 8 - split_c) : dx + cc * 8;
+            const int ostride = dx2 ? (second ? s.C - split_c : split_c) : s.C;
+            const bool oacc = second && accumulate2;
+            u32x4_t rd[SETS], ra[SETS], rb[SETS], rc[SETS];
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
                 const int n2 = k * nx + n;
@@ -321,6 +329,8 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
                 const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : orow;
                 rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8);
                 ra[k] = accum ? *reinterpret_cast<const u32x4_t*>(accum + orow * s.C + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                rb[k] = accum2 ? *reinterpret_cast<const u32x4_t*>(accum2 + orow * s.C + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                rc[k] = oacc ? *reinterpret_cast<const u32x4_t*>(obase + orow * ostride) : u32x4_t{0u, 0u, 0u, 0u};
             }
             float v[8], xh[8], dsl[8];
             unpack8(rx, v);
@@ -332,15 +342,15 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
                 const long orow = (long)(k * nx + n) * rpi + w.row();
-                float d[8], r[8], o[8];
-                unpack8(rd[k], d); unpack8(ra[k], r);
+                float d[8], r[8], r2[8], r3[8], o[8];
+                unpack8(rd[k], d); unpack8(ra[k], r); unpack8(rb[k], r2); unpack8(rc[k], r3);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float t = rs[e] * (d[e] * dsl[e] - m1[k][e] - xh[e] * m2[k][e]);
                     cs[k][e] += t;
-                    o[e] = t + r[e];
+                    o[e] = t + r[e] + r2[e] + r3[e];
                 }
-                *reinterpret_cast<u32x4_t*>(dx + orow * s.C + cc * 8) = pack8(o);
+                *reinterpret_cast<u32x4_t*>(obase + orow * ostride) = pack8(o);
             }
         }
     }
@@ -403,10 +413,13 @@ int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, voi
 
 // dx (padded, n2 samples) from dy (n2 samples, padded or compact) and the saved x (nx samples,
 // x index = n2 % nx).  dgamma/dbeta: [sets][...] accumulated atomically at set = n2 / set_images
-// with `set_stride` floats between sets.  accum (optional, padded like dx) is added to dx;
+// with `set_stride` floats between sets.  accum / accum2 (optional, padded [.., C] like a C-channel dx) are added;
+// dx2 (optional): the normalised input was a channel concat -- channels [0, split_c) of the result go to dx
+// (row stride split_c), channels [split_c, C) to dx2 (row stride C - split_c; += when accumulate2);
 // colsum (optional, f32 rows of colsum_ld floats, pre-zeroed) receives the per-sample channel sums of dx.
 int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
-                       const float* mean, const float* rstd, void* dx, const void* accum, float* dgamma,
+                       const float* mean, const float* rstd, void* dx, const void* accum, const void* accum2,
+                       void* dx2, int split_c, int accumulate2, float* dgamma,
                        float* dbeta, float* colsum, long colsum_ld, float* partial, int n2, int nx, int set_images,
                        long set_stride, int H, int W, int C, int G, int silu, int dy_compact, void* stream) {
     GNShape s;
@@ -414,7 +427,8 @@ int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const 
     SISS_CHECK_ARG(n2 > 0 && nx > 0 && set_images > 0 && n2 % set_images == 0);
     SISS_CHECK_ARG(n2 == nx || n2 == 2 * nx);     // cotangent sets per saved sample: 1 or 2
     SISS_CHECK_ARG(make_shape(H, W, C, G, s, nx));
-    SISS_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)accum) % 16 == 0);
+    SISS_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)accum | (uintptr_t)accum2 | (uintptr_t)dx2) % 16 == 0);
+    SISS_CHECK_ARG(!dx2 || (split_c > 0 && split_c < C && split_c % 8 == 0));
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, nx);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;
@@ -422,7 +436,8 @@ int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const 
     gn_bwd_stats_kernel<SILU, SETS><<<grid, kThreads, 0, st>>>(dyp, xp, gamma, beta, mean, rstd, s, nx, dy_compact, \
                                                                set_images, set_stride, partial, dgamma, dbeta);    \
     gn_bwd_apply_kernel<SILU, SETS><<<grid, kThreads, 0, st>>>(dyp, xp, gamma, beta, mean, rstd, partial, s, nx,    \
-                                                               dy_compact, (const bf16_t*)accum, (bf16_t*)dx, colsum, colsum_ld)
+                                                               dy_compact, (const bf16_t*)accum, (const bf16_t*)accum2, (bf16_t*)dx, (bf16_t*)dx2, split_c,  \
+                                                               accumulate2, colsum, colsum_ld)
     if (n2 == nx) { if (silu) { GN_BWD(true, 1); } else { GN_BWD(false, 1); } }
     else          { if (silu) { GN_BWD(true, 2); } else { GN_BWD(false, 2); } }
 #undef GN_BWD

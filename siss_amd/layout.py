@@ -14,10 +14,11 @@ import torch
 class Act:
     """A padded NHWC bf16 activation living in one flat torch buffer."""
 
-    __slots__ = ("buf", "n", "h", "w", "c", "guard")
+    __slots__ = ("buf", "n", "h", "w", "c", "guard", "cat_parts", "cat_done")
 
     def __init__(self, n, h, w, c, device="cuda", buf=None):
         self.n, self.h, self.w, self.c = n, h, w, c
+        self.cat_parts, self.cat_done = None, False
         self.guard = (w + 2) + 2                      # rows of zero guard on each side
         rows = self.rows + 2 * self.guard
         if buf is None:

@@ -32,7 +32,7 @@ SIGNATURES = {
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
-    "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],
+    "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],
     "siss_upsample2x": [P, P, I, I, I, I, P],
     "siss_upsample2x_bwd": [P, P, I, I, I, I, P],
     "siss_concat": [P, P, P, I, I, I, I, I, P],

@@ -384,15 +384,24 @@ class UNetEngine:
         lib.call("siss_groupnorm_fwd", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
                  self._gn_partial(x.n, x.h, x.w, x.c), x.n, x.h, x.w, x.c, G, float(eps), int(silu), int(compact_out))
 
-        def bwd(dy, colsum=None, accum: Act = None, colsum_ld=0):
-            """dy: Act (padded) or compact tensor, nb samples.  Returns dx Act (nb samples)."""
+        def bwd(dy, colsum=None, accum: Act = None, colsum_ld=0, accum2: Act = None, split=None):
+            """dy: Act (padded) or compact tensor, nb samples.  Returns dx Act (nb samples).
+            accum / accum2: cotangents already known for x (added; accum is overwritten in place).
+            split = (da, db, accumulate_b): x was concat(a, b) -- write the two halves straight into da / db."""
             nb = self.nb
             if accum is not None:
                 self._wsync(accum)                      # written in place
-            dx = accum if accum is not None else self._get(nb, x.h, x.w, x.c)
+            if split is not None:
+                da, db, accb = split
+                dx, dx2p, split_c = da, db.data, da.c
+                self._wsync(db)
+            else:
+                dx = accum if accum is not None else self._get(nb, x.h, x.w, x.c)
+                dx2p, split_c, accb = None, 0, False
             dyp = dy.data if isinstance(dy, Act) else dy
             lib.call("siss_groupnorm_bwd", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
                      dx.data, accum.data if accum is not None else None,
+                     accum2.data if accum2 is not None else None, dx2p, split_c, int(accb),
                      ps.g(pre + ".weight", self.gbase), ps.g(pre + ".bias", self.gbase), colsum, colsum_ld,
                      self._gn_partial(nb, x.h, x.w, x.c), nb, x.n, self.set_images, ps.total,
                      x.h, x.w, x.c, G, int(silu), int(not isinstance(dy, Act)))
@@ -511,14 +520,29 @@ class UNetEngine:
             self._put(da2)
             da1 = c1_b(dh, bias_grad=False)
             self._put(dh)
+            prior = self.gmap.pop(id(x), None)          # cotangent x already received from another consumer
             if has_sc:
-                dxs = sc_b(dout, bias_grad=False)
+                acc = sc_b(dout, bias_grad=False)
                 self._put(dout)
-                dx = gn1_b(da1, accum=dxs)
             else:
-                dx = gn1_b(da1, accum=dout)
+                acc = dout
+            parts = getattr(x, "cat_parts", None)
+            if parts is not None:
+                # x = concat(a, b): norm1's backward writes d_a and d_b (+= the skip's running cotangent) directly
+                a, b = parts
+                da = self._get(nb, a.h, a.w, a.c)
+                accb = self.gmap.get(id(b))
+                db = accb if accb is not None else self._get(nb, b.h, b.w, b.c)
+                gn1_b(da1, accum=acc, accum2=prior, split=(da, db, accb is not None))
+                self.gmap[id(b)] = db
+                self._put(acc)
+                self._give(a, da)
+                x.cat_done = True
+            else:
+                dx = gn1_b(da1, accum=acc, accum2=prior)
+                self.gmap[id(x)] = dx
+            self._put(prior)
             self._put(da1)
-            self._give(x, dx)
         self.tape.append(bwd)
         return out
 
@@ -671,9 +695,13 @@ class UNetEngine:
     def concat(self, a: Act, b: Act):
         out = self._act(self._name("cat"), a.n, a.h, a.w, a.c + b.c)
         lib.call("siss_concat", a.data, b.data, out.data, a.n, a.h, a.w, a.c, b.c)
+        out.cat_parts, out.cat_done = (a, b), False
 
         def bwd():
             nb = self.nb
+            if out.cat_done:                    # the consuming resnet's norm1 backward already split the cotangent
+                out.cat_done = False
+                return
             dcat = self._take(out)
             da = self._get(nb, a.h, a.w, a.c)
             accb = self.gmap.get(id(b))

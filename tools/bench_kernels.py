@@ -65,7 +65,7 @@ def main():
             xb = x.rows * ci * 2 / 1e9
             t = timeit(lambda: lib.call("siss_groupnorm_fwd", x.data, gamma, beta, yy.data, mean, rstd, part, B, hw, hw, ci, G, 1e-6, 1, 0), a.iters)
             print(f"gn fwd {hw:4d}^2 C={ci:4d}     {t*1e3:8.1f} us  {3*xb/t*1e3:8.1f} GB/s (3X)")
-            t = timeit(lambda: lib.call("siss_groupnorm_bwd", dyy.data, x.data, gamma, beta, mean, rstd, dxx.data, None, dg, db, None, 0, part,
+            t = timeit(lambda: lib.call("siss_groupnorm_bwd", dyy.data, x.data, gamma, beta, mean, rstd, dxx.data, None, None, None, 0, 0, dg, db, None, 0, part,
                                         2 * B, B, B, ci, hw, hw, ci, G, 1, 0), a.iters)
             print(f"gn bwd {hw:4d}^2 C={ci:4d}     {t*1e3:8.1f} us  {8*xb/t*1e3:8.1f} GB/s (8X)")
 
