@@ -219,9 +219,11 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(const bf16_t* __restri
 
 // conv_in front end: NCHW image (f32 or bf16) -> im2col rows [N][H+2][W+2][K] bf16, K >= 9*Cin,
 // k = tap*Cin + ci (zero beyond); halo rows are written as zeros.
+// flip = 1 mirrors the tap offsets (k = tap*Cin + ci reads img[y - (ky-1), x - (kx-1)]): the im2col of a
+// COTANGENT image, which turns conv_out's dgrad / wgrad into plain one-panel GEMMs.
 template <bool BF16>
 __global__ void im2col3x3_kernel(const void* __restrict__ img, bf16_t* __restrict__ out, int N, int Cin, int H,
-                                 int W, int K) {
+                                 int W, int K, int flip) {
     const long total = (long)N * (H + 2) * (W + 2);
     for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (long)gridDim.x * blockDim.x) {
         const int xp = r % (W + 2); long t = r / (W + 2);
@@ -235,7 +237,8 @@ __global__ void im2col3x3_kernel(const void* __restrict__ img, bf16_t* __restric
                 const int k = k0 + e, tap = k / Cin, ci = k - tap * Cin;
                 float val = 0.f;
                 if (!halo && tap < 9) {
-                    const int y = yp - 1 + tap / 3 - 1, x = xp - 1 + tap % 3 - 1;
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    const int y = yp - 1 + (flip ? -dy : dy), x = xp - 1 + (flip ? -dx : dx);
                     if (y >= 0 && y < H && x >= 0 && x < W) {
                         const long o = (((long)n * Cin + ci) * H + y) * W + x;
                         val = BF16 ? bf2f(reinterpret_cast<const bf16_t*>(img)[o]) : reinterpret_cast<const float*>(img)[o];
@@ -245,6 +248,27 @@ __global__ void im2col3x3_kernel(const void* __restrict__ img, bf16_t* __restric
             }
             *reinterpret_cast<u32x4_t*>(dst + k0) = pack8(v);
         }
+    }
+}
+
+// out[set][c] += sum over the set's images and pixels of img[n][c][:, :]   (f32 NCHW; conv_out bias gradient)
+__global__ __launch_bounds__(kThreads) void nchw_channel_sums_kernel(const float* __restrict__ img, int set_images,
+                                                                    int C, long hw, long out_set_stride,
+                                                                    float* __restrict__ out) {
+    __shared__ float sh[kThreads / 64];
+    const int c = blockIdx.y, set = blockIdx.z;
+    float a = 0.f;
+    for (int n = 0; n < set_images; ++n) {
+        const float* src = img + ((long)(set * set_images + n) * C + c) * hw;
+        for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < hw; i += (long)gridDim.x * kThreads) a += src[i];
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) t += sh[i];
+        atomicAdd(out + (long)set * out_set_stride + c, t);
     }
 }
 
@@ -327,13 +351,25 @@ int siss_colsum(const void* y, long rows_per_set, int C, int nsets, long out_set
     colsum_kernel<<<grid, kThreads, C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)y, rows_per_set, C, out_set_stride, out, out2);
     SISS_LAUNCH_RET();
 }
-int siss_im2col3x3(const void* img, int img_bf16, void* out, int N, int Cin, int H, int W, int K, void* stream) {
+int siss_im2col3x3(const void* img, int img_bf16, void* out, int N, int Cin, int H, int W, int K, int flip,
+                   void* stream) {
     SISS_CHECK_ARG(img && out && N > 0 && Cin > 0 && H > 0 && W > 0 && K >= 9 * Cin && K % 8 == 0);
     const long total = (long)N * (H + 2) * (W + 2);
     if (img_bf16)
-        im2col3x3_kernel<true><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(img, (bf16_t*)out, N, Cin, H, W, K);
+        im2col3x3_kernel<true><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(img, (bf16_t*)out, N, Cin, H, W, K, flip);
     else
-        im2col3x3_kernel<false><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(img, (bf16_t*)out, N, Cin, H, W, K);
+        im2col3x3_kernel<false><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(img, (bf16_t*)out, N, Cin, H, W, K, flip);
+    SISS_LAUNCH_RET();
+}
+
+// out[set*out_set_stride + c] += sum_{n in set, y, x} img[n][c][y][x]
+int siss_nchw_channel_sums(const float* img, int nsets, int set_images, int C, long hw, long out_set_stride, float* out,
+                           void* stream) {
+    SISS_CHECK_ARG(img && out && nsets > 0 && set_images > 0 && C > 0 && hw > 0);
+    long nb = (hw + kThreads * 16 - 1) / (kThreads * 16);
+    if (nb > 64) nb = 64;
+    dim3 grid((int)nb, C, nsets);
+    nchw_channel_sums_kernel<<<grid, kThreads, 0, (hipStream_t)stream>>>(img, set_images, C, hw, out_set_stride, out);
     SISS_LAUNCH_RET();
 }
 

@@ -267,7 +267,7 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
                  float* dbias, float* dbias2, void* stream) {
     SISS_CHECK_ARG(Y && X && dW && shifts && coffs && zero_page);
     SISS_CHECK_ARG(N > 0 && C > 0 && npanels >= 1 && npanels <= kMaxPanels && nsets >= 1 && nsplits >= 1);
-    SISS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && N % 8 == 0 && C % 8 == 0);
+    SISS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && C % 8 == 0);   // N may be ragged (masked at the store)
     SISS_CHECK_ARG(((uintptr_t)Y | (uintptr_t)X | (uintptr_t)zero_page) % 16 == 0 && (uintptr_t)dW % 4 == 0);
     SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set);
     TNParams p;

@@ -44,7 +44,8 @@ SIGNATURES = {
     "siss_compact_add_to_pad": [P, P, P, I, I, I, I, P],
     "siss_transpose_bf16": [P, P, I, I, I, P],
     "siss_colsum": [P, L, I, I, L, P, P, P],
-    "siss_im2col3x3": [P, I, P, I, I, I, I, I, P],
+    "siss_im2col3x3": [P, I, P, I, I, I, I, I, I, P],
+    "siss_nchw_channel_sums": [P, I, I, I, L, L, P, P],
     "siss_conv_out_fprop": [P, P, P, P, I, I, I, I, I, P],
     "siss_conv_out_dgrad": [P, P, P, I, I, I, I, I, P],
     "siss_conv_out_wgrad": [P, P, P, P, I, I, I, L, L, I, I, I, I, P],

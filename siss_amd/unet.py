@@ -273,6 +273,12 @@ class UNetEngine:
             self._build_wt_jobs()
         lib.call("siss_conv_weight_dgrad_multi", ps.flat, self._wt_all, self._wt_jobs, self._wt_njobs,
                  self._wt_tiles)
+        # conv_out dgrad operand: Wn^T, [Cin][K = 9*Cout padded to 64] bf16 (k = tap*Cout + co)
+        w = ps.p("conv_out.weight")
+        k = w.shape[0] * w.shape[1]
+        if getattr(self, "_wd_out", None) is None:
+            self._wd_out = torch.zeros(w.shape[2], -(-k // 64) * 64, dtype=torch.bfloat16, device=self.device)
+        self._wd_out[:, :k] = w.reshape(k, w.shape[2]).t()
 
     def _build_wt_jobs(self):
         """One bf16 buffer holding every dgrad weight copy ([taps][Cin][Cout], tap order reversed) and the
@@ -728,7 +734,7 @@ class UNetEngine:
         # conv_in: im2col rows (K = 9*Cin padded to 64) then a one-panel GEMM
         kp = ps.specs["conv_in.weight"].native_shape[1]
         col = self._act("conv_in.col", N, H, W, kp)
-        lib.call("siss_im2col3x3", x, int(x.dtype == torch.bfloat16), col.data, N, cin, H, W, kp)
+        lib.call("siss_im2col3x3", x, int(x.dtype == torch.bfloat16), col.data, N, cin, H, W, kp, 0)
         c0 = cfg.block_out_channels[0]
         h = self._act("conv_in.out", N, H, W, c0)
         ops.gemm_nt(lib.ptr(col.data), kp, ps.sh("conv_in.weight"), lib.ptr(h.data), c0, col.rows, c0, kp, [0], [0],
@@ -771,14 +777,26 @@ class UNetEngine:
         hl = h
 
         def head_bwd():
+            """conv_out backward as GEMMs: the flipped im2col of the (3-channel) cotangent image is a [rows][64]
+            matrix `col`; dgrad = col . Wn (one-panel NT GEMM, K = 64), wgrad = col^T . a (one-panel TN GEMM)."""
             c = self.cot
             nb = self.nb
             gb = self.gbase
-            off = ps.specs["conv_out.weight"].off
-            lib.call("siss_conv_out_wgrad", c, a.data, ps.grads[gb:, off:], ps.g("conv_out.bias", gb), self.nsets,
-                     self.set_images, a.n, ps.total, ps.total, H, W, c0, co)
+            kc = self._wd_out.shape[1]
+            col = self._get(nb, H, W, kc)
+            lib.call("siss_im2col3x3", c, 0, col.data, nb, co, H, W, kc, 1)
+            lib.call("siss_nchw_channel_sums", c, self.nsets, self.set_images, co, H * W, ps.total,
+                     ps.g("conv_out.bias", gb))
+            rows_per_set = self.set_images * col.rows_per_image
+            rb, re = col.wp + 1, rows_per_set - (col.wp + 1)
+            ns = ops._nsplits(1, 1, self.nsets, re - rb, False)
+            lib.call("siss_gemm_tn", col.data, kc, a.data, c0, ps.grads[gb:, ps.specs["conv_out.weight"].off:], ps.total,
+                     9 * co, c0, 1, lib.int_array([0]), lib.int_array([0]), self.nsets, rows_per_set,
+                     rows_per_set if a.n == nb else 0, rb, re, ns, ops.zero_page(self.device), None, None)
             da = self._get(nb, H, W, c0)
-            lib.call("siss_conv_out_dgrad", c, ps.p("conv_out.weight"), da.data, nb, H, W, c0, co)
+            ops.gemm_nt(lib.ptr(col.data), kc, self._wd_out, lib.ptr(da.data), c0, col.rows, c0, kc, [0], [0],
+                        rows_per_image=col.rows_per_image, hp=col.hp, wp=col.wp)
+            self._put(col)
             dh = gn_b(da)
             self._put(da)
             self._give(hl, dh)
