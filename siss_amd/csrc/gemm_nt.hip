@@ -248,6 +248,10 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;
     if (stages == 1 || (stages == 0 && tiles128 >= 2048)) return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
+    // tiny grids (8x8 / 16x16 layers, attention): 64-row tiles double the block count
+    static int small = -1;
+    if (small < 0) { const char* e = getenv("SISS_NT_SMALL"); small = e ? atoi(e) : 0; }   // opt-in: measured +-5 % (these layers are K-latency-bound, not block-count-bound)
+    if (small && tiles128 < 256) return launch_nt<64, 2, 2>(p, batch, (hipStream_t)stream);
     return launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
 }
 

@@ -1,1 +1,1 @@
-for a in 0 8; do echo "== ABLATE $a"; SISS_NT_ABLATE=$a python tools/bench_kernels.py --iters 10 --only nt 2>&1 | grep -E "fprop|dgrad" | head -8; done
+for a in 0 1; do echo "== SMALL $a"; SISS_NT_SMALL=$a python tools/bench_kernels.py --iters 20 --only nt 2>&1 | grep -E "fprop|dgrad" | tail -6; done
