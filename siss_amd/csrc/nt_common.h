@@ -42,6 +42,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
     const int rpi = p.rows_per_image;
     const int img0 = m0 / rpi;                       // tile rows span at most 3 images (rows_per_image >= 64)
     const int b1 = (img0 + 1) * rpi - m0, b2 = b1 + rpi;
+    const int last_img = (p.M - 1) / rpi;
     {
         f32x4_t bias4[4];
 #pragma unroll
@@ -53,7 +54,11 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
         for (int j = 0; j < MT; ++j) {
             const int m = wm * (MT * 16) + j * 16 + frow;
             const float* rb = nullptr;
-            if (p.rowbias) rb = p.rowbias + (long)(img0 + (m >= b1) + (m >= b2)) * p.ldrb;
+            if (p.rowbias) {                 // rows past M (tile overhang) must not index past the last image's row
+                int img = img0 + (m >= b1) + (m >= b2);
+                img = img < last_img ? img : last_img;
+                rb = p.rowbias + (long)img * p.ldrb;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int nl = wn * 64 + i * 16 + fq * 4;

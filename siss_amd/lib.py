@@ -49,6 +49,8 @@ SIGNATURES = {
     "siss_conv_out_fprop": [P, P, P, P, I, I, I, I, I, P],
     "siss_conv_out_dgrad": [P, P, P, I, I, I, I, I, P],
     "siss_conv_out_wgrad": [P, P, P, P, I, I, I, L, L, I, I, I, I, P],
+    "siss_mha_small_fwd": [P, P, P, P, P, I, I, I, I, F, P],
+    "siss_mha_small_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P],
     "siss_softmax_fwd": [P, P, L, I, P],
     "siss_softmax_bwd": [P, P, P, L, L, I, F, P],
     "siss_timestep_sincos": [P, P, I, I, I, F, P],

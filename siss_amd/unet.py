@@ -553,11 +553,15 @@ class UNetEngine:
         return out
 
     def attention(self, x: Act, pre):
-        """Single-head spatial self-attention block (attention_head_dim = C)."""
+        """Spatial self-attention block.  attention_head_dim = C (CelebA-HQ: one 512-wide head) runs QK^T / PV
+        on the MFMA GEMMs; small head dims (diffusers default 8: the MNIST UNet) use the per-(sample, head)
+        online-softmax kernels."""
         ps = self.ps
         C, B, S = x.c, x.n, x.h * x.w
-        assert self.cfg.head_dim(C) == C, "multi-head attention is not on the HIP path yet"
-        scale = C ** -0.5
+        D = self.cfg.head_dim(C)
+        small = D != C
+        assert not small or D in (8, 16, 32), f"attention_head_dim {D} is not covered by the HIP kernels"
+        scale = D ** -0.5
         rows = B * S
         nm = self._name(pre)
         hn, gn_b = self.gn(x, pre + ".group_norm", False, compact_out=True)
@@ -570,12 +574,16 @@ class UNetEngine:
             ops.gemm_nt(lib.ptr(a), C, ps.sh(wname + ".weight"), lib.ptr(out), C, n_rows, C, C, [0], [0],
                         bias=ps.p(wname + ".bias") if bias else None)
         lin(hn, pre + ".to_q", q, rows); lin(hn, pre + ".to_k", k, rows); lin(hn, pre + ".to_v", v, rows)
-        lib.call("siss_transpose_bf16", v, vT, B, S, C)
-        ops.gemm_nt(lib.ptr(q), C, k, lib.ptr(sc), S, S, S, C, [0], [0], alpha=scale, batch=B,
-                    stride_a=S * C, stride_w=S * C, stride_c=S * S)
-        lib.call("siss_softmax_fwd", sc, p, B * S, S)
-        ops.gemm_nt(lib.ptr(p), S, vT, lib.ptr(o), C, S, C, S, [0], [0], batch=B,
-                    stride_a=S * S, stride_w=C * S, stride_c=S * C)
+        if small:
+            lse = self._buf(nm + ".lse", (B, C // D, S))
+            lib.call("siss_mha_small_fwd", q, k, v, o, lse, B, S, C, D, float(scale))
+        else:
+            lib.call("siss_transpose_bf16", v, vT, B, S, C)
+            ops.gemm_nt(lib.ptr(q), C, k, lib.ptr(sc), S, S, S, C, [0], [0], alpha=scale, batch=B,
+                        stride_a=S * C, stride_w=S * C, stride_c=S * S)
+            lib.call("siss_softmax_fwd", sc, p, B * S, S)
+            ops.gemm_nt(lib.ptr(p), S, vT, lib.ptr(o), C, S, C, S, [0], [0], batch=B,
+                        stride_a=S * S, stride_w=C * S, stride_c=S * C)
         lin(o, pre + ".to_out.0", y, rows)
         out = self._act(nm + ".out", B, x.h, x.w, C)
         lib.call("siss_compact_add_to_pad", y, x.data, out.data, B, x.h, x.w, C)
@@ -600,31 +608,34 @@ class UNetEngine:
                                 [0], [0], res_ptr=lib.ptr(dx_out) if accumulate else None, ldr=C)
             do = tb(".do", (rows2, C))
             lin_bwd(dy, o, pre + ".to_out.0", do, False)
-            dp, ds = tb(".dp", (nb, S, S)), tb(".ds", (nb, S, S))
             dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (rows2, C)), tb(".dv", (rows2, C))
-            dkf, dvf = tb(".dkf", (nb, S, C), torch.float32), tb(".dvf", (nb, S, C), torch.float32)
-            kT = tb(".kT", (B, C, S))
-            lib.call("siss_transpose_bf16", k, kT, B, S, C)
-            dkf.zero_(); dvf.zero_()
-            for g in range(nb // B):      # cotangent groups that share the B forward samples
-                sl = slice(g * B, (g + 1) * B)
-                # dP = dO V^T
-                ops.gemm_nt(lib.ptr(do[g * B * S:]), C, v, lib.ptr(dp[sl]), S, S, S, C, [0], [0], batch=B,
-                            stride_a=S * C, stride_w=S * C, stride_c=S * S)
-                # dV[key][c] = sum_q P[q][key] dO[q][c]
-                lib.call("siss_gemm_tn", p, S, do[g * B * S:], C, dvf[sl], S * C, S, C, 1, lib.int_array([0]),
-                         lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
-            lib.call("siss_softmax_bwd", p, dp, ds, nb * S, B * S, S, float(scale))
-            for g in range(nb // B):
-                sl = slice(g * B, (g + 1) * B)
-                # dQ = dS K
-                ops.gemm_nt(lib.ptr(ds[sl]), S, kT, lib.ptr(dq[g * B * S:]), C, S, C, S, [0], [0], batch=B,
-                            stride_a=S * S, stride_w=C * S, stride_c=S * C)
-                # dK[key][c] = sum_q dS[q][key] Q[q][c]
-                lib.call("siss_gemm_tn", ds[sl], S, q, C, dkf[sl], S * C, S, C, 1, lib.int_array([0]),
-                         lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
-            lib.call("siss_cast_f32_bf16", dkf, dk, dkf.numel())
-            lib.call("siss_cast_f32_bf16", dvf, dv, dvf.numel())
+            if small:
+                lib.call("siss_mha_small_bwd", q, k, v, o, lse, do, dq, dk, dv, nb, B, S, C, D, float(scale))
+            else:
+                dp, ds = tb(".dp", (nb, S, S)), tb(".ds", (nb, S, S))
+                dkf, dvf = tb(".dkf", (nb, S, C), torch.float32), tb(".dvf", (nb, S, C), torch.float32)
+                kT = tb(".kT", (B, C, S))
+                lib.call("siss_transpose_bf16", k, kT, B, S, C)
+                dkf.zero_(); dvf.zero_()
+                for g in range(nb // B):      # cotangent groups that share the B forward samples
+                    sl = slice(g * B, (g + 1) * B)
+                    # dP = dO V^T
+                    ops.gemm_nt(lib.ptr(do[g * B * S:]), C, v, lib.ptr(dp[sl]), S, S, S, C, [0], [0], batch=B,
+                                stride_a=S * C, stride_w=S * C, stride_c=S * S)
+                    # dV[key][c] = sum_q P[q][key] dO[q][c]
+                    lib.call("siss_gemm_tn", p, S, do[g * B * S:], C, dvf[sl], S * C, S, C, 1, lib.int_array([0]),
+                             lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
+                lib.call("siss_softmax_bwd", p, dp, ds, nb * S, B * S, S, float(scale))
+                for g in range(nb // B):
+                    sl = slice(g * B, (g + 1) * B)
+                    # dQ = dS K
+                    ops.gemm_nt(lib.ptr(ds[sl]), S, kT, lib.ptr(dq[g * B * S:]), C, S, C, S, [0], [0], batch=B,
+                                stride_a=S * S, stride_w=C * S, stride_c=S * C)
+                    # dK[key][c] = sum_q dS[q][key] Q[q][c]
+                    lib.call("siss_gemm_tn", ds[sl], S, q, C, dkf[sl], S * C, S, C, 1, lib.int_array([0]),
+                             lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
+                lib.call("siss_cast_f32_bf16", dkf, dk, dkf.numel())
+                lib.call("siss_cast_f32_bf16", dvf, dv, dvf.numel())
             dhn = tb(".dhn", (rows2, C))
             lin_bwd(dq, hn, pre + ".to_q", dhn, False)
             lin_bwd(dk, hn, pre + ".to_k", dhn, True)

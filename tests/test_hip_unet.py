@@ -236,3 +236,38 @@ def test_bf16_io_mode_and_graph_replay(setup):
     for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm"):
         assert abs(rep[k] - eager[k]) <= 2e-2 * abs(eager[k]), (k, rep[k], eager[k])
     assert rep["step"] == 1
+
+
+def test_mnist_tshirt_config_step_matches_oracle():
+    """BASELINE config 1 on the HIP path: MNIST 28x28 UNet (64/128/256 channels, 16/32-head attention with
+    head_dim 8, downsample_padding=1, flip_sin_to_cos), t ~ U{0..999}, inf guard (delete_tshirt.py)."""
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.step import SISSStepper
+    from siss_amd.unet import UNetEngine
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    from oracle.unet import OracleUNet2D, UNetConfig
+    eng = UNetEngine(UNet2DConfig.mnist_tshirt(), "cuda:0")
+    sd = eng.init_random(seed=11)
+    net = OracleUNet2D(UNetConfig.mnist_tshirt())
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(46)
+    B = 4
+    x = torch.randn(B, 1, 28, 28, generator=g)
+    t = torch.tensor([999, 500, 20, 731])
+    with torch.no_grad():
+        ref = net(x, t)[0]
+    got = eng.forward(x.cuda(), t.cuda()).cpu()
+    assert (got - ref).abs().max() <= 3e-2 * ref.abs().max()
+    ac = S.alphas_cumprod()
+    opt = torch.optim.AdamW(net.parameters(), lr=5e-5, betas=(0.95, 0.999), weight_decay=1e-6)
+    st = SISSStepper(eng, ac, lr=5e-5, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
+                     train_batch_size=B, inf_guard=True, mixed_precision=None)
+    mb = dict(x0=torch.rand(B, 1, 28, 28, generator=g) * 2 - 1, a0=torch.rand(B, 1, 28, 28, generator=g) * 2 - 1,
+              noise=torch.randn(B, 1, 28, 28, generator=g), t=torch.tensor([999, 800, 950, 600]),
+              u=torch.tensor([0.9, 0.1, 0.6, 0.3]))
+    r, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), "importance_sampling_with_mixture", ac,
+                            [mb], train_batch_size=B, scaling_norm=5.0, loss_params={"lambd": 0.5}, inf_guard=True)
+    st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+    _check_scalars(r, st.stats())

@@ -40,3 +40,27 @@ def test_tiny_forward_backward():
     y = m(x, torch.tensor([3, 999]))[0]
     y.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_mnist_config_one_siss_step_on_cpu():
+    """BASELINE config 1 (delete_tshirt.yaml: MNIST 28x28 DDPM, SISS, CPU reference path): one optimizer step of
+    the oracle at a reduced batch -- plumbing check of the CPU path at the real architecture."""
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    torch.manual_seed(0)
+    net = OracleUNet2D(UNetConfig.mnist_tshirt())
+    ac = S.alphas_cumprod()
+    opt = torch.optim.AdamW(net.parameters(), lr=5e-5, betas=(0.95, 0.999), weight_decay=1e-6)
+    g = torch.Generator().manual_seed(46)
+    B = 2
+    mb = dict(x0=torch.rand(B, 1, 28, 28, generator=g) * 2 - 1, a0=torch.rand(B, 1, 28, 28, generator=g) * 2 - 1,
+              noise=torch.randn(B, 1, 28, 28, generator=g), t=torch.randint(0, 1000, (B,), generator=g),
+              u=torch.rand(B, generator=g))
+    before = [p.detach().clone() for p in net.parameters()]
+    st, gx, ga, gfin = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)),
+                                       "importance_sampling_with_mixture", ac, [mb], train_batch_size=B,
+                                       scaling_norm=5.0, loss_params={"lambd": 0.5}, inf_guard=True)
+    assert all(map(lambda v: v == v and v != float("inf"), (st.norm_loss_x, st.norm_loss_a, st.pre_clip_norm)))
+    assert abs(st.scaling_factor * st.norm_loss_a - 5.0) < 1e-4          # norm fixing: ||s * g_a|| = scaling_norm
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
