@@ -71,6 +71,8 @@ class _DeleteBase(Task):
     def datasets(self, shape):
         cfg = self.cfg
         try:
+            if cfg.get("dataset_all") is None or cfg.get("dataset_deletion") is None:
+                raise FileNotFoundError("no dataset configured")
             transform = hydra_lite.instantiate(cfg.transform)
             ds_all = hydra_lite.instantiate(cfg.dataset_all, transform=transform)
             ds_del = hydra_lite.instantiate(cfg.dataset_deletion, transform=transform)
@@ -125,7 +127,7 @@ class _DeleteBase(Task):
             if rank == 0:
                 print(f"step {step + 1}/{n_steps}  |g_x| {st['norm_loss_x']:.4g}  |g_a| {st['norm_loss_a']:.4g}  "
                       f"s {st['scaling_factor']:.4g}")
-        if rank == 0:
+        if rank == 0 and cfg.get("save_final", True):
             unet.save_pretrained(os.path.join(cfg.output_dir, "unet"))
         return stepper
 
