@@ -50,6 +50,13 @@ class SISSStepper:
                              max_grad_norm=max_grad_norm, shadow=engine.ps.shadow)
         self._micro = 0
         self.last = None
+        self._pending = []
+        # Data-parallel overlap: the tail [split, P) of the flat gradient buffer (up / mid / deep down blocks,
+        # ~85 % of the bytes) is final long before the high-resolution down blocks finish their backward;
+        # its all-reduce is started from a hook inside the backward pass and runs beside the rest of it.
+        self.overlap = self.pg is not None and self.world > 1 and engine.ps.split < engine.ps.total
+        if self.overlap:
+            engine.on_early_grads_final = self._early_allreduce
 
     # ------------------------------------------------------------------ one micro-batch
     def micro_step(self, x0, a0, noise, t, u):
@@ -92,11 +99,27 @@ class SISSStepper:
     def _partials(self, B, chw):
         return self.e._buf("loss_partials", (lib.query("siss_loss_partials_words", B, chw),), torch.float64)
 
+    def _early_allreduce(self):
+        if self._micro + 1 != self.ga:          # only the sync micro-step communicates
+            return
+        ps = self.e.ps
+        for s in range(ps.grads.shape[0]):
+            self._pending.append(torch.distributed.all_reduce(ps.grads[s, ps.split:], group=self.pg, async_op=True))
+
     def _sync_and_update(self):
         g = self.e.ps.grads
         if self.pg is not None and self.world > 1:
-            # the ONE collective of the step: sum of [g_x ; g_a] over ranks (RCCL over xGMI)
-            allreduce_flat_grads(g, self.pg)
+            # the exchange of the step: sum of [g_x ; g_a] over ranks (RCCL over xGMI) -- one flat buffer; with
+            # the overlap hook the early-final tail is already in flight and only the head remains
+            if self.overlap and self._pending:
+                split = self.e.ps.split
+                for s in range(g.shape[0]):
+                    self._pending.append(torch.distributed.all_reduce(g[s, :split], group=self.pg, async_op=True))
+                for w in self._pending:
+                    w.wait()
+                self._pending = []
+            else:
+                allreduce_flat_grads(g, self.pg)
         self.opt.launch(g, scaling_norm=self.scaling_norm, eta=self.eta, inf_guard=self.inf_guard)
         self.e.refresh_weights()
 

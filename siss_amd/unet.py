@@ -64,6 +64,24 @@ class ParamStore:
         self.total += -(-numel // ALIGN) * ALIGN
         return sp
 
+    def relayout(self, early_final):
+        """Re-assign offsets so that the parameters whose gradients are final EARLY in the backward pass
+        (early_final(name) is True) form one contiguous tail [split, total): data-parallel runs all-reduce that
+        tail while the rest of the backward is still running.  Call before allocate()."""
+        order = [sp for sp in self.specs.values() if not early_final(sp.name)]
+        split_at = len(order)
+        order += [sp for sp in self.specs.values() if early_final(sp.name)]
+        off = 0
+        self.split = 0
+        for i, sp in enumerate(order):
+            if i == split_at:
+                self.split = off
+            sp.off = off
+            off += -(-sp.numel // ALIGN) * ALIGN
+        if split_at == len(order):
+            self.split = off
+        self.total = off
+
     def allocate(self, device, nsets=2):
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.grads = torch.zeros(nsets, self.total, dtype=torch.float32, device=device)
@@ -142,6 +160,7 @@ class UNetEngine:
         self.device = torch.device(device)
         self.ps = ParamStore()
         self._declare_params()
+        self.ps.relayout(self._grads_final_early)
         self.ps.allocate(self.device)
         self._build_temb_tables()
         self.wT = {}
@@ -151,6 +170,7 @@ class UNetEngine:
         self.tape = []
         self.gmap = {}
         self._uid = 0
+        self.on_early_grads_final = None
         # weight-gradient GEMMs only feed the flat gradient buffer, so they CAN run on a second HIP stream beside
         # the dgrad -> GroupNorm-backward chain.  Measured on MI355X: +1.5 % step rate only (the 8-wave wgrad
         # blocks leave too few VGPRs for co-resident blocks) while per-kernel times inflate, so it is opt-in.
@@ -158,6 +178,21 @@ class UNetEngine:
         self.side = torch.cuda.Stream(device=self.device) if os.environ.get("SISS_SIDE_STREAM", "0") == "1" else None
 
     # ------------------------------------------------------------------ parameters
+    def _early_blocks(self):
+        """Down blocks whose backward runs before the (long) high-resolution tail: the lower half of the ladder."""
+        n = len(self.cfg.block_out_channels)
+        return {f"down_blocks.{i}." for i in range(n // 2 + 1, n)} if n >= 4 else set()
+
+    def _grads_final_early(self, name):
+        """True for parameters whose gradient is complete once the backward pass has left the deepest down blocks
+        (up blocks, mid block, output head, deep down blocks) -- except the time-embedding-fed ones, whose
+        gradients come from ONE batched kernel at the very end of the backward."""
+        if ".time_emb_proj." in name or name.endswith(".conv1.bias") or name.startswith(("time_embedding.", "conv_in.")):
+            return False
+        if name.startswith(("up_blocks.", "mid_block.", "conv_norm_out.", "conv_out.")):
+            return True
+        return any(name.startswith(p) for p in self._early_blocks())
+
     def _declare_resnet(self, pre, cin, cout, temb):
         a = self.ps.add
         if not hasattr(self, "temb_cols"):
@@ -760,7 +795,11 @@ class UNetEngine:
         self.tape.append(conv_in_bwd)
 
         skips = [h]
+        early = self._early_blocks()
+        self._early_mark = None
         for (i, cin_b, cout_b, attn, down) in self.plan_down:
+            if self._early_mark is None and f"down_blocks.{i}." in early:
+                self._early_mark = len(self.tape)      # closures from here on belong to the early-final group
             for j in range(cfg.layers_per_block):
                 h = self.resnet(h, f"down_blocks.{i}.resnets.{j}")
                 if attn:
@@ -829,8 +868,11 @@ class UNetEngine:
         d_s.zero_()
         self.dtp_all = self._buf("temb.dtp_all", (nb, self.temb_ntot))
         self.dtp_all.zero_()
-        for fn in reversed(self.tape):
-            fn()
+        mark = getattr(self, "_early_mark", None)
+        for idx in range(len(self.tape) - 1, -1, -1):
+            self.tape[idx]()
+            if idx == mark and self.on_early_grads_final is not None:
+                self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)     # join: every wgrad has landed in ps.grads
             _BUSY.clear()
