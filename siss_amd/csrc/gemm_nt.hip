@@ -92,18 +92,27 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     const int steps = p.npanels * kchunks;
     const long wpanel = (long)p.N * p.Kp;
 
-    int st_pn = 0, st_kc = 0;                  // (panel, k-chunk) of the NEXT stage() call: steps are staged in order
+    // (panel, k-chunk) of the NEXT stage() call; steps are staged in order.  The panel's row shift / channel
+    // offset live in the kernel arguments: they are fetched right AFTER a stage's DMA has been issued, so the
+    // scalar-load latency hides behind the compute phase instead of sitting between the barrier and the DMA.
+    int st_pn = 0, st_kc = 0;
+    long a_base = (long)p.shift[0] * p.lda + p.coff[0], w_base = 0;
     auto stage = [&](int buf, int step) {
         (void)step;
-        const int pn = st_pn, kc = st_kc;
-        if (++st_kc == kchunks) { st_kc = 0; ++st_pn; }
-        const long aoff = (long)p.shift[pn] * p.lda + p.coff[pn] + kc * BK;
-        const long woff = pn * wpanel + kc * BK;
+        const long aoff = a_base + st_kc * BK;
+        const long woff = w_base + st_kc * BK;
         char* base = smem + buf * C_::kStageBytes;
 #pragma unroll
         for (int j = 0; j < C_::kAPieces; ++j) glds16(asrc[j] + aoff, base + (w * C_::kAPieces + j) * 1024);
 #pragma unroll
         for (int j = 0; j < C_::kWPieces; ++j) glds16(wsrc[j] + woff, base + BM * 128 + (w * C_::kWPieces + j) * 1024);
+        if (++st_kc == kchunks) {
+            st_kc = 0;
+            if (++st_pn < p.npanels) {
+                a_base = (long)p.shift[st_pn] * p.lda + p.coff[st_pn];
+                w_base += wpanel;
+            }
+        }
     };
 
     f32x4_t acc[4][MT];   // [n-tile][m-tile]
