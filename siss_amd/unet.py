@@ -635,9 +635,10 @@ class UNetEngine:
             def lin_bwd(dyt, xin, wname, dx_out, accumulate):
                 """dyt [rows2,C] cotangent of y = xin W^T + b (xin has B*S rows shared by the sets)."""
                 dW = ps.grads[gb:, ps.specs[wname + ".weight"].off:]
+                tiles = (-(-C // 128)) ** 2
                 lib.call("siss_gemm_tn", dyt, C, xin, C, dW, ps.total, C, C, 1, lib.int_array([0]),
                          lib.int_array([0]), ns, si * S, si * S if B == nb else 0,
-                         0, si * S, 1, zp, ps.g(wname + ".bias", gb), None)
+                         0, si * S, ops._nsplits(tiles, 1, ns, si * S, False), zp, ps.g(wname + ".bias", gb), None)
                 if dx_out is not None:
                     ops.gemm_nt(lib.ptr(dyt), C, self.wT[wname + ".weight"], lib.ptr(dx_out), C, rows2, C, C,
                                 [0], [0], res_ptr=lib.ptr(dx_out) if accumulate else None, ldr=C)
