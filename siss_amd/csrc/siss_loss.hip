@@ -268,6 +268,23 @@ __global__ void fold_partials_kernel(const double* __restrict__ partials, int nb
     if (sum_a) sum_a[n] = (float)sa;
 }
 
+
+// One DDPM reverse step x_t -> x_{t-1} (epsilon prediction, clip_sample, fixed_small variance), fused:
+//   x0 = clamp((x - sqrt_b * eps) / sqrt_a, -1, 1);  x_prev = c_x0 * x0 + c_xt * x + sigma * noise
+// (diffusers DDPMScheduler.step as used by evaluate.py:37-79).  f32 NCHW in / out, HBM-bound.
+__global__ __launch_bounds__(kThreads) void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                             const float* __restrict__ noise, float* __restrict__ out,
+                                                             long n, float sqrt_a, float sqrt_b, float c_x0, float c_xt,
+                                                             float sigma, int clip) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        float x0 = (x[i] - sqrt_b * eps[i]) / sqrt_a;
+        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float o = c_x0 * x0 + c_xt * x[i];
+        if (noise) o += sigma * noise[i];
+        out[i] = o;
+    }
+}
+
 inline int blocks_for(long chw) {
     long v = chw / kVec / kThreads;
     if (v < 1) v = 1;
@@ -355,6 +372,16 @@ int siss_mse_bwd_seed(const float* pred, const void* target, int target_bf16, fl
     else
         loss_seed_kernel<false, 1><<<grid, kThreads, 0, s>>>(pred, target, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale, chw, c, nullptr, loss, nullptr, partials);
     fold_partials_kernel<<<cdiv(B, 64), 64, 0, s>>>(partials, nblk, B, sum_loss, nullptr);
+    SISS_LAUNCH_RET();
+}
+
+// out = c_x0 * clamp((x - sqrt_b*eps)/sqrt_a) + c_xt * x + sigma * noise   (noise may be NULL at t = 0)
+int siss_ddpm_step(const float* x, const float* eps, const float* noise, float* out, long n, float sqrt_a, float sqrt_b,
+                   float c_x0, float c_xt, float sigma, int clip, void* stream) {
+    SISS_CHECK_ARG(x && eps && out && n > 0 && sqrt_a > 0.f);
+    long nb = (n + kThreads - 1) / kThreads;
+    if (nb > 4096) nb = 4096;
+    ddpm_step_kernel<<<(int)nb, kThreads, 0, (hipStream_t)stream>>>(x, eps, noise, out, n, sqrt_a, sqrt_b, c_x0, c_xt, sigma, clip);
     SISS_LAUNCH_RET();
 }
 

@@ -19,6 +19,7 @@ SIGNATURES = {
     "siss_loss_partials_words": [I, L],
     "siss_mixture_fwd": [P, P, P, I, P, P, P, P, P, F, I, L, P, P, P, P, P, P, P, P, P],
     "siss_mixture_select": [P, P, P, P, I, P, P, P, P, F, I, L, P, P, P, P, P, P, P, P, P],
+    "siss_ddpm_step": [P, P, P, P, L, F, F, F, F, F, I, P],
     "siss_loss_bwd_seed": [P, P, P, P, I, P, P, P, P, F, I, L, P, P, P, P, P, P, P, P],
     "siss_mse_bwd_seed": [P, P, I, F, I, L, P, P, P, P, P],
     "siss_opt_partials_words": [],
