@@ -110,13 +110,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("SISS_BENCH_SINGLE_DEVICE") == "1":   # smoke-testing the N>1 code path on a 1-GPU box (gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" IS RCCL on ROCm
+        backend = os.environ.get("SISS_DIST_BACKEND", "nccl")           # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     from siss_amd import lib
@@ -189,13 +195,15 @@ def main():
     # ---- per-kernel timing of the dominant kernels (eager, HIP events on the launch stream) ----
     roof = None
     kern = {}
-    if not a.no_kernel_timing and rank == 0:
-        lib.PROF = []
+    if not a.no_kernel_timing:
+        # every rank runs these steps (the step holds a collective when N>1); only rank 0 records events
+        lib.PROF = [] if rank == 0 else None
         ksteps = min(a.steps, 3)
         for _ in range(ksteps):
             one_step()
-        torch.cuda.synchronize()
+        sync()
         prof, lib.PROF = lib.PROF, None
+    if not a.no_kernel_timing and rank == 0:
         for name, s, e, work in prof:
             d = kern.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1; d[1] += s.elapsed_time(e); d[2] += work
