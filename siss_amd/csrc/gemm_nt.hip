@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < steps) stage(s, s);
     int buf = 0, nbuf = STAGES - 1;
-    for (int s = 0; s < steps; ++s) {
+    for (int s = 0; s < ((p.ablate & 16) ? 0 : steps); ++s) {
         if (STAGES == 1) {
             // single buffer, two barriers per step: latency is hidden only by the OTHER resident blocks
             // (34 KiB of LDS per block -> 4 blocks per CU)
@@ -202,6 +202,7 @@ int launch_nt(const NTParams& p, int batch, hipStream_t st) {
 }  // namespace
 
 int siss_launch_gemm_nt_conv3(const void* params, void* stream);   // gemm_nt_conv3.hip
+int siss_launch_gemm_nt_c3(const void* params, void* stream);      // gemm_nt_c3.hip
 
 extern "C" {
 
@@ -239,6 +240,10 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
         static int use3 = -1;
         if (use3 < 0) { const char* e = getenv("SISS_NT_CONV3"); use3 = e ? atoi(e) : 0; }   // opt-in: measured a wash
         const long tiles = (long)cdiv(M, 128) * cdiv(N, BN);
+        static int c3 = -1;
+        if (c3 < 0) { const char* e = getenv("SISS_NT_C3"); c3 = e ? atoi(e) : 2; }   // 0 off, 1 always, 2 large grids
+        if (conv3 && Kp % 64 == 0 && N % BN == 0 && rows_per_image >= 256 && (c3 == 1 || (c3 == 2 && tiles >= 2048)))
+            return siss_launch_gemm_nt_c3(&p, stream);
         if (conv3 && (use3 == 1 || (use3 == 2 && tiles >= 1024))) return siss_launch_gemm_nt_conv3(&p, stream);
     }
     // big problems: 256-row tiles (one 8-wave block per CU, 3-stage ring); otherwise 128-row tiles

@@ -33,7 +33,8 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // MT = 16-row m-tiles per wave (4: 64-row wave tile, 8: 128-row wave tile); waves are laid out 2 (n) wide.
 template <int BM, int kThreads, int MT = 4>
 __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4][MT], char* smem, int m0, int n0,
-                                            int bz, int tid, int wm, int wn, int frow, int fq) {
+                                            int bz, int tid, int wm, int wn, int frow, int fq,
+                                            bool writer = true, int vrows = BM) {
     // ---- epilogue: bf16 tile through LDS (one 34 KiB image), then 16-B coalesced rows ----
     // Registers: acc[i][j][r] = channel n = wn*64 + i*16 + fq*4 + r of pixel m = wm*64 + j*16 + frow.
     // alpha, bias and the per-image row bias (time embedding) are applied in f32 BEFORE the one rounding to
@@ -43,7 +44,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
     const int img0 = m0 / rpi;                       // tile rows span at most 3 images (rows_per_image >= 64)
     const int b1 = (img0 + 1) * rpi - m0, b2 = b1 + rpi;
     const int last_img = (p.M - 1) / rpi;
-    {
+    if (writer) {
         f32x4_t bias4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -85,7 +86,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
     for (int it = 0; it < BM / kRowsPerIt; ++it) {
         const int row = it * kRowsPerIt + (tid >> 4);
         const int r = m0 + row;
-        if (r >= p.M) break;
+        if (r >= p.M || row >= vrows) break;
         u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * kCRow + chunk * 16);
         if (p.Hp > 0) {
             const int rem = r - (img0 + (row >= b1) + (row >= b2)) * rpi;
