@@ -59,4 +59,18 @@ __device__ __forceinline__ float dsilu_f(float z) {
     return s * (1.f + z * (1.f - s));
 }
 
+
+// LDS-DMA (global_load_lds_dwordx4) as inline asm: 16 B per lane, lane-linear LDS destination starting at the
+// wave-uniform byte address `lds_dst`.  Unlike __builtin_amdgcn_global_load_lds the compiler does not know this
+// statement writes LDS, so it does NOT put a conservative s_waitcnt vmcnt(0) in front of the next LDS read --
+// completion is counted by hand (s_waitcnt vmcnt(N) + barrier before the staged bytes are read).
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

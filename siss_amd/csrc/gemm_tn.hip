@@ -61,7 +61,8 @@ struct TCfg {
     static constexpr int kPieces = 16 / kWaves;                   // 4-row DMA pieces per wave and operand
     static constexpr int kXRows = BR + (TAPS == 3 ? 4 : 0);       // 64 (+ one extra 4-row DMA piece)
     static constexpr int kStageBytes = kYTile + kXRows * 256;
-    static constexpr int kSmemBytes = 2 * kStageBytes;
+    static constexpr int kStages = TAPS == 3 ? 3 : 2;            // 3 taps: one block per CU -> room for a 3-deep ring
+    static constexpr int kSmemBytes = kStages * kStageBytes;
 };
 
 template <int TAPS>
@@ -116,24 +117,25 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
         xsrc_extra = p.X + (xrow0 + row) * p.ldx + p.coff[pn] + c0 + ((lane & 15) ^ swz(row)) * 8;
     }
     const long ystep = (long)BR * p.ldy, xstep = (long)BR * p.ldx;
+    const unsigned smem_a = lds_addr(smem);
     auto stage = [&](int buf, int step) {
-        char* base = smem + buf * C_::kStageBytes + (w * NP * 4) * 256;
+        const unsigned base = smem_a + buf * C_::kStageBytes + (w * NP * 4) * 256;
         const int rbase = r0 + step * BR;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const bool ok = rbase + trow[j] < r1;
-            glds16(ok ? ysrc[j] + step * ystep : zsrc, base + j * 1024);
+            glds16_asm(ok ? ysrc[j] + step * ystep : zsrc, base + j * 1024);
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             // an X row matters only if one of the (up to TAPS) Y rows it meets is in range; everything
             // else comes from the zero page (never read past the operand; 0 * garbage could be NaN)
             const bool ok = rbase + trow[j] - (TAPS - 1) < r1;
-            glds16(ok ? xsrc[j] + step * xstep : zsrc, base + kYTile + j * 1024);
+            glds16_asm(ok ? xsrc[j] + step * xstep : zsrc, base + kYTile + j * 1024);
         }
         if (TAPS == 3 && w == 0) {
             const bool ok = rbase + BR + (lane >> 4) - (TAPS - 1) < r1;
-            glds16(ok ? xsrc_extra + step * xstep : zsrc, smem + buf * C_::kStageBytes + kYTile + BR * 256);
+            glds16_asm(ok ? xsrc_extra + step * xstep : zsrc, smem_a + buf * C_::kStageBytes + kYTile + BR * 256);
         }
     };
 
@@ -170,41 +172,99 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
         }
     }
 
-    // One barrier per K-step (see gemm_nt.hip): wait own DMA + own LDS reads, barrier, restage, compute.
-    stage(0, 0);
-    for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (s + 1 < steps) stage(buf ^ 1, s + 1);
-        const char* sb = smem + buf * C_::kStageBytes;
+    auto load_frags = [&](bf16x8_t (&yf)[4], bf16x8_t (&xf)[TAPS][CT], const char* sb, int kk) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t yf[4];
+        for (int i = 0; i < 4; ++i) {
+            s16x4_t a0 = tr_read(sb + ((y_off[0] ^ (i << 5)) + kk * 8192));
+            s16x4_t a1 = tr_read(sb + ((y_off[1] ^ (i << 5)) + kk * 8192));
+            yf[i] = bf16x8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s16x4_t a0 = tr_read(sb + ((y_off[0] ^ (i << 5)) + kk * 8192));
-                s16x4_t a1 = tr_read(sb + ((y_off[1] ^ (i << 5)) + kk * 8192));
-                yf[i] = bf16x8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                s16x4_t b0 = tr_read(sb + ((x_off[t][0] ^ (i << 5)) + kk * 8192));
+                s16x4_t b1 = tr_read(sb + ((x_off[t][1] ^ (i << 5)) + kk * 8192));
+                xf[t][i] = bf16x8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             }
+    };
+    auto mma_tap = [&](bf16x8_t (&yf)[4], bf16x8_t (&xf)[TAPS][CT], int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[t][j], acc[t][i][j], 0, 0, 0);
+    };
+
+    if constexpr (TAPS == 3) {
+        // Ring of three stage buffers, one barrier per K-step, and the fragment reads run one HALF-step ahead of
+        // the MFMAs in registers -- across the barrier too: the barrier at the bottom of step s comes after every
+        // wave's vmcnt(0) for stage s+2, so stage s+1 (landed one barrier earlier) may be read before it.
+        // Without this each wave exposed an LDS round trip ~6 times per step, and both waves of a SIMD (same
+        // block, same barrier) exposed it at the same time.
+        constexpr int SB = C_::kStageBytes;
+        bf16x8_t yf[2][4], xf[2][TAPS][CT];
+        stage(0, 0);
+        if (steps > 1) stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(yf[0], xf[0], smem, 0);
+        int buf = 0;
+        for (int s = 0; s < steps; ++s) {
+            const int b1 = buf + 1 == 3 ? 0 : buf + 1, b2 = b1 + 1 == 3 ? 0 : b1 + 1;
+            if (s + 2 < steps) stage(b2, s + 2);
+            const char* sb = smem + buf * SB;
+            const char* sbn = smem + b1 * SB;
+            // half-step kk = 0
             if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, bacc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[0][i], ones, bacc[i], 0, 0, 0);
             }
+            // taps in REVERSE load order: the first MFMAs need the last-loaded fragment, so the compiler's wait
+            // there is lgkmcnt(0) and no older read is outstanding when the next 20 are issued (lgkmcnt counts
+            // to 15 only; a capped wait would force some of the NEW reads to land before the MFMAs below)
+            mma_tap(yf[0], xf[0], 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(yf[1], xf[1], sb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(yf[0], xf[0], 1);
+            mma_tap(yf[0], xf[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // half-step kk = 1
+            if (do_bias) {
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                bf16x8_t xf[CT];
+                for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[1][i], ones, bacc[i], 0, 0, 0);
+            }
+            mma_tap(yf[1], xf[1], 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < steps) load_frags(yf[0], xf[0], sbn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(yf[1], xf[1], 1);
+            mma_tap(yf[1], xf[1], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            buf = b1;
+        }
+    } else {
+        // One barrier per K-step (see gemm_nt.hip): wait own DMA + own LDS reads, barrier, restage, compute.
+        stage(0, 0);
+        for (int s = 0; s < steps; ++s) {
+            const int buf = s & 1;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < steps) stage(buf ^ 1, s + 1);
+            const char* sb = smem + buf * C_::kStageBytes;
 #pragma unroll
-                for (int i = 0; i < CT; ++i) {
-                    s16x4_t b0 = tr_read(sb + ((x_off[t][0] ^ (i << 5)) + kk * 8192));
-                    s16x4_t b1 = tr_read(sb + ((x_off[t][1] ^ (i << 5)) + kk * 8192));
-                    xf[i] = bf16x8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t yf[4], xf[TAPS][CT];
+                load_frags(yf, xf, sb, kk);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, bacc[i], 0, 0, 0);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < CT; ++j)
-                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[t][i][j], 0, 0, 0);
+                for (int t = 0; t < TAPS; ++t) mma_tap(yf, xf, t);
             }
         }
     }
