@@ -97,15 +97,16 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     // scalar-load latency hides behind the compute phase instead of sitting between the barrier and the DMA.
     int st_pn = 0, st_kc = 0;
     long a_base = (long)p.shift[0] * p.lda + p.coff[0], w_base = 0;
+    const unsigned smem_a = lds_addr(smem);
     auto stage = [&](int buf, int step) {
         (void)step;
         const long aoff = a_base + st_kc * BK;
         const long woff = w_base + st_kc * BK;
-        char* base = smem + buf * C_::kStageBytes;
+        const unsigned base = smem_a + buf * C_::kStageBytes;
 #pragma unroll
-        for (int j = 0; j < C_::kAPieces; ++j) glds16(asrc[j] + aoff, base + (w * C_::kAPieces + j) * 1024);
+        for (int j = 0; j < C_::kAPieces; ++j) glds16_asm(asrc[j] + aoff, base + (w * C_::kAPieces + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < C_::kWPieces; ++j) glds16(wsrc[j] + woff, base + BM * 128 + (w * C_::kWPieces + j) * 1024);
+        for (int j = 0; j < C_::kWPieces; ++j) glds16_asm(wsrc[j] + woff, base + BM * 128 + (w * C_::kWPieces + j) * 1024);
         if (++st_kc == kchunks) {
             st_kc = 0;
             if (++st_pn < p.npanels) {
@@ -161,19 +162,51 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
             if (s + STAGES - 1 < steps && !((p.ablate & 2) && s >= 2)) stage(nbuf, s + STAGES - 1);
         }
         const char* sb = smem + buf * C_::kStageBytes;
-        if (!(p.ablate & 4))
+        if constexpr (STAGES == 1 && BM == 128) {
+            // 4 blocks per CU (128 VGPRs): no room for a second fragment set; the other three blocks hide the reads
+            if (!(p.ablate & 4))
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t af[MT], wf[4];
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t af[MT], wf[4];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sb + (a_off[i] ^ (kk << 6)));
+                for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sb + (a_off[i] ^ (kk << 6)));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(sb + (w_off[i] ^ (kk << 6)));
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(sb + (w_off[i] ^ (kk << 6)));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+            }
+        } else if (!(p.ablate & 4)) {
+            // Both k-halves' fragments live in registers: the kk = 1 reads are issued after the first MFMA row of
+            // kk = 0 and land under the remaining rows.  MFMA rows run i = 3 .. 0 so that the first row needs the
+            // LAST-issued read (the compiler's wait there is lgkmcnt(0); nothing older is outstanding later).
+            bf16x8_t af[2][MT], wf[2][4];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const bf16x8_t*>(sb + a_off[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[0][i] = *reinterpret_cast<const bf16x8_t*>(sb + w_off[i]);
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                acc[3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][3], af[0][j], acc[3][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[1][i] = *reinterpret_cast<const bf16x8_t*>(sb + (a_off[i] ^ 64));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[1][i] = *reinterpret_cast<const bf16x8_t*>(sb + (w_off[i] ^ 64));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 2; i >= 0; --i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], af[0][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 3; i >= 0; --i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], af[1][j], acc[i][j], 0, 0, 0);
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
         nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
