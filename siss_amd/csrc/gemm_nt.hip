@@ -154,7 +154,11 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         } else {
-            if (STAGES == 3 && s + 1 < steps)
+            // stages s .. s+STAGES-2 have been issued; step s must have landed, the younger ones may fly
+            const int rem = steps - 1 - s;
+            if (STAGES >= 4 && rem >= 2)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * C_::kPerStage) : "memory");
+            else if (STAGES >= 3 && rem >= 1)
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C_::kPerStage) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -236,6 +240,7 @@ int launch_nt(const NTParams& p, int batch, hipStream_t st) {
 
 int siss_launch_gemm_nt_conv3(const void* params, void* stream);   // gemm_nt_conv3.hip
 int siss_launch_gemm_nt_c3(const void* params, void* stream);      // gemm_nt_c3.hip
+int siss_launch_gemm_nt_c3p(const void* params, void* stream);     // gemm_nt_c3p.hip
 
 extern "C" {
 
@@ -260,6 +265,7 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+    { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     SISS_CHECK_ARG((!rowbias && Hp == 0) || rows_per_image >= 64);   // <= 3 images per 128/256-row tile
     SISS_CHECK_ARG(N % 8 == 0 && (!rowbias || ldrb % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0));
     for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
@@ -275,8 +281,11 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
         const long tiles = (long)cdiv(M, 128) * cdiv(N, BN);
         static int c3 = -1;
         if (c3 < 0) { const char* e = getenv("SISS_NT_C3"); c3 = e ? atoi(e) : 2; }   // 0 off, 1 always, 2 large grids
-        if (conv3 && Kp % 64 == 0 && N % BN == 0 && rows_per_image >= 256 && (c3 == 1 || (c3 == 2 && tiles >= 2048)))
-            return siss_launch_gemm_nt_c3(&p, stream);
+        if (conv3 && Kp % 64 == 0 && N % BN == 0 && rows_per_image >= 256 && (c3 == 1 || (c3 == 2 && tiles >= 2048))) {
+            static int c3p = -1;
+            if (c3p < 0) { const char* e = getenv("SISS_NT_C3P"); c3p = e ? atoi(e) : 1; }   // persistent producer/consumer variant
+            return c3p ? siss_launch_gemm_nt_c3p(&p, stream) : siss_launch_gemm_nt_c3(&p, stream);
+        }
         if (conv3 && (use3 == 1 || (use3 == 2 && tiles >= 1024))) return siss_launch_gemm_nt_conv3(&p, stream);
     }
     // big problems: 256-row tiles (one 8-wave block per CU, 3-stage ring); otherwise 128-row tiles
@@ -295,6 +304,11 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;
     if (stages == 1 || (stages == 0 && tiles128 >= 2048)) return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
+    // at most one block per CU anyway: a 4-deep ring (128 KiB) keeps three K-steps of DMA in flight, so a step
+    // costs its MFMA time instead of an L2 round trip (the 8x8 .. 32x32 layers are bound by the serial K loop)
+    static int deep = -1;
+    if (deep < 0) { const char* e = getenv("SISS_NT_DEEP"); deep = e ? atoi(e) : 1; }
+    if (deep && tiles128 <= 256) return launch_nt<128, 4, 4>(p, batch, (hipStream_t)stream);
     // tiny grids (8x8 / 16x16 layers, attention): 64-row tiles double the block count
     static int small = -1;
     if (small < 0) { const char* e = getenv("SISS_NT_SMALL"); small = e ? atoi(e) : 0; }   // opt-in: measured +-5 % (these layers are K-latency-bound, not block-count-bound)

@@ -1,0 +1,328 @@
+// Persistent, producer/consumer-specialised 3x3-convolution kernel (fprop and dgrad on the large grids).
+//
+// What the one-role kernels (gemm_nt.hip, gemm_nt_c3.hip) cannot hide: a wave issues its instructions in order, and
+// one global_load_lds piece costs 60-180 issue cycles, so the waves that own the MFMAs stall for the whole DMA
+// issue of every K-step (measured: DMA phase + MFMA phase ~ sum, no overlap), and the epilogue of a tile overlaps
+// nothing unless another block is resident.  Here one 8-wave block per CU runs ALL its tiles:
+//
+//   waves 0-3  consumers: a 254x128 output tile as four 128x64 wave tiles (8x4 MFMA accumulators), LDS fragment
+//              reads one 16-MFMA block ahead of the MFMAs; at the end of a tile they only add bias / row bias, round
+//              to bf16 and park the tile in the LDS slot they just finished reading;
+//   waves 4-7  producers: the LDS-DMA of every group, and the rest of the epilogue: they pull the parked tile into
+//              registers (which frees the slot for the next DMA), then mask the halo, add the residual and store
+//              16 B per lane / 128 B per row while the consumers are already in the next tile's MFMAs.
+//              Consumer w and producer w+4 share a SIMD: DMA issue, epilogue VALU and stores overlap MFMA issue.
+// (A lone consumer wave doing the whole epilogue cost 40 % of a tile: wave64 VALU ops take 4 cycles each and every
+// dependent global load is a full round trip with nobody to hide it.)
+//
+// Group = (tile, filter row ky, 64-channel chunk kc): as in gemm_nt_c3 the A tile of a group is staged once
+// (256 rows x 128 B) beside the three taps' weight tiles and read at row offsets 0/1/2: 80 KiB per group, two slots
+// = all 160 KiB of the CU's LDS.  ONE barrier per group (192 MFMAs per consumer wave), shared by all eight waves:
+// the producers pass barrier #g only after group g has landed (vmcnt(0)), then issue group g+1 into the slot that
+// group g-1 just left.  The group sequence simply continues over tile boundaries: while the consumers run the
+// epilogue of tile i, tile i+1's first group is already landing.
+#include "nt_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int P_BM = 256, P_VALID = 254, P_THREADS = 512;
+constexpr int P_ABYTES = P_BM * 128;                       // 32,768
+constexpr int P_WBYTES = BN * 128;                         // 16,384 per tap
+constexpr int P_SLOT = P_ABYTES + 3 * P_WBYTES;            // 81,920: one GROUP (A tile + three weight tiles)
+constexpr int P_SMEM = 2 * P_SLOT;                         // 163,840 = all of the CU's LDS
+
+__device__ __forceinline__ int swz3p(int row) { return row & 6; }
+// s_barrier as inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin barrier, which would make every
+// consumer wave wait for its epilogue STORES (an HBM round trip) before the next tile's first group barrier.
+// Everything that must be complete at a barrier here is waited for explicitly.
+__device__ __forceinline__ void c3p_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+struct TileMap {
+    int nb, per, b_lo, b_hi, tiles_n, ntiles;
+    __device__ __forceinline__ int tile(int k) const { return k * nb + b_lo * per + b_hi; }   // XCD-contiguous
+};
+
+__global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    TileMap tm;
+    tm.nb = gridDim.x; tm.per = tm.nb >> 3; tm.b_lo = blockIdx.x & 7; tm.b_hi = blockIdx.x >> 3;
+    tm.tiles_n = p.N / BN;
+    tm.ntiles = ((p.M + P_VALID - 1) / P_VALID) * tm.tiles_n;
+    int count = 0;
+    while (tm.tile(count) < tm.ntiles) ++count;
+    const int kchunks = p.Kp / BK;
+    const int gpt = 3 * kchunks;                           // groups per tile
+    const int G = count * gpt;
+    if (G == 0) return;
+    const long wtap = (long)p.N * p.Kp;
+    constexpr int SROW = 144;                              // parked tile: 128 B of channels + 16 B pad per row
+    const int rpi = p.rows_per_image;
+    const int last_img = (p.M - 1) / rpi;
+
+    if (w >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pw = w - 4;
+        const int wm = pw >> 1, wn = pw & 1;               // the consumer wave whose sub-tile this wave stores
+        const int prow = lane >> 3, pc = lane & 7;
+        const unsigned smem_a = lds_addr(smem);
+        int gk = 0, gky = 0, gkc = 0, issued = 0;          // group cursor: (tile k, filter row ky, K chunk kc)
+        const bf16_t* asrc[8];
+        const bf16_t* wsrc[4];
+        auto set_tile = [&](int k) {
+            const int t = tm.tile(k);
+            const int m0 = (t / tm.tiles_n) * P_VALID, n0 = (t % tm.tiles_n) * BN;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = (pw * 8 + j) * 8 + prow;
+                int gr = m0 + row; gr = gr < p.M + 1 ? gr : p.M + 1;
+                asrc[j] = p.A + (long)gr * p.lda + ((pc ^ swz3p(row)) << 3);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = (pw * 4 + j) * 8 + prow;
+                wsrc[j] = p.W + (long)(n0 + row) * p.Kp + ((pc ^ swz3p(row)) << 3);
+            }
+        };
+        auto issue_group = [&]() {
+            const long aoff = (long)p.shift[3 * gky] * p.lda + p.coff[3 * gky] + gkc * BK;
+            const long woff = 3L * gky * wtap + gkc * BK;
+            const unsigned dst = smem_a + (issued & 1) * P_SLOT;
+            if (!((p.ablate & 2) && issued >= 2)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) glds16_asm(asrc[j] + aoff, dst + (pw * 8 + j) * 1024);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        glds16_asm(wsrc[j] + woff + t * wtap, dst + P_ABYTES + t * P_WBYTES + (pw * 4 + j) * 1024);
+            }
+            ++issued;
+            if (++gkc == kchunks) { gkc = 0; if (++gky == 3) { gky = 0; ++gk; if (gk < count) set_tile(gk); } }
+        };
+
+        // The parked tile of the previous tile, in registers: lane -> (row = it*8 + lane>>3, 16-B chunk = lane&7).
+        u32x4_t ov[16];
+        int pend = -1, phalf = 0;                          // tile iteration whose rows `ov` holds (-1: none), next half
+        // Stores rows it = 8*half .. 8*half+7 of the parked tile (one half per group, so that the producers are
+        // back at the next group barrier in time).  Returns true when exactly 8 store instructions were issued.
+        auto store_tile = [&](auto has_r, int half) -> bool {
+            constexpr bool HAS_R = decltype(has_r)::value;
+            const int tl = tm.tile(pend);
+            const int m0 = (tl / tm.tiles_n) * P_VALID, n0 = (tl % tm.tiles_n) * BN;
+            const int img0 = m0 / rpi;                     // a 256-row tile spans at most two images (rpi >= 256)
+            const int split = (img0 + 1) * rpi;            // first row of the second image
+            const int ccol = n0 + wn * 64 + pc * 8;
+            u32x4_t res[HAS_R ? 8 : 1];
+            if constexpr (HAS_R) {
+                // all residual loads, then ONE wait, before the first store: vmcnt counts loads and stores in one
+                // in-order queue on gfx9 -- a load waited for after a store would wait for that store's round trip
+#pragma unroll
+                for (int i8 = 0; i8 < 8; ++i8) {
+                    const int row = wm * 128 + (half * 8 + i8) * 8 + prow;
+                    int r = m0 + row; r = r < p.M ? r : p.M - 1;
+                    res[i8] = *reinterpret_cast<const u32x4_t*>(p.R + (long)r * p.ldr + ccol);
+                }
+#pragma unroll
+                for (int i8 = 0; i8 < 8; ++i8) asm volatile("" : "+v"(res[i8]));
+            }
+#pragma unroll
+            for (int i8 = 0; i8 < 8; ++i8) {
+                const int row = wm * 128 + (half * 8 + i8) * 8 + prow;
+                const int r = m0 + row;
+                if (row >= P_VALID || r >= p.M) continue;
+                u32x4_t o = half ? ov[8 + i8] : ov[i8];
+                bool halo = false;
+                if (p.Hp > 0) {
+                    const int rem = r - img0 * rpi - (r >= split ? rpi : 0);
+                    const int y = (int)(((float)rem + 0.5f) * p.inv_wp), x = rem - y * p.Wp;
+                    halo = (y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1);
+                }
+                if (halo) o = u32x4_t{0u, 0u, 0u, 0u};
+                else if constexpr (HAS_R) {
+                    const u32x4_t rr = res[i8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
+                                        __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
+                }
+                *reinterpret_cast<u32x4_t*>(p.C + (long)r * p.ldc + ccol) = o;
+            }
+            return m0 + wm * 128 + half * 64 + 64 <= p.M;  // rows 254/255 only mask lanes of the last instruction
+        };
+
+        int gin = 0;
+        set_tile(0);
+        issue_group();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int g = 0; g < G; ++g) {
+            c3p_barrier();                                 // #g: group g has landed; consumers are done with group g-1
+            if (g + 1 < G) issue_group();                  // -> slot (g+1)&1: last read by group g-1 / parked tile already in `ov`
+            bool counted = false;
+            if (pend >= 0) {
+                if (!(p.ablate & 1)) {
+                    if (p.R) store_tile(std::true_type{}, phalf);      // its wait retired the DMA above as well
+                    else counted = store_tile(std::false_type{}, phalf);
+                }
+                if (++phalf == 2) { phalf = 0; pend = -1; }
+            }
+            // the DMA of group g+1 must have landed before barrier #g+1; 8 younger stores may stay in flight
+            if (counted) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (++gin == gpt) {                            // g was the last group of its tile
+                gin = 0;
+                c3p_barrier();                             // E : every consumer has finished reading slot g&1
+                c3p_barrier();                             // E2: the consumers have parked the tile there
+                const char* st = smem + (g & 1) * P_SLOT + pw * (128 * SROW);
+#pragma unroll
+                for (int it = 0; it < 16; ++it)
+                    ov[it] = *reinterpret_cast<const u32x4_t*>(st + (it * 8 + prow) * SROW + pc * 16);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) asm volatile("" : "+v"(ov[it]));      // in registers before barrier #g+1
+                pend = g / gpt;
+            }
+        }
+        if (pend >= 0 && !(p.ablate & 1)) {
+            for (; phalf < 2; ++phalf) {
+                if (p.R) store_tile(std::true_type{}, phalf); else store_tile(std::false_type{}, phalf);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm = w >> 1, wn = w & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_base[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) a_base[t] = (wm * 128 + frow + t) * 128 + ((fq ^ swz3p(frow + t)) << 4);
+    const int w_base = P_ABYTES + (wn * 64 + frow) * 128 + ((fq ^ swz3p(frow)) << 4);
+
+    f32x4_t acc[4][8];   // [n-tile][m-tile]
+    bf16x8_t wf[2][4], af[2][4];
+    int gg = 0;                                            // global group index (slot = gg & 1)
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    long long t0 = clock64();
+#define C3P_TICK(i) do { if (p.dbg) { const long long t1 = clock64(); tk[i] += t1 - t0; t0 = t1; } } while (0)
+    for (int k = 0; k < count; ++k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < gpt; ++g, ++gg) {
+            const char* sl = smem + (gg & 1) * P_SLOT;
+            auto ldA = [&](bf16x8_t (&dst)[4], int t, int kk, int h) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    dst[jj] = *reinterpret_cast<const bf16x8_t*>(sl + (a_base[t] ^ (kk << 6)) + (h * 4 + jj) * 2048);
+            };
+            auto ldW = [&](bf16x8_t (&dst)[4], int t, int kk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    dst[i] = *reinterpret_cast<const bf16x8_t*>(sl + (w_base ^ (kk << 6)) + t * P_WBYTES + i * 2048);
+            };
+            c3p_barrier();                                 // #gg: this group's slot has landed
+            if (p.ablate & 4) continue;
+            ldW(wf[0], 0, 0);
+            ldA(af[0], 0, 0, 0);
+            // 12 blocks of 16 MFMAs: block b = (tap t, k-half kk, m-half h); the fragments of block b+1 are read
+            // before block b's MFMAs (counted lgkmcnt leaves them in flight).  Block 0 runs one MFMA row first:
+            // the wait in front of it is lgkmcnt(0) and must not cover fresh reads.
+#pragma unroll
+            for (int b = 0; b < 12; ++b) {
+                const int h = b & 1;
+                if (b == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][0], af[0][jj], acc[0][jj], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (b + 1 < 12) {
+                    const int nb = b + 1, nt = nb >> 2, nkk = (nb >> 1) & 1, nh = nb & 1;
+                    ldA(af[nb & 1], nt, nkk, nh);
+                    if (nh == 0) ldW(wf[(nb >> 1) & 1], nt, nkk);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = (b == 0 ? 1 : 0); i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc[i][h * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(b >> 1) & 1][i], af[b & 1][jj],
+                                                                                      acc[i][h * 4 + jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        C3P_TICK(0);
+
+        // ---- consumer half of the epilogue: alpha, bias and the per-image row bias in f32, ONE rounding to bf16
+        // (the residual is added after it by the producers: the reference's autocast order), parked in the slot of
+        // the tile's last group as four wave-private 128 x 64 images.
+        // acc[i][j][r] = channel n0 + wn*64 + i*16 + fq*4 + r of row m0 + wm*128 + j*16 + frow.
+        const int tl = tm.tile(k);
+        const int m0 = (tl / tm.tiles_n) * P_VALID, n0 = (tl % tm.tiles_n) * BN;
+        const int img0 = m0 / rpi;
+        const int img1 = img0 + 1 < last_img ? img0 + 1 : last_img;
+        const int split = (img0 + 1) * rpi;
+        const int ncol = n0 + wn * 64 + fq * 4;
+        // every load of this half is issued here, in front of barrier E, so that its round trip overlaps the wait
+        f32x4_t b0[4], b1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b0[i] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + ncol + i * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            b1[i] = b0[i];
+        }
+        if (p.rowbias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(p.rowbias + (long)img0 * p.ldrb + ncol + i * 16);
+                const f32x4_t r1 = *reinterpret_cast<const f32x4_t*>(p.rowbias + (long)img1 * p.ldrb + ncol + i * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { b0[i][e] += r0[e]; b1[i][e] += r1[e]; }
+            }
+        }
+        c3p_barrier();                                     // E: every consumer wave has finished reading the slot
+        C3P_TICK(1);
+        {
+            char* st = smem + ((gg - 1) & 1) * P_SLOT + w * (128 * SROW) + frow * SROW + fq * 8;
+            auto park = [&](auto two_images) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool second = decltype(two_images)::value && m0 + wm * 128 + j * 16 + frow >= split;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4_t v = acc[i][j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + (second ? b1[i][e] : b0[i][e]);
+                        *reinterpret_cast<u32x2_t*>(st + j * 16 * SROW + i * 32) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    }
+                }
+            };
+            // almost every tile lies inside one image: no per-row select between the two images' row biases
+            if (p.rowbias && m0 + P_BM > split) park(std::true_type{}); else park(std::false_type{});
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        c3p_barrier();                                     // E2: the tile is parked; the producers take it from here
+        C3P_TICK(2);
+    }
+    if (p.dbg && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 6; ++i) p.dbg[w * 8 + i] = tk[i];
+}
+
+}  // namespace
+
+// Preconditions (checked by siss_gemm_nt): nine panels in three row-consecutive triples, Kp % 64 == 0,
+// N % 128 == 0, batch == 1, rows_per_image >= 256.
+int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
+    const NTParams& p = *reinterpret_cast<const NTParams*>(params);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_c3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_SMEM) != hipSuccess)
+            return SISS_ERR_LAUNCH;
+        attr_set = true;
+    }
+    gemm_nt_c3p_kernel<<<dim3(256), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+}

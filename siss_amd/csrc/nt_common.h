@@ -17,6 +17,7 @@ struct NTParams {
     int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
     float alpha, inv_wp;
     int ablate;
+    long long* dbg;                   // timing probe buffer (SISS_NT_DEBUG_PTR), normally null
     int shift[kMaxPanels];
     int coff[kMaxPanels];
 };
