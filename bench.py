@@ -95,7 +95,7 @@ def hbm_traffic(launcher):
     fn = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
     if not os.path.exists(fn):
         return None
-    stem = launcher.replace("siss_", "") + "_kernel"
+    stem = launcher.replace("siss_", "") + "_"        # gemm_nt_kernel<..>, gemm_nt_c3p_kernel, ...
     tot = n = 0.0
     for k, v in json.load(open(fn)).items():
         if k.startswith(stem):
