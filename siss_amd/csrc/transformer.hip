@@ -1,0 +1,321 @@
+// Token-space pieces of the SD UNet's Transformer2DModel (SURVEY.md §8 a-U config 5, Appendix A7):
+// LayerNorm, GEGLU, head split / merge for the batched attention GEMMs, and a row softmax of any length.
+// All tensors are compact row-major bf16 [rows][C]; statistics and gradients are f32.
+// HBM-bound helpers -- the matrix products around them run on gemm_nt / gemm_tn.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxChunks = 4;            // 8-channel chunks per lane: C <= 64 * 8 * 4 = 2048
+
+__device__ __forceinline__ void unpack8f(const u32x4_t r, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __builtin_bit_cast(float, r[e] << 16);
+        v[2 * e + 1] = __builtin_bit_cast(float, r[e] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4_t pack8f(const float (&v)[8]) {
+    return u32x4_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+
+// One wave per row; lane l owns 8-channel chunks l, l+64, ...
+__global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd,
+                                                                 long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int nch = C >> 3;
+    float v[kMaxChunks][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            unpack8f(*reinterpret_cast<const u32x4_t*>(x + r * C + c * 8), v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i)
+        if (lane + i * 64 < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+        }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * gamma[c * 8 + e] + beta[c * 8 + e];
+            *reinterpret_cast<u32x4_t*>(y + r * C + c * 8) = pack8f(o);
+        }
+    }
+}
+
+// dx[r] = (accum[r] +) rstd * (dy*gamma - mean_c(dy*gamma) - xhat * mean_c(dy*gamma*xhat)); saved row = r % rows_x.
+// dgamma / dbeta: per cotangent set (set = r / set_rows), per-lane partial column sums over the block's rows,
+// folded across the block's waves in LDS, one f32 atomic per column and block.
+__global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const bf16_t* __restrict__ accum,
+                                                                 bf16_t* __restrict__ dx, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, long rows2, long rows_x, long set_rows,
+                                                                 long set_stride, int C, int rows_per_block) {
+    __shared__ float red[2][kThreads / 64][64 * 8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nch = C >> 3;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block; r1 = r1 < rows2 ? r1 : rows2;
+    // a block never straddles two sets (rows_per_block divides set_rows)
+    const long set = r0 / set_rows;
+    float dg[kMaxChunks][8], db[kMaxChunks][8], ga[kMaxChunks][8];
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dg[i][e] = 0.f; db[i][e] = 0.f;
+            const int c = lane + i * 64;
+            ga[i][e] = c < nch ? gamma[c * 8 + e] : 0.f;
+        }
+    for (long r = r0 + w; r < r1; r += kThreads / 64) {
+        const long rx = r % rows_x;
+        const float mu = mean[rx], rs = rstd[rx];
+        float d[kMaxChunks][8], xh[kMaxChunks][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxChunks; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                float xv[8];
+                unpack8f(*reinterpret_cast<const u32x4_t*>(dy + r * C + c * 8), d[i]);
+                unpack8f(*reinterpret_cast<const u32x4_t*>(x + rx * C + c * 8), xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    dg[i][e] += d[i][e] * xh[i][e];
+                    db[i][e] += d[i][e];
+                    d[i][e] *= ga[i][e];
+                    s1 += d[i][e];
+                    s2 += d[i][e] * xh[i][e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < kMaxChunks; ++i) {
+            const int c = lane + i * 64;
+            if (c < nch) {
+                float o[8], a[8];
+                if (accum) unpack8f(*reinterpret_cast<const u32x4_t*>(accum + r * C + c * 8), a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (d[i][e] - s1 - xh[i][e] * s2) + (accum ? a[e] : 0.f);
+                *reinterpret_cast<u32x4_t*>(dx + r * C + c * 8) = pack8f(o);
+            }
+        }
+    }
+    if (!dgamma) return;
+    for (int i = 0; i < kMaxChunks; ++i) {
+        if (i * 64 >= nch) break;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][w][lane * 8 + e] = dg[i][e]; red[1][w][lane * 8 + e] = db[i][e]; }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * 512; t += kThreads) {
+            const int which = t >> 9, col = t & 511;
+            const int c = i * 512 + col;
+            if (c < C) {
+                float sum = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < kThreads / 64; ++ww) sum += red[which][ww][col];
+                atomicAdd((which ? dbeta : dgamma) + set * set_stride + c, sum);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float g) {
+    return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+
+// out[r][f] = h[r][f] * gelu(h[r][F + f])
+__global__ __launch_bounds__(kThreads) void geglu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ out, long rows, int F) {
+    const long idx = (long)blockIdx.x * kThreads + threadIdx.x;       // one 8-channel chunk per thread
+    const int nch = F >> 3;
+    if (idx >= rows * nch) return;
+    const long r = idx / nch; const int c = (int)(idx - r * nch);
+    float a[8], g[8], o[8];
+    unpack8f(*reinterpret_cast<const u32x4_t*>(h + r * 2 * F + c * 8), a);
+    unpack8f(*reinterpret_cast<const u32x4_t*>(h + r * 2 * F + F + c * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] * gelu_f(g[e]);
+    *reinterpret_cast<u32x4_t*>(out + r * F + c * 8) = pack8f(o);
+}
+
+// dh[r][:F] = dout * gelu(g), dh[r][F:] = dout * a * gelu'(g); saved row = r % rows_x
+__global__ __launch_bounds__(kThreads) void geglu_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ h,
+                                                             bf16_t* __restrict__ dh, long rows2, long rows_x, int F) {
+    const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
+    const int nch = F >> 3;
+    if (idx >= rows2 * nch) return;
+    const long r = idx / nch; const int c = (int)(idx - r * nch);
+    const long rx = r % rows_x;
+    float a[8], g[8], d[8], oa[8], og[8];
+    unpack8f(*reinterpret_cast<const u32x4_t*>(h + rx * 2 * F + c * 8), a);
+    unpack8f(*reinterpret_cast<const u32x4_t*>(h + rx * 2 * F + F + c * 8), g);
+    unpack8f(*reinterpret_cast<const u32x4_t*>(dout + r * F + c * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { oa[e] = d[e] * gelu_f(g[e]); og[e] = d[e] * a[e] * dgelu_f(g[e]); }
+    *reinterpret_cast<u32x4_t*>(dh + r * 2 * F + c * 8) = pack8f(oa);
+    *reinterpret_cast<u32x4_t*>(dh + r * 2 * F + F + c * 8) = pack8f(og);
+}
+
+// dst[(b*H + h)][s][d] = src[b][s][h*D + d] for s < S, d < D; zero for the padding (s in [S, Sp), d in [D, Dp))
+__global__ __launch_bounds__(kThreads) void head_split_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              int B, int S, int H, int D, int Sp, int Dp) {
+    const long idx = (long)blockIdx.x * kThreads + threadIdx.x;       // one 8-element chunk of dst per thread
+    const int nch = Dp >> 3;
+    const long total = (long)B * H * Sp * nch;
+    if (idx >= total) return;
+    const int c = (int)(idx % nch);
+    long t = idx / nch;
+    const int s = (int)(t % Sp); t /= Sp;
+    const int h = (int)(t % H); const int b = (int)(t / H);
+    u32x4_t o = u32x4_t{0u, 0u, 0u, 0u};
+    if (s < S && c * 8 < D) o = *reinterpret_cast<const u32x4_t*>(src + ((long)b * S + s) * H * D + h * D + c * 8);
+    *reinterpret_cast<u32x4_t*>(dst + idx * 8) = o;
+}
+
+// dst[b][s][h*D + d] = src[(b*H + h)][s][d]
+__global__ __launch_bounds__(kThreads) void head_merge_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              int B, int S, int H, int D, int Sp, int Dp) {
+    const long idx = (long)blockIdx.x * kThreads + threadIdx.x;       // one 8-element chunk of dst per thread
+    const int nch = D >> 3;
+    const long total = (long)B * S * H * nch;
+    if (idx >= total) return;
+    const int c = (int)(idx % nch);
+    long t = idx / nch;
+    const int h = (int)(t % H); t /= H;
+    const int s = (int)(t % S); const int b = (int)(t / S);
+    *reinterpret_cast<u32x4_t*>(dst + idx * 8) =
+        *reinterpret_cast<const u32x4_t*>(src + (((long)b * H + h) * Sp + s) * Dp + c * 8);
+}
+
+// p[r][k] = softmax over k < valid of s[r][k]; p[r][k] = 0 for valid <= k < ld.  One wave per row, any length.
+__global__ __launch_bounds__(kThreads) void softmax_rows_fwd_kernel(const bf16_t* __restrict__ s, bf16_t* __restrict__ p,
+                                                                    long rows, int valid, int ld) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bf16_t* src = s + r * ld;
+    float mx = -INFINITY;
+    for (int k = lane; k < valid; k += 64) mx = fmaxf(mx, bf2f(src[k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int k = lane; k < valid; k += 64) sum += __expf(bf2f(src[k]) - mx);
+    const float inv = 1.f / wave_sum(sum);
+    for (int k = lane; k < ld; k += 64) p[r * ld + k] = k < valid ? f2bf(__expf(bf2f(src[k]) - mx) * inv) : (bf16_t)0;
+}
+
+// ds[r][k] = scale * p[rp][k] * (dp[r][k] - sum_k p*dp), rp = r % p_rows; zero in the padding
+__global__ __launch_bounds__(kThreads) void softmax_rows_bwd_kernel(const bf16_t* __restrict__ p, const bf16_t* __restrict__ dp,
+                                                                    bf16_t* __restrict__ ds, long rows, long p_rows, int valid,
+                                                                    int ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bf16_t* pr = p + (r % p_rows) * ld;
+    const bf16_t* dr = dp + r * ld;
+    float dot = 0.f;
+    for (int k = lane; k < valid; k += 64) dot += bf2f(pr[k]) * bf2f(dr[k]);
+    dot = wave_sum(dot);
+    for (int k = lane; k < ld; k += 64)
+        ds[r * ld + k] = k < valid ? f2bf(scale * bf2f(pr[k]) * (bf2f(dr[k]) - dot)) : (bf16_t)0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// y = LayerNorm(x) * gamma + beta over the last dim; mean / rstd [rows] are saved for the backward.
+int siss_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       long rows, int C, float eps, void* stream) {
+    SISS_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * kMaxChunks);
+    layernorm_fwd_kernel<<<cdiv(rows, kThreads / 64), kThreads, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+    SISS_LAUNCH_RET();
+}
+
+// dy [rows2][C] (rows2 = nsets * set_rows), saved x / mean / rstd of rows_x rows (index r % rows_x);
+// dx = LN backward (+ accum if given, same shape as dx); dgamma/dbeta[set * set_stride + c] += column sums (optional).
+int siss_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                       const void* accum, void* dx, float* dgamma, float* dbeta, long rows2, long rows_x, long set_rows,
+                       long set_stride, int C, void* stream) {
+    SISS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows2 > 0 && rows_x > 0 && set_rows > 0);
+    SISS_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 64 * 8 * kMaxChunks && rows2 % set_rows == 0 && (!dgamma || dbeta));
+    // rows per block: a divisor of set_rows near 64 (blocks must not straddle sets)
+    int rpb = 64;
+    while (rpb > 1 && set_rows % rpb) --rpb;
+    layernorm_bwd_kernel<<<cdiv(rows2, rpb), kThreads, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)accum, (bf16_t*)dx, dgamma, dbeta, rows2,
+        rows_x, set_rows, set_stride, C, rpb);
+    SISS_LAUNCH_RET();
+}
+
+int siss_geglu_fwd(const void* h, void* out, long rows, int F, void* stream) {
+    SISS_CHECK_ARG(h && out && rows > 0 && F > 0 && F % 8 == 0);
+    geglu_fwd_kernel<<<cdiv(rows * (F / 8), kThreads), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)h, (bf16_t*)out, rows, F);
+    SISS_LAUNCH_RET();
+}
+
+int siss_geglu_bwd(const void* dout, const void* h, void* dh, long rows2, long rows_x, int F, void* stream) {
+    SISS_CHECK_ARG(dout && h && dh && rows2 > 0 && rows_x > 0 && F > 0 && F % 8 == 0);
+    geglu_bwd_kernel<<<cdiv(rows2 * (F / 8), kThreads), kThreads, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dout, (const bf16_t*)h, (bf16_t*)dh, rows2, rows_x, F);
+    SISS_LAUNCH_RET();
+}
+
+// [B][S][H*D] -> [B*H][Sp][Dp], zero padded (Sp >= S, Dp >= D, all of D, Dp multiples of 8)
+int siss_head_split(const void* src, void* dst, int B, int S, int H, int D, int Sp, int Dp, void* stream) {
+    SISS_CHECK_ARG(src && dst && B > 0 && S > 0 && H > 0 && D > 0 && D % 8 == 0 && Dp % 8 == 0 && Sp >= S && Dp >= D);
+    head_split_kernel<<<cdiv((long)B * H * Sp * (Dp / 8), kThreads), kThreads, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)src, (bf16_t*)dst, B, S, H, D, Sp, Dp);
+    SISS_LAUNCH_RET();
+}
+
+// [B*H][Sp][Dp] -> [B][S][H*D]
+int siss_head_merge(const void* src, void* dst, int B, int S, int H, int D, int Sp, int Dp, void* stream) {
+    SISS_CHECK_ARG(src && dst && B > 0 && S > 0 && H > 0 && D > 0 && D % 8 == 0 && Dp % 8 == 0 && Sp >= S && Dp >= D);
+    head_merge_kernel<<<cdiv((long)B * S * H * (D / 8), kThreads), kThreads, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)src, (bf16_t*)dst, B, S, H, D, Sp, Dp);
+    SISS_LAUNCH_RET();
+}
+
+// Row softmax over the first `valid` of `ld` columns (the rest is written as zero); s already carries the scale.
+int siss_softmax_rows_fwd(const void* s, void* p, long rows, int valid, int ld, void* stream) {
+    SISS_CHECK_ARG(s && p && rows > 0 && valid > 0 && ld >= valid);
+    softmax_rows_fwd_kernel<<<cdiv(rows, kThreads / 64), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)s, (bf16_t*)p, rows, valid, ld);
+    SISS_LAUNCH_RET();
+}
+
+int siss_softmax_rows_bwd(const void* p, const void* dp, void* ds, long rows, long p_rows, int valid, int ld, float scale,
+                          void* stream) {
+    SISS_CHECK_ARG(p && dp && ds && rows > 0 && p_rows > 0 && valid > 0 && ld >= valid);
+    softmax_rows_bwd_kernel<<<cdiv(rows, kThreads / 64), kThreads, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)ds, rows, p_rows, valid, ld, scale);
+    SISS_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -54,6 +54,14 @@ SIGNATURES = {
     "siss_mha_small_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P],
     "siss_softmax_fwd": [P, P, L, I, P],
     "siss_softmax_bwd": [P, P, P, L, L, I, F, P],
+    "siss_layernorm_fwd": [P, P, P, P, P, P, L, I, F, P],
+    "siss_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, L, L, L, I, P],
+    "siss_geglu_fwd": [P, P, L, I, P],
+    "siss_geglu_bwd": [P, P, P, L, L, I, P],
+    "siss_head_split": [P, P, I, I, I, I, I, I, P],
+    "siss_head_merge": [P, P, I, I, I, I, I, I, P],
+    "siss_softmax_rows_fwd": [P, P, L, I, I, P],
+    "siss_softmax_rows_bwd": [P, P, P, L, L, I, I, F, P],
     "siss_timestep_sincos": [P, P, I, I, I, F, P],
     "siss_linear_small_fwd": [P, P, P, P, I, I, I, I, P],
     "siss_linear_multi_fwd": [P, P, P, P, P, I, I, I, P],

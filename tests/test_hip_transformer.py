@@ -1,0 +1,119 @@
+"""Parity of the token-space kernels of the SD UNet (transformer.hip) against plain torch fp32 on the same
+bf16-rounded inputs.  Tolerances: outputs are rounded to bf16 -> rel 1e-2 of the tensor's scale; f32 column
+sums (dgamma / dbeta) rel 2e-3."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    from siss_amd import lib
+    lib.load()
+    return torch.device("cuda:0")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _close(got, ref, rel, what=""):
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g} (rel {err / scale:.3g} > {rel})"
+
+
+@pytest.mark.parametrize("rows,C", [(96, 320), (130, 640), (64, 1280), (24, 64)])
+def test_layernorm_fwd_bwd_two_sets(dev, rows, C):
+    from siss_amd import lib
+    g = torch.Generator().manual_seed(rows + C)
+    x = _bf(torch.randn(rows, C, generator=g) * 2 + 0.5)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    dy = _bf(torch.randn(2 * rows, C, generator=g))            # two cotangent sets over the same saved rows
+    acc = _bf(torch.randn(2 * rows, C, generator=g))
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    refs = []
+    for k in range(2):
+        gx, gg, gb = torch.autograd.grad(y_ref, (xr, gr, br), dy[k * rows:(k + 1) * rows], retain_graph=True)
+        refs.append((gx, gg, gb))
+
+    xd, yd = x.to(dev).to(torch.bfloat16), torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    lib.call("siss_layernorm_fwd", xd, gamma.to(dev), beta.to(dev), yd, mean, rstd, rows, C, 1e-5)
+    _close(yd.float().cpu(), y_ref.detach(), 1e-2, "ln fwd")
+    dx = torch.empty(2 * rows, C, dtype=torch.bfloat16, device=dev)
+    P = 4096
+    grads = torch.zeros(2, P, device=dev)
+    lib.call("siss_layernorm_bwd", dy.to(dev).to(torch.bfloat16), xd, gamma.to(dev), mean, rstd,
+             acc.to(dev).to(torch.bfloat16), dx, grads[0, 100:], grads[0, 2000:], 2 * rows, rows, rows, P, C)
+    torch.cuda.synchronize()
+    for k in range(2):
+        _close(dx[k * rows:(k + 1) * rows].float().cpu(), refs[k][0] + acc[k * rows:(k + 1) * rows], 1.5e-2, f"ln dx set {k}")
+        _close(grads[k, 100:100 + C].cpu(), refs[k][1], 2e-3, f"ln dgamma set {k}")
+        _close(grads[k, 2000:2000 + C].cpu(), refs[k][2], 2e-3, f"ln dbeta set {k}")
+
+
+def test_geglu_fwd_bwd(dev):
+    from siss_amd import lib
+    g = torch.Generator().manual_seed(3)
+    rows, Fd = 70, 256
+    h = _bf(torch.randn(rows, 2 * Fd, generator=g) * 1.5)
+    dout = _bf(torch.randn(2 * rows, Fd, generator=g))
+    hr = h.clone().requires_grad_(True)
+    a, gg = hr.chunk(2, dim=-1)
+    out_ref = a * F.gelu(gg)
+    hd = h.to(dev).to(torch.bfloat16)
+    out = torch.empty(rows, Fd, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_geglu_fwd", hd, out, rows, Fd)
+    _close(out.float().cpu(), out_ref.detach(), 1e-2, "geglu fwd")
+    dh = torch.empty(2 * rows, 2 * Fd, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_geglu_bwd", dout.to(dev).to(torch.bfloat16), hd, dh, 2 * rows, rows, Fd)
+    for k in range(2):
+        (gh,) = torch.autograd.grad(out_ref, hr, dout[k * rows:(k + 1) * rows], retain_graph=True)
+        _close(dh[k * rows:(k + 1) * rows].float().cpu(), gh, 1e-2, f"geglu bwd set {k}")
+
+
+@pytest.mark.parametrize("B,S,H,D,Sp,Dp", [(2, 64, 8, 40, 64, 64), (3, 7, 2, 32, 64, 64), (1, 77, 8, 160, 128, 192)])
+def test_head_split_merge_roundtrip(dev, B, S, H, D, Sp, Dp):
+    from siss_amd import lib
+    g = torch.Generator().manual_seed(B + S)
+    x = torch.randn(B, S, H * D, generator=g).to(torch.bfloat16).to(dev)
+    hs = torch.full((B * H, Sp, Dp), 7.0, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_head_split", x, hs, B, S, H, D, Sp, Dp)
+    ref = x.view(B, S, H, D).permute(0, 2, 1, 3).reshape(B * H, S, D)
+    assert torch.equal(hs[:, :S, :D], ref)
+    assert float(hs[:, S:, :].abs().sum()) == 0 and float(hs[:, :, D:].abs().sum()) == 0
+    back = torch.empty_like(x)
+    lib.call("siss_head_merge", hs, back, B, S, H, D, Sp, Dp)
+    assert torch.equal(back, x)
+
+
+@pytest.mark.parametrize("rows,valid,ld", [(40, 77, 128), (16, 4096, 4096), (33, 64, 64)])
+def test_softmax_rows_fwd_bwd(dev, rows, valid, ld):
+    from siss_amd import lib
+    g = torch.Generator().manual_seed(valid)
+    s = _bf(torch.randn(rows, ld, generator=g) * 3)
+    dp = _bf(torch.randn(2 * rows, ld, generator=g))
+    sr = s[:, :valid].clone().requires_grad_(True)
+    p_ref = torch.softmax(sr, dim=-1)
+    sd = s.to(dev).to(torch.bfloat16)
+    p = torch.full((rows, ld), 5.0, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_softmax_rows_fwd", sd, p, rows, valid, ld)
+    _close(p[:, :valid].float().cpu(), p_ref.detach(), 1e-2, "softmax fwd")
+    assert float(p[:, valid:].abs().sum()) == 0
+    ds = torch.full((2 * rows, ld), 5.0, dtype=torch.bfloat16, device=dev)
+    scale = 0.37
+    lib.call("siss_softmax_rows_bwd", p, dp.to(dev).to(torch.bfloat16), ds, 2 * rows, rows, valid, ld, scale)
+    pb = p[:, :valid].float().cpu()
+    for k in range(2):
+        d = dp[k * rows:(k + 1) * rows, :valid]
+        ref = scale * pb * (d - (pb * d).sum(-1, keepdim=True))
+        _close(ds[k * rows:(k + 1) * rows, :valid].float().cpu(), ref, 2e-2, f"softmax bwd set {k}")
+    assert float(ds[:, valid:].abs().sum()) == 0
