@@ -60,3 +60,42 @@ class UNet2DConfig:
 
     def head_dim(self, channels):
         return self.attention_head_dim if self.attention_head_dim is not None else channels
+
+
+@dataclass
+class UNet2DConditionConfig:
+    """``UNet2DConditionModel`` (Stable Diffusion v1.x UNet; delete_sd.py:458-462, config/delete_sd.yaml:70).
+    diffusers quirk kept as is: for this model ``attention_head_dim`` is the NUMBER of heads (8)."""
+    sample_size: int = 64
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",)
+    up_block_types: Tuple[str, ...] = ("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3
+    layers_per_block: int = 2
+    attention_head_dim: int = 8
+    cross_attention_dim: int = 768
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    downsample_padding: int = 1
+    flip_sin_to_cos: bool = True
+    freq_shift: int = 0
+    act_fn: str = "silu"
+
+    @staticmethod
+    def sd15():
+        return UNet2DConditionConfig()
+
+    @staticmethod
+    def from_dict(d):
+        names = {f.name for f in fields(UNet2DConditionConfig)}
+        return UNet2DConditionConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k in names})
+
+    @staticmethod
+    def from_json(path):
+        with open(path) as f:
+            return UNet2DConditionConfig.from_dict(json.load(f))
+
+    @property
+    def heads(self):
+        return self.attention_head_dim

@@ -63,6 +63,48 @@ __global__ __launch_bounds__(kThreads) void conv_out_fprop_kernel(
     }
 }
 
+// Any C % 8 == 0 (the SD UNet's 320-channel head): one WAVE per pixel, lane l owns the 8-channel chunks
+// l, l+64, ...; the 64 partial dot products meet in a full-wave butterfly.
+template <int CO>
+__global__ __launch_bounds__(kThreads) void conv_out_fprop_wave_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ pred, int B, int H, int W, int C) {
+    extern __shared__ float shw[];   // [9][CO][C]
+    for (int i = threadIdx.x; i < 9 * CO * C; i += kThreads) shw[i] = w[i];
+    __syncthreads();
+    const int nch = C / 8, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long npix = (long)B * H * W;
+    const int Wp = W + 2;
+    for (long p = (long)blockIdx.x * (kThreads / 64) + wv; p < npix; p += (long)gridDim.x * (kThreads / 64)) {
+        const int xx = p % W; long t = p / W;
+        const int yy = t % H; const int n = t / H;
+        const long row = ((long)n * (H + 2) + yy + 1) * Wp + xx + 1;
+        float acc[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+        for (int cc = lane; cc < nch; cc += 64) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const long r = row + (tap / 3 - 1) * Wp + (tap % 3 - 1);
+                float v[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(x + r * C + cc * 8), v);
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    const float* ww = shw + (tap * CO + o) * C + cc * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o] += v[e] * ww[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = wave_sum(acc[o]);
+        if (lane == 0) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) pred[(((long)n * CO + o) * H + yy) * W + xx] = acc[o] + bias[o];
+        }
+    }
+}
+
 template <int CO>
 __global__ __launch_bounds__(kThreads) void conv_out_dgrad_kernel(
     const float* __restrict__ c, const float* __restrict__ w, bf16_t* __restrict__ dx, int N2, int H, int W,
@@ -178,11 +220,18 @@ extern "C" {
 
 int siss_conv_out_fprop(const void* x, const float* w, const float* bias, float* pred, int B, int H, int W, int C,
                         int CO, void* stream) {
-    SISS_CHECK_ARG(x && w && bias && pred && B > 0 && H > 0 && W > 0 && lpp_ok(C));
+    SISS_CHECK_ARG(x && w && bias && pred && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    SISS_CHECK_ARG(9L * CO * C * sizeof(float) <= 64 * 1024);
+    hipStream_t st = (hipStream_t)stream;
+    if (!lpp_ok(C)) {
+        long nb = ((long)B * H * W + 3) / 4;
+        if (nb > 4096) nb = 4096;
+        DISPATCH_CO(CO, (conv_out_fprop_wave_kernel<kCO><<<(int)nb, kThreads, 9 * kCO * C * sizeof(float), st>>>((const bf16_t*)x, w, bias, pred, B, H, W, C)));
+        SISS_LAUNCH_RET();
+    }
     const int ppb = kThreads / (C / 8);
     long nb = ((long)B * H * W + ppb - 1) / ppb;
     if (nb > 4096) nb = 4096;
-    hipStream_t st = (hipStream_t)stream;
     DISPATCH_CO(CO, (conv_out_fprop_kernel<kCO><<<(int)nb, kThreads, 9 * kCO * C * sizeof(float), st>>>((const bf16_t*)x, w, bias, pred, B, H, W, C)));
     SISS_LAUNCH_RET();
 }

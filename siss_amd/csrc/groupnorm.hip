@@ -22,9 +22,12 @@ constexpr int kThreads = 256;
 constexpr int kMaxG = 32;
 constexpr int kMaxC = 1024;
 
+// Wide tensors (C > kMaxC: the SD UNet's 1280..2560-channel concats) are cut into channel SLICES of whole
+// groups (blockIdx.z): C / G below are the slice's, ld / Gf the full tensor's.
 struct GNShape {
     int H, W, C, G, cpg, lpp, ppi;     // lanes per pixel (C/8), pixels per iteration
     int chunk_px, nchunks;             // interior pixels per block, blocks per sample
+    int ld, Gf, nslices;               // row stride (= full channel count), full group count, channel slices
 };
 
 __device__ __forceinline__ long compact_row(int n, int pi, int H, int W) { return (long)n * H * W + pi; }
@@ -84,18 +87,19 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const bf16_t* __rest
     __shared__ __attribute__((aligned(16))) float red[2048];
     __shared__ float ch_a[kMaxC], ch_b[kMaxC];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int c0 = blockIdx.z * s.C;
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
     const bool active = slot < s.ppi;
     float a[8] = {}, b[8] = {};
     if (active) {
-        const bf16_t* base = x + (long)n * (s.H + 2) * (s.W + 2) * s.C + cc * 8;
+        const bf16_t* base = x + (long)n * (s.H + 2) * (s.W + 2) * s.ld + c0 + cc * 8;
         PixelWalk w(s, chunk, slot);
         while (w.ok()) {                       // two pixels per trip: both loads are in flight together
-            const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.C);
+            const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ld);
             w.next();
             const bool two = w.ok();
             u32x4_t r1 = u32x4_t{0u, 0u, 0u, 0u};
-            if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.C); w.next(); }
+            if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ld); w.next(); }
             float v[8], u[8];
             unpack8(r0, v); unpack8(r1, u);
 #pragma unroll
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const bf16_t* __rest
         const float* src = (tid & 1) ? ch_b : ch_a;
         float t = 0.f;
         for (int c = g * s.cpg; c < (g + 1) * s.cpg; ++c) t += src[c];
-        partial[((long)n * s.nchunks + chunk) * 2 * s.G + tid] = t;
+        partial[(((long)n * s.nslices + blockIdx.z) * s.nchunks + chunk) * 2 * s.G + tid] = t;
     }
 }
 
@@ -133,7 +137,7 @@ __device__ __forceinline__ void fold_stats(const float* __restrict__ partial, co
                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                            bool write) {
     __shared__ float red[4][64];
-    fold_slab(partial + (long)n * s.nchunks * 2 * s.G, s.nchunks, s.G, red);
+    fold_slab(partial + ((long)n * s.nslices + blockIdx.z) * s.nchunks * 2 * s.G, s.nchunks, s.G, red);
     const int tid = threadIdx.x;
     if (tid < s.G) {
         const double a = (double)red[0][2 * tid] + red[1][2 * tid] + red[2][2 * tid] + red[3][2 * tid];
@@ -144,7 +148,10 @@ __device__ __forceinline__ void fold_stats(const float* __restrict__ partial, co
         var = var > 0 ? var : 0;
         const float r = (float)(1.0 / sqrt(var + (double)eps));
         sh_mean[tid] = (float)m; sh_rstd[tid] = r;
-        if (write) { mean_out[(long)n * s.G + tid] = (float)m; rstd_out[(long)n * s.G + tid] = r; }
+        if (write) {
+            const long go = (long)n * s.Gf + blockIdx.z * s.G + tid;
+            mean_out[go] = (float)m; rstd_out[go] = r;
+        }
     }
     __syncthreads();
 }
@@ -159,25 +166,27 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
     fold_stats(partial, s, n, eps, sh_mean, sh_rstd, mean_out, rstd_out, chunk == 0);
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
     if (slot >= s.ppi) return;
+    const int c0 = blockIdx.z * s.C;
     float sc[8], sf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = cc * 8 + e, g = c / s.cpg;
-        sc[e] = sh_rstd[g] * gamma[c];
-        sf[e] = beta[c] - sh_mean[g] * sc[e];
+        sc[e] = sh_rstd[g] * gamma[c0 + c];
+        sf[e] = beta[c0 + c] - sh_mean[g] * sc[e];
     }
     const long img = (long)n * (s.H + 2) * (s.W + 2);
-    const bf16_t* base = x + img * s.C + cc * 8;
+    const bf16_t* base = x + img * s.ld + c0 + cc * 8;
+    y += c0;
     auto out_row = [&](const PixelWalk& w) { return out_compact ? compact_row(n, w.pi, s.H, s.W) : img + w.row(); };
     PixelWalk w(s, chunk, slot);
     while (w.ok()) {
-        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.C);
+        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ld);
         const long o0 = out_row(w);
         w.next();
         const bool two = w.ok();
         u32x4_t r1 = u32x4_t{0u, 0u, 0u, 0u};
         long o1 = 0;
-        if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.C); o1 = out_row(w); w.next(); }
+        if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ld); o1 = out_row(w); w.next(); }
         float v[8], u[8];
         unpack8(r0, v); unpack8(r1, u);
 #pragma unroll
@@ -186,8 +195,8 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
             v[e] = SILU ? silu_f(z0) : z0;
             u[e] = SILU ? silu_f(z1) : z1;
         }
-        *reinterpret_cast<u32x4_t*>(y + o0 * s.C + cc * 8) = pack8(v);
-        if (two) *reinterpret_cast<u32x4_t*>(y + o1 * s.C + cc * 8) = pack8(u);
+        *reinterpret_cast<u32x4_t*>(y + o0 * s.ld + cc * 8) = pack8(v);
+        if (two) *reinterpret_cast<u32x4_t*>(y + o1 * s.ld + cc * 8) = pack8(u);
     }
 }
 
@@ -203,8 +212,10 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
     __shared__ __attribute__((aligned(16))) float red[2048];
     __shared__ float ch1[kMaxC], ch2[kMaxC];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int c0 = blockIdx.z * s.C, g0 = blockIdx.z * s.G;
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
     const bool active = slot < s.ppi;
+    gamma += c0; beta += c0; dy += c0;
     float a1[SETS][8], a2[SETS][8];
 #pragma unroll
     for (int k = 0; k < SETS; ++k)
@@ -215,20 +226,20 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cc * 8 + e, g = c / s.cpg;
-            rs[e] = rstd[(long)n * s.G + g]; mr[e] = mean[(long)n * s.G + g] * rs[e];
+            rs[e] = rstd[(long)n * s.Gf + g0 + g]; mr[e] = mean[(long)n * s.Gf + g0 + g] * rs[e];
             ga[e] = gamma[c]; be[e] = beta[c];
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
-        const bf16_t* xb = x + (long)n * rpi * s.C + cc * 8;
+        const bf16_t* xb = x + (long)n * rpi * s.ld + c0 + cc * 8;
         for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
             // all loads of this pixel (x + one dy per set) are issued before the first use
-            const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C);
+            const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.ld);
             u32x4_t rd[SETS];
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
                 const int n2 = k * nx + n;
                 const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : (long)n2 * rpi + w.row();
-                rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8);
+                rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.ld + cc * 8);
             }
             float v[8], xh[8], dsl[8];
             unpack8(rx, v);
@@ -258,9 +269,9 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
             const float* src = (tid & 1) ? ch2 : ch1;
             float t = 0.f;
             for (int c = g * s.cpg; c < (g + 1) * s.cpg; ++c) t += src[c] * gamma[c];
-            partial[((long)n2 * s.nchunks + chunk) * 2 * s.G + tid] = t;
+            partial[(((long)n2 * s.nslices + blockIdx.z) * s.nchunks + chunk) * 2 * s.G + tid] = t;
         }
-        const long so = (long)(n2 / set_images) * set_stride;
+        const long so = (long)(n2 / set_images) * set_stride + c0;
         for (int i = tid; i < s.C; i += kThreads) {
             atomicAdd(dgamma + so + i, ch2[i]);
             atomicAdd(dbeta + so + i, ch1[i]);
@@ -280,12 +291,14 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
     __shared__ __attribute__((aligned(16))) float red[2048];
     __shared__ float chs[kMaxC];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int c0 = blockIdx.z * s.C, g0 = blockIdx.z * s.G;
+    gamma += c0; beta += c0;
     {
         __shared__ float fr[4][64];
         const double cnt = (double)s.H * s.W * s.cpg;
         for (int k = 0; k < SETS; ++k) {
             const int n2 = k * nx + n;
-            fold_slab(partial + (long)n2 * s.nchunks * 2 * s.G, s.nchunks, s.G, fr);
+            fold_slab(partial + ((long)n2 * s.nslices + blockIdx.z) * s.nchunks * 2 * s.G, s.nchunks, s.G, fr);
             if (tid < s.G) {
                 sh_s1[k][tid] = (float)(((double)fr[0][2 * tid] + fr[1][2 * tid] + fr[2][2 * tid] + fr[3][2 * tid]) / cnt);
                 sh_s2[k][tid] = (float)(((double)fr[0][2 * tid + 1] + fr[1][2 * tid + 1] + fr[2][2 * tid + 1] + fr[3][2 * tid + 1]) / cnt);
@@ -305,21 +318,22 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cc * 8 + e, g = c / s.cpg;
-            rs[e] = rstd[(long)n * s.G + g]; mr[e] = mean[(long)n * s.G + g] * rs[e];
+            rs[e] = rstd[(long)n * s.Gf + g0 + g]; mr[e] = mean[(long)n * s.Gf + g0 + g] * rs[e];
             ga[e] = gamma[c]; be[e] = beta[c];
 #pragma unroll
             for (int k = 0; k < SETS; ++k) { m1[k][e] = sh_s1[k][g]; m2[k][e] = sh_s2[k][g]; }
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
-        const bf16_t* xb = x + (long)n * rpi * s.C + cc * 8;
+        const bf16_t* xb = x + (long)n * rpi * s.ld + c0 + cc * 8;
+        const int ch = c0 + cc * 8;                       // first channel of this lane in the full tensor
         for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
-            const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.C);
+            const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.ld);
             // Output routing: one tensor of C channels, or (dx2 != null: the input was a channel concat)
             // channels [0, split_c) -> dx (row stride split_c) and [split_c, C) -> dx2 (row stride C - split_c,
             // optionally accumulated): the concat backward costs no extra pass.
-            const bool second = dx2 != nullptr && cc * 8 >= split_c;
-            bf16_t* const obase = second ? dx2 + (cc * 8 - split_c) : dx + cc * 8;
-            const int ostride = dx2 ? (second ? s.C - split_c : split_c) : s.C;
+            const bool second = dx2 != nullptr && ch >= split_c;
+            bf16_t* const obase = second ? dx2 + (ch - split_c) : dx + ch;
+            const int ostride = dx2 ? (second ? s.ld - split_c : split_c) : s.ld;
             const bool oacc = second && accumulate2;
             u32x4_t rd[SETS], ra[SETS], rb[SETS], rc[SETS];
 #pragma unroll
@@ -327,9 +341,9 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
                 const int n2 = k * nx + n;
                 const long orow = (long)n2 * rpi + w.row();
                 const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : orow;
-                rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.C + cc * 8);
-                ra[k] = accum ? *reinterpret_cast<const u32x4_t*>(accum + orow * s.C + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
-                rb[k] = accum2 ? *reinterpret_cast<const u32x4_t*>(accum2 + orow * s.C + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.ld + ch);
+                ra[k] = accum ? *reinterpret_cast<const u32x4_t*>(accum + orow * s.ld + ch) : u32x4_t{0u, 0u, 0u, 0u};
+                rb[k] = accum2 ? *reinterpret_cast<const u32x4_t*>(accum2 + orow * s.ld + ch) : u32x4_t{0u, 0u, 0u, 0u};
                 rc[k] = oacc ? *reinterpret_cast<const u32x4_t*>(obase + orow * ostride) : u32x4_t{0u, 0u, 0u, 0u};
             }
             float v[8], xh[8], dsl[8];
@@ -357,22 +371,40 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
     if (colsum) {
         for (int k = 0; k < SETS; ++k) {
             reduce_slots(cs[k], active, slot, cc, s, red, chs);
-            for (int i = tid; i < s.C; i += kThreads) atomicAdd(colsum + (long)(k * nx + n) * colsum_ld + i, chs[i]);
+            for (int i = tid; i < s.C; i += kThreads) atomicAdd(colsum + (long)(k * nx + n) * colsum_ld + c0 + i, chs[i]);
             __syncthreads();
         }
     }
 }
 
 bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16) {
-    if (H <= 0 || W <= 0 || C <= 0 || G <= 0 || G > kMaxG || C % G || C % 8 || C > kMaxC) return false;
-    s.H = H; s.W = W; s.C = C; s.G = G; s.cpg = C / G;
-    s.lpp = C / 8;
+    if (H <= 0 || W <= 0 || C <= 0 || G <= 0 || G > kMaxG || C % G || C % 8) return false;
+    s.H = H; s.W = W; s.ld = C; s.Gf = G; s.cpg = C / G;
+    int gs = G;                                         // groups per slice
+    if (C > kMaxC) {
+        // the largest whole-group slice of <= kMaxC channels (a multiple of 8) that keeps >= 90 % of the
+        // block's lanes busy; else the best utilisation found
+        int best = 0, best_util = -1;
+        gs = 0;
+        for (int d = G; d >= 1; --d) {
+            if (G % d) continue;
+            const int cs = d * s.cpg;
+            if (cs > kMaxC || cs % 8) continue;
+            const int lpp = cs / 8, util = (kThreads / lpp) * lpp;
+            if (util * 10 >= kThreads * 9) { gs = d; break; }
+            if (util > best_util) { best_util = util; best = d; }
+        }
+        if (gs == 0) gs = best;
+        if (gs == 0) return false;
+    }
+    s.G = gs; s.C = gs * s.cpg; s.nslices = G / gs;
+    s.lpp = s.C / 8;
     if (s.lpp > kThreads) return false;
     s.ppi = kThreads / s.lpp;
     const int px = H * W;
     // ~3 blocks per CU, and >= 16 pixel iterations per thread so that the per-block prologue (slab fold)
     // and epilogue (LDS + global atomics) are amortised
-    int nch = (768 + N - 1) / N;
+    int nch = (768 + N * s.nslices - 1) / (N * s.nslices);
     const int max_by_work = (px + 16 * s.ppi - 1) / (16 * s.ppi);
     if (nch > max_by_work) nch = max_by_work;
     if (nch > 256) nch = 256;
@@ -390,7 +422,7 @@ extern "C" {
 long siss_gn_partial_words(int n, int H, int W, int C, int G) {
     GNShape s;
     if (!make_shape(H, W, C, G, s, 1)) return -1;   // N = 1 gives the largest chunk count -> upper bound
-    return (long)n * s.nchunks * 2 * G;
+    return (long)n * s.nslices * s.nchunks * 2 * s.G;
 }
 
 // y = act(GroupNorm(x)); x padded NHWC; y padded or compact ([N][H*W][C]).  Writes mean/rstd [N][G].
@@ -402,7 +434,7 @@ int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, voi
     SISS_CHECK_ARG(make_shape(H, W, C, G, s, N));
     SISS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(s.nchunks, N);
+    dim3 grid(s.nchunks, N, s.nslices);
     gn_stats_kernel<<<grid, kThreads, 0, st>>>((const bf16_t*)x, s, partial);
     if (silu)
         gn_apply_kernel<true><<<grid, kThreads, 0, st>>>((const bf16_t*)x, gamma, beta, partial, s, eps, out_compact, (bf16_t*)y, mean, rstd);
@@ -430,7 +462,7 @@ int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const 
     SISS_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)accum | (uintptr_t)accum2 | (uintptr_t)dx2) % 16 == 0);
     SISS_CHECK_ARG(!dx2 || (split_c > 0 && split_c < C && split_c % 8 == 0));
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(s.nchunks, nx);
+    dim3 grid(s.nchunks, nx, s.nslices);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;
 #define GN_BWD(SILU, SETS)                                                                                          \
     gn_bwd_stats_kernel<SILU, SETS><<<grid, kThreads, 0, st>>>(dyp, xp, gamma, beta, mean, rstd, s, nx, dy_compact, \

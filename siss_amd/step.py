@@ -59,10 +59,13 @@ class SISSStepper:
             engine.on_early_grads_final = self._early_allreduce
 
     # ------------------------------------------------------------------ one micro-batch
-    def micro_step(self, x0, a0, noise, t, u):
+    def micro_step(self, x0, a0, noise, t, u, conditioning=None):
         """Inputs: x0/a0/noise [B,C,H,W] (cast to the io dtype like delete_celeb.py:561-581),
-        t [B] int64, u [B] keep/forget uniforms.  Enqueues fwd + dual backward; no host sync."""
+        t [B] int64, u [B] keep/forget uniforms; conditioning: the dict the reference splats into the UNet
+        call ({} or {'encoder_hidden_states': [B,77,768]}, delete_sd.py:974-976).  Enqueues fwd + dual
+        backward; no host sync."""
         e = self.e
+        cond = dict(conditioning or {})
         if self._micro == 0:
             e.zero_grad()
         x0, a0, noise = (v.to(device=e.device, dtype=self.io_dtype).contiguous() for v in (x0, a0, noise))
@@ -70,7 +73,7 @@ class SISSStepper:
         scale = 1.0 / (self.train_batch_size * self.world * self.ga)
         if self.loss_fn == SISS:
             m = mixture_fwd(x0, a0, noise, t, u, self.ac, self.gamma_tab, self.sigma_tab, self.lambd)
-            pred = e.forward(m.x_mix, t)
+            pred = e.forward(m.x_mix, t, **cond)
             cot = e._buf("cot", (2 * B, *pred.shape[1:]))
             # c_x / c_a go straight into the stacked cotangent buffer that seeds the dual backward
             seed = loss_bwd_seed(pred, m, x0, a0, scale, c_out=cot, partials=self._partials(B, pred[0].numel()))
@@ -84,7 +87,8 @@ class SISSStepper:
             mf = mixture_fwd(x0, a0, noise, t, torch.zeros(B, device=e.device), self.ac, self.gamma_tab,
                              self.sigma_tab, 0.5)  # u=0 <= .5: forget rows -> q_sample(a0)
             xin = torch.cat([m.x_mix, mf.x_mix], 0)
-            pred = e.forward(xin, torch.cat([t, t], 0))
+            cond2 = {k: torch.cat([v, v], 0) for k, v in cond.items()}
+            pred = e.forward(xin, torch.cat([t, t], 0), **cond2)
             tgt = torch.cat([noise, noise], 0)
             cot, _, sums = mse_bwd_seed(pred, tgt, scale)
             e.backward(cot, nsets=2)
@@ -123,10 +127,10 @@ class SISSStepper:
         self.opt.launch(g, scaling_norm=self.scaling_norm, eta=self.eta, inf_guard=self.inf_guard)
         self.e.refresh_weights()
 
-    def step(self, x0, a0, noise, t, u):
+    def step(self, x0, a0, noise, t, u, conditioning=None):
         """GA=1 convenience."""
         assert self.ga == 1
-        self.micro_step(x0, a0, noise, t, u)
+        self.micro_step(x0, a0, noise, t, u, conditioning)
 
     # ------------------------------------------------------------------ logging (one small D2H)
     def stats(self):

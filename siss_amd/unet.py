@@ -409,9 +409,9 @@ class UNetEngine:
         assert words > 0
         return self._buf("gn_partial", (max(words, 1),))
 
-    def gn(self, x: Act, pre, silu, compact_out=False):
+    def gn(self, x: Act, pre, silu, compact_out=False, eps=None):
         """GroupNorm(+SiLU).  Returns Act (or a compact [N*H*W, C] bf16 tensor)."""
-        G, eps = self.cfg.norm_num_groups, self.cfg.norm_eps
+        G, eps = self.cfg.norm_num_groups, (self.cfg.norm_eps if eps is None else eps)
         ps = self.ps
         nm = self._name(pre)
         mean = self._buf(nm + ".mean", (x.n, G))
@@ -778,23 +778,7 @@ class UNetEngine:
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
-        # conv_in: im2col rows (K = 9*Cin padded to 64) then a one-panel GEMM
-        kp = ps.specs["conv_in.weight"].native_shape[1]
-        col = self._act("conv_in.col", N, H, W, kp)
-        lib.call("siss_im2col3x3", x, int(x.dtype == torch.bfloat16), col.data, N, cin, H, W, kp, 0)
-        c0 = cfg.block_out_channels[0]
-        h = self._act("conv_in.out", N, H, W, c0)
-        ops.gemm_nt(lib.ptr(col.data), kp, ps.sh("conv_in.weight"), lib.ptr(h.data), c0, col.rows, c0, kp, [0], [0],
-                    bias=ps.p("conv_in.bias"), rows_per_image=col.rows_per_image, hp=col.hp, wp=col.wp)
-        h0 = h
-
-        def conv_in_bwd():
-            dh = self._take(h0)
-            dW = ps.grads[self.gbase:, ps.specs["conv_in.weight"].off:]
-            self._wgrad(dh, col, dW, c0, kp, 1, dbias=ps.g("conv_in.bias", self.gbase))
-            self._put(dh)
-        self.tape.append(conv_in_bwd)
-
+        h = self._conv_in(x)
         skips = [h]
         early = self._early_blocks()
         self._early_mark = None
@@ -821,6 +805,33 @@ class UNetEngine:
             if up:
                 h = self.upsample(h, f"up_blocks.{i}.upsamplers.0")
         assert not skips
+        return self._head(h)
+
+    def _conv_in(self, x):
+        """conv_in: im2col rows (K = 9*Cin padded to 64) then a one-panel GEMM."""
+        cfg, ps = self.cfg, self.ps
+        N, cin, H, W = x.shape
+        kp = ps.specs["conv_in.weight"].native_shape[1]
+        col = self._act("conv_in.col", N, H, W, kp)
+        lib.call("siss_im2col3x3", x, int(x.dtype == torch.bfloat16), col.data, N, cin, H, W, kp, 0)
+        c0 = cfg.block_out_channels[0]
+        h = self._act("conv_in.out", N, H, W, c0)
+        ops.gemm_nt(lib.ptr(col.data), kp, ps.sh("conv_in.weight"), lib.ptr(h.data), c0, col.rows, c0, kp, [0], [0],
+                    bias=ps.p("conv_in.bias"), rows_per_image=col.rows_per_image, hp=col.hp, wp=col.wp)
+        h0 = h
+
+        def conv_in_bwd():
+            dh = self._take(h0)
+            dW = ps.grads[self.gbase:, ps.specs["conv_in.weight"].off:]
+            self._wgrad(dh, col, dW, c0, kp, 1, dbias=ps.g("conv_in.bias", self.gbase))
+            self._put(dh)
+        self.tape.append(conv_in_bwd)
+        return h
+
+    def _head(self, h: Act):
+        """conv_norm_out -> SiLU -> conv_out; returns pred [N, Cout, H, W] f32 and tapes its backward."""
+        cfg, ps = self.cfg, self.ps
+        N, H, W, c0 = h.n, h.h, h.w, cfg.block_out_channels[0]
         a, gn_b = self.gn(h, "conv_norm_out", True)
         co = cfg.out_channels
         pred = self._buf("pred", (N, co, H, W))

@@ -64,3 +64,40 @@ def test_mnist_config_one_siss_step_on_cpu():
     assert all(map(lambda v: v == v and v != float("inf"), (st.norm_loss_x, st.norm_loss_a, st.pre_clip_norm)))
     assert abs(st.scaling_factor * st.norm_loss_a - 5.0) < 1e-4          # norm fixing: ||s * g_a|| = scaling_norm
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+
+
+def test_sd15_param_count_and_keys():
+    """UNet2DConditionModel of runwayml/stable-diffusion-v1-5 (config/delete_sd.yaml:70): 859,520,964 parameters in
+    686 tensors, diffusers key names."""
+    from oracle.unet_cond import OracleUNet2DCondition, UNetCondConfig
+    with torch.device("meta"):
+        m = OracleUNet2DCondition(UNetCondConfig.sd15())
+    ps = dict(m.named_parameters())
+    assert sum(p.numel() for p in ps.values()) == 859_520_964
+    assert len(ps) == 686
+    for k in ("conv_in.weight", "time_embedding.linear_2.bias", "down_blocks.0.attentions.0.norm.weight",
+              "down_blocks.0.attentions.1.proj_in.weight",
+              "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+              "down_blocks.2.attentions.1.transformer_blocks.0.attn2.to_k.weight",
+              "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.bias",
+              "up_blocks.1.attentions.2.transformer_blocks.0.ff.net.2.weight",
+              "up_blocks.3.attentions.2.proj_out.bias", "up_blocks.2.upsamplers.0.conv.weight",
+              "down_blocks.3.resnets.1.conv2.weight", "conv_out.bias"):
+        assert k in ps, k
+    assert "down_blocks.3.attentions.0.norm.weight" not in ps and "up_blocks.0.attentions.0.norm.weight" not in ps
+    assert "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.bias" not in ps
+    assert ps["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_v.weight"].shape == (320, 768)
+    assert ps["mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight"].shape == (10240, 1280)
+    assert ps["up_blocks.1.resnets.0.conv1.weight"].shape == (1280, 2560, 3, 3)
+    assert ps["up_blocks.3.resnets.2.conv1.weight"].shape == (320, 640, 3, 3)
+
+
+def test_sd_tiny_forward_backward():
+    from oracle.unet_cond import OracleUNet2DCondition, UNetCondConfig
+    torch.manual_seed(0)
+    m = OracleUNet2DCondition(UNetCondConfig.tiny())
+    x = torch.randn(2, 4, 16, 16)
+    y = m(x, torch.tensor([3, 999]), torch.randn(2, 7, 64))[0]
+    assert y.shape == x.shape
+    y.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
