@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FWD_GFLOP_PER_SAMPLE = 498.35          # SURVEY.md §8d (2*MAC: conv + linear + attention matmuls + GN)
+SD_FWD_GFLOP_PER_SAMPLE = 803.9        # SD v1 UNet at 64x64 latents, 77 text tokens
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -33,7 +34,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE: 16)")
-    ap.add_argument("--config", default="celebahq256", choices=["celebahq256", "small"])
+    ap.add_argument("--config", default="celebahq256", choices=["celebahq256", "small", "sd15"],
+                    help="celebahq256 = the BASELINE metric's workload (configs[1]); sd15 = BASELINE configs[4] "
+                         "(SD v1.5 UNet, 64x64 latents, text conditioning) as a secondary measurement")
     ap.add_argument("--loss-fn", default="importance_sampling_with_mixture")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("SISS_GRAPH", "1")),
                     help="replay the step from a captured hipGraph (1) or launch eagerly (0)")
@@ -45,13 +48,14 @@ def parse():
 CPU_SAMPLE_BATCH = 2
 
 
-def cpu_baseline(cfg_kw, seed):
+def cpu_baseline(cfg_kw, seed, sd=False):
     """The oracle (CPU restatement pinned by the reference's golden vectors) timed on the host cores
     on a bounded sample: ONE optimizer step at batch CPU_SAMPLE_BATCH (1/8 of the GPU workload), fp32."""
     from oracle import schedule as S
     from oracle.loss import OracleDeletionLoss
     from oracle.step import unlearning_step
     from oracle.unet import OracleUNet2D, UNetConfig
+    from oracle.unet_cond import OracleUNet2DCondition, UNetCondConfig
     # usable cores: the affinity mask (a container may expose far fewer than os.cpu_count()), capped at
     # 32 threads -- beyond that torch's CPU convolutions stop scaling and oversubscription can stall.
     try:
@@ -66,7 +70,7 @@ def cpu_baseline(cfg_kw, seed):
         pass
     cores = max(1, min(avail, 32))
     torch.set_num_threads(cores)
-    net = OracleUNet2D(UNetConfig(**cfg_kw))
+    net = OracleUNet2DCondition(UNetCondConfig(**cfg_kw)) if sd else OracleUNet2D(UNetConfig(**cfg_kw))
     g = torch.Generator().manual_seed(seed)
     hw = cfg_kw["sample_size"]
     c = cfg_kw["in_channels"]
@@ -76,13 +80,19 @@ def cpu_baseline(cfg_kw, seed):
     noise = torch.randn(nb, c, hw, hw, generator=g)
     t = torch.full((nb,), 999, dtype=torch.long)
     u = torch.rand(nb, generator=g)
-    ac = S.alphas_cumprod()
+    cond = None
+    if sd:
+        ac = S.alphas_cumprod(beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012)
+        x0, a0 = 0.18215 * x0, 0.18215 * a0
+        cond = {"encoder_hidden_states": torch.randn(1, 77, cfg_kw["cross_attention_dim"], generator=g).repeat(nb, 1, 1)}
+    else:
+        ac = S.alphas_cumprod()
     opt = torch.optim.AdamW(net.parameters(), lr=5e-6, betas=(0.95, 0.999), weight_decay=1e-6)
     L = OracleDeletionLoss(*S.gamma_sigma(ac))
     t0 = time.perf_counter()
     unlearning_step(net, opt, L, "importance_sampling_with_mixture", ac,
                     [dict(x0=x0, a0=a0, noise=noise, t=t, u=u)], train_batch_size=nb, scaling_norm=500.0,
-                    loss_params={"lambd": 0.5})
+                    loss_params={"lambd": 0.5}, conditioning=cond)
     dt = time.perf_counter() - t0
     return dt, cores
 
@@ -130,28 +140,46 @@ def main():
     from siss_amd.step import SISSStepper
     from siss_amd.unet import UNetEngine
 
+    sd = a.config == "sd15"
     if a.config == "celebahq256":
         cfg = UNet2DConfig.celebahq256()
+    elif sd:
+        from siss_amd.config import UNet2DConditionConfig
+        from siss_amd.unet_cond import UNetCondEngine
+        cfg = UNet2DConditionConfig.sd15()
     else:
         cfg = UNet2DConfig(sample_size=64, block_out_channels=(128, 128, 256),
                            down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D"),
                            up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D"))
     B, hw, cin = a.batch, cfg.sample_size, cfg.in_channels
-    eng = UNetEngine(cfg, dev)
+    eng = UNetCondEngine(cfg, dev) if sd else UNetEngine(cfg, dev)
     eng.init_random(seed=42)                       # same weights on every rank (config/delete_celeb.yaml:4)
-    ac = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, 1000, dtype=torch.float32), 0)
-    st = SISSStepper(eng, ac, lr=5e-6, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,   # delete_celeb.yaml:127-133
-                     scaling_norm=500.0, lambd=0.5, train_batch_size=B, grad_accum=1, loss_fn=a.loss_fn,
-                     process_group=pg, mixed_precision="bf16")
     g = torch.Generator(device=dev).manual_seed(42 + rank)      # per-rank shard of the synthetic stream
-    x0 = (torch.rand(B, cin, hw, hw, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
-    a0 = (torch.rand(1, cin, hw, hw, generator=g, device=dev) * 2 - 1).repeat(B, 1, 1, 1).to(torch.bfloat16)
+    cond = None
+    if sd:
+        # delete_sd.yaml: scaled-linear betas, AdamW lr 1e-5 / (0.9, 0.999) / wd 1e-2, scaling_norm 750; latents carry
+        # the VAE scaling factor 0.18215 (delete_sd.py:883,888); ONE prompt embedding repeated (delete_sd.py:941-944)
+        ac = torch.cumprod(1.0 - torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2, 0)
+        st = SISSStepper(eng, ac, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, scaling_norm=750.0,
+                         lambd=0.5, train_batch_size=B, grad_accum=1, loss_fn=a.loss_fn, process_group=pg,
+                         mixed_precision="bf16")
+        x0 = (0.18215 * torch.randn(B, cin, hw, hw, generator=g, device=dev)).to(torch.bfloat16)
+        a0 = (0.18215 * torch.randn(1, cin, hw, hw, generator=g, device=dev)).repeat(B, 1, 1, 1).to(torch.bfloat16)
+        cond = {"encoder_hidden_states": torch.randn(1, 77, cfg.cross_attention_dim, generator=g, device=dev)
+                .repeat(B, 1, 1).to(torch.bfloat16)}
+    else:
+        ac = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, 1000, dtype=torch.float32), 0)
+        st = SISSStepper(eng, ac, lr=5e-6, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,   # delete_celeb.yaml:127-133
+                         scaling_norm=500.0, lambd=0.5, train_batch_size=B, grad_accum=1, loss_fn=a.loss_fn,
+                         process_group=pg, mixed_precision="bf16")
+        x0 = (torch.rand(B, cin, hw, hw, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+        a0 = (torch.rand(1, cin, hw, hw, generator=g, device=dev) * 2 - 1).repeat(B, 1, 1, 1).to(torch.bfloat16)
     noise = torch.randn(B, cin, hw, hw, generator=g, device=dev).to(torch.bfloat16)
     t = torch.full((B,), 999, dtype=torch.long, device=dev)
     u = torch.rand(B, generator=g, device=dev)
 
     def one_step():
-        st.step(x0, a0, noise, t, u)
+        st.step(x0, a0, noise, t, u, cond)
 
     def sync():
         if world > 1:
@@ -212,7 +240,7 @@ def main():
         n, tms, work = kern[dom]
         ach = work / (tms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(dom),
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic(dom) if a.config == "celebahq256" else None,
                 "launches_per_step": n // ksteps, "avg_launch_us": round(tms / n * 1e3, 2),
                 "share_of_step_kernel_time": round(tms / tot_ms, 3)}
         other = "siss_gemm_tn" if dom == "siss_gemm_nt" else "siss_gemm_nt"
@@ -226,8 +254,9 @@ def main():
         cfg_kw = {k: getattr(cfg, k) for k in ("sample_size", "in_channels", "out_channels", "block_out_channels",
                                                 "down_block_types", "up_block_types", "layers_per_block",
                                                 "attention_head_dim", "norm_num_groups", "norm_eps",
-                                                "downsample_padding", "flip_sin_to_cos", "freq_shift")}
-        cdt, cores = cpu_baseline(cfg_kw, 42)
+                                                "downsample_padding", "flip_sin_to_cos", "freq_shift")
+                  + (("cross_attention_dim",) if sd else ())}
+        cdt, cores = cpu_baseline(cfg_kw, 42, sd)
         cpu = {"value": round(CPU_SAMPLE_BATCH / cdt, 5), "unit": "samples/sec", "cores": cores, "kind": "port",
                "sample": f"1 optimizer step at batch {CPU_SAMPLE_BATCH} ({CPU_SAMPLE_BATCH}/{B} of the per-GPU "
                          f"batch) of the same UNet/resolution, fp32 torch CPU oracle, {cdt:.1f} s",
@@ -235,17 +264,23 @@ def main():
 
     if rank == 0:
         steps_per_sec = 1e3 / ms
-        step_tflop = 5 * FWD_GFLOP_PER_SAMPLE * B / 1e3 if a.config == "celebahq256" else None
+        step_tflop = 5 * FWD_GFLOP_PER_SAMPLE * B / 1e3 if a.config == "celebahq256" else (
+            5 * SD_FWD_GFLOP_PER_SAMPLE * B / 1e3 if sd else None)
+        workload = {"celebahq256": "delete_celeb.yaml: CelebA-HQ 256x256 DDPM UNet (113.7M params), SISS lambd=0.5, "
+                                   "t=999, bf16, bs=%d/GPU, GA=1, scaling_norm=500, AdamW lr 5e-6" % B,
+                    "sd15": "delete_sd.yaml: Stable Diffusion v1.5 UNet (859.5M params), 64x64x4 latents + 77x768 text "
+                            "embedding, SISS lambd=0.5, t=999, bf16, bs=%d/GPU, GA=1, scaling_norm=750, AdamW lr 1e-5, "
+                            "no gradient checkpointing (activations kept in HBM)" % B,
+                    "small": "small 64x64 dev config"}[a.config]
         out = {
-            "metric": "unlearning samples/sec (= unlearning-steps/sec x batch x gpus), CelebA-HQ-256 DDPM SISS",
+            "metric": "unlearning samples/sec (= unlearning-steps/sec x batch x gpus), "
+                      + ("SD-v1.5 UNet SISS (secondary; BASELINE metric is the CelebA-HQ line)" if sd else "CelebA-HQ-256 DDPM SISS"),
             "value": round(steps_per_sec * B * world, 3), "unit": "samples/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "steps_per_sec": round(steps_per_sec, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "delete_celeb.yaml: CelebA-HQ 256x256 DDPM UNet (113.7M params), SISS lambd=0.5, "
-                                   "t=999, bf16, bs=%d/GPU, GA=1, scaling_norm=500, AdamW lr 5e-6" % B
-                       if a.config == "celebahq256" else "small 64x64 dev config",
+            "config": {"workload": workload,
                        "loss_fn": a.loss_fn, "global_batch": B * world, "parallelism": f"dp{world}",
                        "hipgraph": bool(use_graph)},
             "step_tflop_algorithmic": step_tflop,

@@ -101,10 +101,22 @@ def test_conv_out_fprop_any_channels(dev):
 
 
 # ---------------------------------------------------------------- SD-shaped UNet, end to end
-def _cfgs():
+CASES = {
+    # one cross-attention level (head_dim 32, padded to 64 inside) + one plain level; mid attention head_dim 64
+    "tiny": dict(ch=(64, 128), heads=2, cross_dim=64, sample_size=16, layers=2),
+    # SD v1 widths of the first two levels: head_dim 40 / 80 (padded to 64 / 128), 10 channels per group,
+    # 768-wide text embedding, 960- and 1280-channel concats
+    "sd_widths": dict(ch=(320, 640), heads=8, cross_dim=768, sample_size=16, layers=1),
+}
+
+
+def _cfgs(case):
     from siss_amd.config import UNet2DConditionConfig
     from oracle.unet_cond import UNetCondConfig
-    oc = UNetCondConfig.tiny(ch=(64, 128), heads=2, cross_dim=64, sample_size=16, in_channels=4)
+    c = CASES[case]
+    oc = UNetCondConfig.tiny(ch=c["ch"], heads=c["heads"], cross_dim=c["cross_dim"], sample_size=c["sample_size"],
+                             in_channels=4)
+    oc.layers_per_block = c["layers"]
     kw = {k: getattr(oc, k) for k in ("sample_size", "in_channels", "out_channels", "block_out_channels",
                                       "down_block_types", "up_block_types", "layers_per_block", "attention_head_dim",
                                       "cross_attention_dim", "norm_num_groups", "norm_eps", "downsample_padding",
@@ -112,11 +124,11 @@ def _cfgs():
     return UNet2DConditionConfig(**kw), oc
 
 
-@pytest.fixture(scope="module")
-def setup(dev):
+@pytest.fixture(scope="module", params=list(CASES))
+def setup(dev, request):
     from siss_amd.unet_cond import UNetCondEngine
     from oracle.unet_cond import OracleUNet2DCondition
-    hc, oc = _cfgs()
+    hc, oc = _cfgs(request.param)
     eng = UNetCondEngine(hc, "cuda:0")
     sd = eng.init_random(seed=1)
     net = OracleUNet2DCondition(oc)
@@ -135,9 +147,10 @@ def test_param_names_and_roundtrip(setup):
 def test_forward_matches_oracle(setup):
     eng, net, _ = setup
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 4, 16, 16, generator=g)
+    hw, X = eng.cfg.sample_size, eng.cfg.cross_attention_dim
+    x = torch.randn(2, 4, hw, hw, generator=g)
     t = torch.tensor([999, 40])
-    ctx = torch.randn(2, 13, 64, generator=g)              # ragged text length (padded to 64 keys inside)
+    ctx = torch.randn(2, 13, X, generator=g)               # ragged text length (padded to 64 keys inside)
     with torch.no_grad():
         ref = net(x, t, ctx)[0]
     got = eng.forward(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).cpu()
@@ -149,11 +162,12 @@ def test_dual_backward_matches_oracle(setup):
     eng, net, _ = setup
     g = torch.Generator().manual_seed(1)
     B = 2
-    x = torch.randn(B, 4, 16, 16, generator=g)
+    hw, X = eng.cfg.sample_size, eng.cfg.cross_attention_dim
+    x = torch.randn(B, 4, hw, hw, generator=g)
     t = torch.tensor([999, 300])
-    ctx = torch.randn(B, 77, 64, generator=g)
-    cx = torch.randn(B, 4, 16, 16, generator=g)
-    ca = torch.randn(B, 4, 16, 16, generator=g)
+    ctx = torch.randn(B, 77, X, generator=g)
+    cx = torch.randn(B, 4, hw, hw, generator=g)
+    ca = torch.randn(B, 4, hw, hw, generator=g)
     refs = []
     for c in (cx, ca):
         net.zero_grad()
@@ -192,13 +206,14 @@ def test_siss_step_with_text_conditioning_matches_oracle(setup):
     opt = torch.optim.AdamW(net.parameters(), **kw)
     st = SISSStepper(eng, ac, scaling_norm=7.5, lambd=0.5, train_batch_size=2, mixed_precision=None, **kw)
     g = torch.Generator().manual_seed(7)
+    hw, X = eng.cfg.sample_size, eng.cfg.cross_attention_dim
     for step in range(2):
-        x0 = torch.randn(2, 4, 16, 16, generator=g)
-        a0 = torch.randn(1, 4, 16, 16, generator=g).repeat(2, 1, 1, 1)
-        noise = torch.randn(2, 4, 16, 16, generator=g)
+        x0 = 0.5 * torch.randn(2, 4, hw, hw, generator=g)
+        a0 = (0.5 * torch.randn(1, 4, hw, hw, generator=g)).repeat(2, 1, 1, 1)
+        noise = torch.randn(2, 4, hw, hw, generator=g)
         t = torch.full((2,), 999, dtype=torch.long)
         u = torch.tensor([0.9, 0.2])
-        ctx = torch.randn(1, 77, 64, generator=g).repeat(2, 1, 1)          # one prompt repeated (delete_sd.py:941-944)
+        ctx = torch.randn(1, 77, X, generator=g).repeat(2, 1, 1)           # one prompt repeated (delete_sd.py:941-944)
         ref, *_ = unlearning_step(net, opt, L, "importance_sampling_with_mixture", ac,
                                   [dict(x0=x0, a0=a0, noise=noise, t=t, u=u)], train_batch_size=2, scaling_norm=7.5,
                                   loss_params={"lambd": 0.5}, conditioning={"encoder_hidden_states": ctx})
