@@ -64,17 +64,34 @@ class CelebAHQ(torch.utils.data.Dataset):
 
 
 class SyntheticImages(torch.utils.data.Dataset):
-    """x ~ U[-1,1] images of a fixed shape (ToTensor+Normalize(0.5,0.5) range); deterministic per index."""
+    """x ~ U[-1,1] images of a fixed shape (ToTensor+Normalize(0.5,0.5) range), or scale * N(0,1) "latents"
+    (normal=True: the SD task's stand-in for VAE latents); deterministic per index."""
 
-    def __init__(self, n, shape, seed=0):
-        self.n, self.shape, self.seed = n, tuple(shape), seed
+    def __init__(self, n, shape, seed=0, scale=1.0, normal=False):
+        self.n, self.shape, self.seed, self.scale, self.normal = n, tuple(shape), seed, float(scale), normal
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1_000_003 + int(i))
-        return torch.rand(self.shape, generator=g) * 2 - 1
+        if self.normal:
+            return self.scale * torch.randn(self.shape, generator=g)
+        return self.scale * (torch.rand(self.shape, generator=g) * 2 - 1)
+
+
+class TensorImages(torch.utils.data.Dataset):
+    """A stack [N, C, H, W] already in memory (pre-encoded SD latents)."""
+
+    def __init__(self, t):
+        assert t.dim() == 4
+        self.t = t.float()
+
+    def __len__(self):
+        return self.t.shape[0]
+
+    def __getitem__(self, i):
+        return self.t[i]
 
 
 class InfiniteSampler(torch.utils.data.Sampler):

@@ -72,7 +72,12 @@ def _wrap(v, root):
         return Cfg(v, root)
     if isinstance(v, (list, tuple)):
         return CfgList(v, root)
+    if isinstance(v, str) and _SCI_FLOAT.match(v):
+        return float(v)           # "1e-5": PyYAML (YAML 1.1) reads a string, OmegaConf (YAML 1.2 floats) a float
     return v
+
+
+_SCI_FLOAT = re.compile(r"^[+-]?\d+(\.\d*)?[eE][+-]?\d+$")
 
 
 def _plain(v):

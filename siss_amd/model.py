@@ -13,17 +13,17 @@ import os
 
 import torch
 
-from .config import UNet2DConfig
+from .config import UNet2DConditionConfig, UNet2DConfig
 from .unet import UNetEngine
 
 
 class _UNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model, sample, timesteps):
+    def forward(ctx, anchor, model, sample, timesteps, *cond):
         ctx.model = model
         ctx.token = model._fwd_token = object()
-        ctx.inputs = (sample.contiguous(), timesteps)
-        return model.engine.forward(ctx.inputs[0], timesteps).clone()
+        ctx.inputs = (sample.contiguous(), timesteps, *cond)
+        return model.engine.forward(*ctx.inputs).clone()
 
     @staticmethod
     def backward(ctx, gout):
@@ -37,15 +37,26 @@ class _UNetFn(torch.autograd.Function):
         eng.ps.grads[0].zero_()
         eng.backward(gout.contiguous().float(), nsets=1)
         m._accumulate_param_grads()
-        return None, None, None, None
+        return (None,) * len(ctx.needs_input_grad)
 
 
 class UNet2DModel:
+    config_cls = UNet2DConfig
+    class_name = "UNet2DModel"
+
+    @staticmethod
+    def _make_engine(config, device):
+        return UNetEngine(config, device)
+
+    def _cond_args(self, kwargs):
+        """Positional conditioning tensors of the engine's forward, from the reference's **conditioning."""
+        return ()
+
     def __init__(self, config=None, device="cuda", **kwargs):
         if config is None:
-            config = UNet2DConfig.from_dict(kwargs) if kwargs else UNet2DConfig.celebahq256()
+            config = self.config_cls.from_dict(kwargs) if kwargs else self.config_cls()
         self.config = config
-        self.engine = UNetEngine(config, device)
+        self.engine = self._make_engine(config, device)
         self.device = self.engine.device
         self.dtype = torch.float32
         self.training = True
@@ -86,7 +97,10 @@ class UNet2DModel:
             else:
                 p.grad += g
 
-    def __call__(self, sample, timestep, return_dict=False, **unused):
+    def __call__(self, sample, timestep, *args, return_dict=False, **kwargs):
+        if args:                                  # diffusers' positional encoder_hidden_states
+            kwargs.setdefault("encoder_hidden_states", args[0])
+        cond = self._cond_args(kwargs)
         t = timestep
         if not torch.is_tensor(t):
             t = torch.tensor([t], dtype=torch.long)
@@ -97,9 +111,9 @@ class UNet2DModel:
         if sample.dtype not in (torch.float32, torch.bfloat16):
             sample = sample.float()
         if torch.is_grad_enabled():
-            out = _UNetFn.apply(self._anchor, self, sample, t)
+            out = _UNetFn.apply(self._anchor, self, sample, t, *cond)
         else:
-            out = self.engine.forward(sample.contiguous(), t).clone()
+            out = self.engine.forward(sample.contiguous(), t, *cond).clone()
         if return_dict:
             return type("UNet2DOutput", (), {"sample": out})()
         return (out,)
@@ -117,7 +131,7 @@ class UNet2DModel:
         d = os.path.join(path, subfolder) if subfolder else path
         if not os.path.exists(os.path.join(d, "config.json")) and os.path.exists(os.path.join(path, "unet")):
             d = os.path.join(path, "unet")
-        m = cls(UNet2DConfig.from_json(os.path.join(d, "config.json")), device=device)
+        m = cls(cls.config_cls.from_json(os.path.join(d, "config.json")), device=device)
         m.load_state_dict(load_file(os.path.join(d, "diffusion_pytorch_model.safetensors")))
         return m
 
@@ -125,8 +139,26 @@ class UNet2DModel:
         from safetensors.torch import save_file
         os.makedirs(d, exist_ok=True)
         cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self.config).items()}
-        cfg["_class_name"] = "UNet2DModel"
+        cfg["_class_name"] = self.class_name
         with open(os.path.join(d, "config.json"), "w") as f:
             json.dump(cfg, f, indent=2)
         save_file({k: v.contiguous() for k, v in self.state_dict().items()},
                   os.path.join(d, "diffusion_pytorch_model.safetensors"))
+
+
+class UNet2DConditionModel(UNet2DModel):
+    """Stable-Diffusion UNet surface: ``unet(x, t, encoder_hidden_states=..., return_dict=False)[0]``
+    (delete_sd.py:458-462 load, :977-985 -> losses/ddpm_deletion_loss.py:24 call)."""
+    config_cls = UNet2DConditionConfig
+    class_name = "UNet2DConditionModel"
+
+    @staticmethod
+    def _make_engine(config, device):
+        from .unet_cond import UNetCondEngine
+        return UNetCondEngine(config, device)
+
+    def _cond_args(self, kwargs):
+        e = kwargs.get("encoder_hidden_states")
+        if e is None:
+            raise TypeError("UNet2DConditionModel needs encoder_hidden_states")
+        return (e.to(self.device),)

@@ -1,5 +1,5 @@
 """Task classes behind the reference's entry points (main.py:9-35): ``Task.run()``,
-``delete_celeb.DeleteCeleb(cfg)``, ``delete_tshirt.DeleteTShirt(cfg)``.
+``delete_celeb.DeleteCeleb(cfg)``, ``delete_tshirt.DeleteTShirt(cfg)``, ``delete_sd.DeleteSD(cfg)``.
 
 The loop is the hot path of delete_celeb.py:557-773 / delete_tshirt.py:501-717 driven through
 ``SISSStepper`` (fused kernels, one dual-cotangent backward, one collective per optimizer step).
@@ -14,7 +14,7 @@ from abc import ABC, abstractmethod
 import torch
 
 from . import hydra_lite
-from .config import UNet2DConfig
+from .config import UNet2DConditionConfig, UNet2DConfig
 from .data import InfiniteSampler, RepeatedSampler, SyntheticImages, batches
 from .scheduler import DDPMScheduler
 from .step import SISSStepper
@@ -81,21 +81,35 @@ class _DeleteBase(Task):
             print(f"[siss_amd] dataset unavailable ({type(e).__name__}: {e}); using synthetic images")
             return SyntheticImages(4096, shape, seed=1), SyntheticImages(1, shape, seed=2)
 
+    def optimizer_args(self):
+        """(lr, betas, eps, weight_decay) of the AdamW the reference instantiates from cfg.optimizer
+        (delete_celeb.py:232)."""
+        opt = hydra_lite.instantiate(self.cfg.optimizer)
+        return opt.lr, opt.betas, opt.eps, opt.weight_decay
+
+    def conditioning(self, B, device):
+        """The dict the reference splats into the UNet call (delete_celeb.py:622: {})."""
+        return None
+
+    def seed(self):
+        return int(self.cfg.random_seed)
+
     # -- the loop ------------------------------------------------------------------------------
     def run(self):
         cfg = self.cfg
         world, rank, local, pg = _dist()
         device = torch.device("cuda", local)
         torch.cuda.set_device(device)
-        torch.manual_seed(int(cfg.random_seed) + rank)
+        seed = self.seed()
+        torch.manual_seed(seed + rank)
         unet = self.load_unet(device)
         eng = unet.engine
         sched = self.load_scheduler()
-        opt = hydra_lite.instantiate(cfg.optimizer)
+        lr, betas, eps, wd = self.optimizer_args()
         d = cfg.deletion
         B, ga = int(cfg.train_batch_size), int(cfg.gradient_accumulation_steps)
         stepper = SISSStepper(
-            eng, sched.alphas_cumprod, lr=opt.lr, betas=opt.betas, eps=opt.eps, weight_decay=opt.weight_decay,
+            eng, sched.alphas_cumprod, lr=lr, betas=betas, eps=eps, weight_decay=wd,
             scaling_norm=float(d.scaling_norm) if d.loss_fn != "erasediff" else None,
             eta=float(d.eta) if d.loss_fn == "erasediff" else None,
             lambd=float((d.loss_params or {}).get("lambd", 0.5)), train_batch_size=B, grad_accum=ga,
@@ -106,9 +120,10 @@ class _DeleteBase(Task):
         it_all = batches(ds_all, InfiniteSampler(ds_all, rank=rank, num_replicas=world), B)
         it_del = batches(ds_del, self.deletion_sampler(ds_del, B), B)
         n_steps = int(cfg.training_steps) * max(1, len(d.get("img_name") or [1]))
+        cond = self.conditioning(B, device)
         os.makedirs(cfg.output_dir, exist_ok=True)
         log = open(os.path.join(cfg.output_dir, f"train_log_rank{rank}.jsonl"), "a")
-        g = torch.Generator(device=device).manual_seed(int(cfg.random_seed) + rank)
+        g = torch.Generator(device=device).manual_seed(seed + rank)
         T = sched.config.num_train_timesteps
         t0 = time.perf_counter()
         for step in range(n_steps):
@@ -118,7 +133,7 @@ class _DeleteBase(Task):
                 noise = torch.randn(x0.shape, device=device, generator=g)           # SAME noise for both batches
                 t = torch.randint(self.timestep_low, T, (B,), device=device, generator=g)
                 u = torch.rand(B, device=device, generator=g)
-                stepper.micro_step(x0, a0, noise, t, u)
+                stepper.micro_step(x0, a0, noise, t, u, cond)
             st = stepper.stats()
             st["global_step"] = step + 1
             st["elapsed_s"] = time.perf_counter() - t0
@@ -145,3 +160,59 @@ class DeleteTShirt(_DeleteBase):
     timestep_low = 0
     inf_guard = True
     default_unet = staticmethod(UNet2DConfig.mnist_tshirt)
+
+
+class DeleteSD(_DeleteBase):
+    """config/delete_sd.yaml -- Stable Diffusion: the same loop on VAE latents with text conditioning
+    (delete_sd.py:864-1127).  On the path: the SISS step through ``UNet2DConditionModel``.  Not on it (SURVEY.md §8f
+    rank 4, not built): the frozen VAE encoder and CLIP text encoder of delete_sd.py:879-888,:941-944 -- latents and the
+    prompt embedding are read from ``.pt`` files when configured (``latents_all`` / ``latents_deletion`` [N,4,h,w],
+    already multiplied by vae.config.scaling_factor; ``validation_prompts[0]`` ending in .pt [77,768] or [1,77,768],
+    the reference's own ``using_augmented_prompt`` branch, delete_sd.py:938) and synthetic otherwise."""
+    default_unet = staticmethod(UNet2DConditionConfig.sd15)
+    VAE_SCALE = 0.18215            # vae.config.scaling_factor (delete_sd.py:883,888)
+
+    def seed(self):
+        return int(self.cfg.get("seed", 42))                   # config/delete_sd.yaml:80
+
+    def load_unet(self, device):
+        from .model import UNet2DConditionModel
+        cfg = self.cfg
+        path = cfg.get("pretrained_model_name_or_path")
+        if path and os.path.isdir(os.path.join(str(path), "unet")):
+            return UNet2DConditionModel.from_pretrained(path, subfolder="unet", device=device)   # delete_sd.py:458-462
+        ucfg = {k: v for k, v in (cfg.get("unet") or {}).items() if not k.startswith("_")}
+        m = UNet2DConditionModel(UNet2DConditionConfig.from_dict(ucfg) if ucfg else self.default_unet(), device=device)
+        m.engine.init_random(seed=self.seed())
+        print(f"[siss_amd] {path!r}/unet not found on disk: random-init weights of the same architecture")
+        return m
+
+    def load_scheduler(self):
+        # the SD v1 scheduler_config.json: scaled-linear betas 0.00085 -> 0.012 (delete_sd.py:412)
+        return DDPMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+
+    def optimizer_args(self):
+        c = self.cfg                                            # delete_sd.py:567-573
+        return (float(c.learning_rate), (float(c.adam_beta1), float(c.adam_beta2)), float(c.adam_epsilon),
+                float(c.adam_weight_decay))
+
+    def datasets(self, shape):
+        cfg = self.cfg
+        la, ld = cfg.get("latents_all"), cfg.get("latents_deletion")
+        if la and ld and os.path.exists(str(la)) and os.path.exists(str(ld)):
+            from .data import TensorImages
+            return TensorImages(torch.load(la)), TensorImages(torch.load(ld))
+        print("[siss_amd] no latent files configured (the VAE front end is outside the path): synthetic latents")
+        return (SyntheticImages(4096, shape, seed=1, scale=self.VAE_SCALE, normal=True),
+                SyntheticImages(1, shape, seed=2, scale=self.VAE_SCALE, normal=True))
+
+    def conditioning(self, B, device):
+        cfg = self.cfg
+        vp = cfg.get("validation_prompts")
+        X = int((cfg.get("unet") or {}).get("cross_attention_dim", 768))
+        if vp and str(vp[0]).endswith(".pt") and os.path.exists(str(vp[0])):
+            e = torch.load(str(vp[0])).to(device).float()
+            e = e.reshape(-1, e.shape[-2], e.shape[-1])[:1]
+        else:
+            e = torch.randn(1, 77, X, generator=torch.Generator().manual_seed(self.seed())).to(device)
+        return {"encoder_hidden_states": e.repeat(B, 1, 1)}     # one prompt for the whole batch (delete_sd.py:941-944)

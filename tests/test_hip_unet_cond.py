@@ -260,3 +260,80 @@ def test_sd15_full_size_step_runs():
     for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm"):
         assert s[k] == s[k] and abs(s[k]) < float("inf") and s[k] > 0, (k, s[k])
     assert abs(s["scaling_factor"] * s["norm_loss_a"] - 750.0) < 1.0       # norm fixing: ||s g_a|| = scaling_norm
+
+
+# ---------------------------------------------------------------- drop-in surface for delete_sd.py
+@pytest.mark.parametrize("loss_fn", ["importance_sampling_with_mixture", "double_forward_with_neg_del"])
+def test_reference_style_sd_loop_on_hip_surface(dev, loss_fn):
+    """The reference loop body (two backward calls with retain_graph, per-parameter grads, torch AdamW;
+    oracle/step.py = delete_sd.py:977-1127) against siss_amd.model.UNet2DConditionModel + DDPMDeletionLoss,
+    conditioning passed by keyword as delete_sd.py:977-985 does."""
+    from siss_amd.loss import DDPMDeletionLoss
+    from siss_amd.model import UNet2DConditionModel
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    from oracle.unet_cond import OracleUNet2DCondition
+    hc, oc = _cfgs("tiny")
+    hip = UNet2DConditionModel(hc, device=dev)
+    sd = hip.engine.init_random(seed=5)
+    cpu = OracleUNet2DCondition(oc)
+    cpu.load_state_dict(sd)
+    ac = S.alphas_cumprod(beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012)
+    gam, sig = S.gamma_sigma(ac)
+    g = torch.Generator().manual_seed(3)
+    B = 4
+    x0 = 0.5 * torch.randn(B, 4, 16, 16, generator=g)
+    a0 = (0.5 * torch.randn(1, 4, 16, 16, generator=g)).repeat(B, 1, 1, 1)
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    t = torch.full((B,), 999, dtype=torch.long)
+    ctx = torch.randn(1, 77, 64, generator=g).repeat(B, 1, 1)
+    lp = {"lambd": 0.5} if loss_fn == "importance_sampling_with_mixture" else {}
+    okw = dict(train_batch_size=B, scaling_norm=7.5, loss_params=lp, pass_u=False)
+    akw = dict(lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-2)
+    torch.manual_seed(80)
+    ref, *_ = unlearning_step(cpu, torch.optim.AdamW(cpu.parameters(), **akw), OracleDeletionLoss(gam, sig), loss_fn, ac,
+                              [dict(x0=x0, a0=a0, noise=noise, t=t)], conditioning={"encoder_hidden_states": ctx}, **okw)
+    torch.manual_seed(80)
+    mb = dict(x0=x0.to(dev), a0=a0.to(dev), noise=noise.to(dev), t=t.to(dev))
+    got, *_ = unlearning_step(hip, torch.optim.AdamW(hip.parameters(), **akw), DDPMDeletionLoss(gam.to(dev), sig.to(dev)),
+                              loss_fn, ac.to(dev), [mb], conditioning={"encoder_hidden_states": ctx.to(dev)}, **okw)
+    for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm", "weighted_loss_x", "weighted_loss_a"):
+        r, v = getattr(ref, k), getattr(got, k)
+        assert abs(v - r) <= 5e-2 * abs(r), (k, v, r)
+
+
+def test_delete_sd_task_runs_from_config(dev, tmp_path):
+    """`python main.py --config-name=delete_sd` path: compose config/delete_sd.yaml, instantiate
+    delete_sd.DeleteSD, run two optimizer steps on a small SD-shaped UNet (synthetic latents / prompt embedding),
+    save in the diffusers on-disk format and reload."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from siss_amd import hydra_lite as H
+    from siss_amd.model import UNet2DConditionModel
+    emb = tmp_path / "prompt.pt"
+    torch.save(torch.randn(1, 77, 64), emb)
+    cfg = H.compose("delete_sd", os.path.join(root, "config"),
+                    ["training_steps=2", "train_batch_size=2", "gradient_accumulation_steps=2",
+                     f"output_dir={tmp_path}/out", "pretrained_model_name_or_path=/nonexistent"])
+    cfg.validation_prompts = [str(emb)]
+    cfg.unet = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=[64, 128],
+                    down_block_types=["CrossAttnDownBlock2D", "DownBlock2D"],
+                    up_block_types=["UpBlock2D", "CrossAttnUpBlock2D"], attention_head_dim=2, cross_attention_dim=64)
+    task = H.instantiate(cfg.task, cfg=cfg, _recursive_=False)
+    assert type(task).__name__ == "DeleteSD"
+    task.run()
+    lines = [json.loads(l) for l in open(os.path.join(cfg.output_dir, "train_log_rank0.jsonl"))]
+    assert len(lines) == 2
+    for st in lines:
+        assert abs(st["scaling_factor"] * st["norm_loss_a"] - 750.0) < 1.0
+    m = UNet2DConditionModel.from_pretrained(cfg.output_dir, subfolder="unet", device=dev)
+    assert json.load(open(os.path.join(cfg.output_dir, "unet", "config.json")))["_class_name"] == "UNet2DConditionModel"
+    assert m.config.cross_attention_dim == 64 and len(m.state_dict()) == len(task_specs(m))
+
+
+def task_specs(m):
+    return m.engine.ps.specs

@@ -114,6 +114,35 @@ def test_unet_param_registry_matches_checkpoint_shape():
     assert sum(int(np.prod(sp.ref_shape)) for sp in e.ps.specs.values()) == 113_673_219
 
 
+def test_sd_unet_param_registry_matches_checkpoint_shape():
+    """SD v1.5 UNet registry of the HIP engine: 859,520,964 parameters in 686 tensors, same keys and shapes as the
+    oracle restatement (which is pinned by the public checkpoint's count, tests/test_oracle_unet.py)."""
+    from siss_amd.config import UNet2DConditionConfig
+    from siss_amd.unet import ParamStore
+    from siss_amd.unet_cond import UNetCondEngine
+    from oracle.unet_cond import OracleUNet2DCondition, UNetCondConfig
+    e = UNetCondEngine.__new__(UNetCondEngine)
+    e.cfg, e.ps = UNet2DConditionConfig.sd15(), ParamStore()
+    e._declare_params()
+    assert len(e.ps.specs) == 686
+    assert sum(int(np.prod(sp.ref_shape)) for sp in e.ps.specs.values()) == 859_520_964
+    with torch.device("meta"):
+        ref = OracleUNet2DCondition(UNetCondConfig.sd15())
+    shapes = {n: tuple(p.shape) for n, p in ref.named_parameters()}
+    assert {n: sp.ref_shape for n, sp in e.ps.specs.items()} == shapes
+
+
+def test_delete_sd_config_composes():
+    from siss_amd import hydra_lite as H
+    c = H.compose("delete_sd", os.path.join(ROOT, "config"), ["train_batch_size=4", "mixed_precision=bf16"])
+    assert c.task._target_ == "delete_sd.DeleteSD" and c.deletion.scaling_norm == 750
+    assert c.learning_rate == 1e-5 and c.adam_weight_decay == 1e-2 and c.deletion.loss_params.lambd == 0.5
+    assert c.output_dir == "checkpoints/sd/sylvester_stallone"
+    import delete_sd
+    from siss_amd.tasks import DeleteSD, Task
+    assert delete_sd.DeleteSD is DeleteSD and issubclass(DeleteSD, Task)
+
+
 DP_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
