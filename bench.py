@@ -232,7 +232,7 @@ def main():
         sync()
         prof, lib.PROF = lib.PROF, None
     if not a.no_kernel_timing and rank == 0:
-        for name, s, e, work in prof:
+        for name, s, e, work, _ in prof:
             d = kern.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1; d[1] += s.elapsed_time(e); d[2] += work
         tot_ms = sum(v[1] for v in kern.values())

@@ -30,7 +30,7 @@ struct TNParams {
     float* dbias; float* dbias2;          // optional: column sums of Y per set (bias gradients)
     long ldy, ldx, set_stride;
     long x_set_rows;
-    int N, C, npanels, nsets, nsplits;
+    int N, C, npanels, nsets, nsplits, rmw;
     int rows_per_set, row_begin, row_end, rows_per_split;
     int shift[kMaxPanels];
     int coff[kMaxPanels];
@@ -285,6 +285,35 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
         float* out = p.dW + (long)set * p.set_stride + (long)(pn + t) * p.N * p.C;
+        if (p.rmw) {
+            // one split: this block OWNS the tile -- plain read-add-write (deterministic; float atomics execute at
+            // the memory side at ~1.3 TB/s chip-wide and dominate the small layers).  All loads of a tap are issued
+            // before the first store (the compiler cannot prove the addresses distinct and would serialise them).
+            float old[4][CT][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int c = c0 + wc * CT * 16 + j * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                        old[i][j][r] = (n < p.N && c < p.C) ? out[(long)n * p.C + c] : 0.f;
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int c = c0 + wc * CT * 16 + j * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                        if (n < p.N && c < p.C) out[(long)n * p.C + c] = old[i][j][r] + acc[t][i][j][r];
+                    }
+                }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -321,12 +350,14 @@ extern "C" {
 // dW must be zeroed (or hold the running sum for gradient accumulation) before the call.
 // dbias / dbias2 (optional): dbias[set*set_stride + n] += sum over the set's rows of Y[r][n].
 // Rows [row_begin, row_end) of every set are reduced; shifts/coffs are HOST arrays.
+// nsplits <= 0: choose the kernel variant and the split count here (cost model below); when that lands on one split
+// the block that owns a tile read-add-writes it with plain accesses instead of atomics.
 int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
                  int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
                  long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
                  float* dbias, float* dbias2, void* stream) {
     SISS_CHECK_ARG(Y && X && dW && shifts && coffs && zero_page);
-    SISS_CHECK_ARG(N > 0 && C > 0 && npanels >= 1 && npanels <= kMaxPanels && nsets >= 1 && nsplits >= 1);
+    SISS_CHECK_ARG(N > 0 && C > 0 && npanels >= 1 && npanels <= kMaxPanels && nsets >= 1);
     SISS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && C % 8 == 0);   // N may be ragged (masked at the store)
     SISS_CHECK_ARG(((uintptr_t)Y | (uintptr_t)X | (uintptr_t)zero_page) % 16 == 0 && (uintptr_t)dW % 4 == 0);
     SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set);
@@ -334,11 +365,8 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
     p.Y = (const bf16_t*)Y; p.X = (const bf16_t*)X; p.dW = dW; p.zero_page = (const bf16_t*)zero_page;
     p.dbias = dbias; p.dbias2 = dbias ? dbias2 : nullptr;
     p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.x_set_rows = x_set_rows;
-    p.N = N; p.C = C; p.npanels = npanels; p.nsets = nsets; p.nsplits = nsplits;
+    p.N = N; p.C = C; p.npanels = npanels; p.nsets = nsets;
     p.rows_per_set = rows_per_set; p.row_begin = row_begin; p.row_end = row_end;
-    int rps = cdiv(row_end - row_begin, nsplits);
-    rps = cdiv(rps, BR) * BR;
-    p.rows_per_split = rps;
     for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
     // 3x3 filter rows: panels come in triples whose shifts are consecutive rows with equal channel offsets
@@ -348,7 +376,50 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
                   p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
     static int force1 = -1;
     if (force1 < 0) { const char* e = getenv("SISS_TN_TAPS"); force1 = e ? atoi(e) : 0; }
-    if (triples && force1 != 1) return launch_tn<3>(p, (hipStream_t)stream);
+    bool fused3 = triples && force1 != 1;
+    const int rows = row_end - row_begin;
+    const bool automatic = nsplits <= 0;
+    if (nsplits <= 0) {
+        // Auto: pick (kernel variant, split count) by a small cost model (us), measured constants:
+        //   a block's K-step (64 rows): 1.5 us for the 3-tap kernel (one 8-wave block per CU), 0.6 us for the
+        //   one-tap kernel alone on a CU, 1.0 us with a second block beside it;
+        //   every split adds the whole dW once more through float atomics (~1.3 TB/s chip-wide), a single split
+        //   owns its tile and read-add-writes it with plain accesses.
+        // The one-tap variant is only considered for short reductions (the 8x8 / 16x16 layers), where it puts 3x the
+        // blocks on the chip without any split; on long reductions it re-reads X three times.
+        static int small1 = -1;
+        if (small1 < 0) { const char* e = getenv("SISS_TN_SMALL1"); small1 = e ? atoi(e) : 1; }
+        const double bytes = (double)nsets * npanels * N * C * 4.0;
+        const long tiles = (long)cdiv(N, BN) * cdiv(C, BC);
+        double best = 1e30;
+        int best_ns = 1;
+        bool best_f3 = fused3;
+        for (int v = 0; v < 2; ++v) {
+            const bool f3 = v == 0;
+            if (f3 && !fused3) continue;
+            if (!f3 && fused3 && (rows >= 8192 || !small1)) continue;
+            const long base = tiles * (f3 ? npanels / 3 : npanels) * nsets;
+            const long slots = f3 ? 256 : 512;
+            const int max_ns = rows / 256 > 1 ? rows / 256 : 1;
+            for (int ns = 1; ns <= max_ns && ns <= 1024; ++ns) {
+                const long blocks = base * ns;
+                const long rounds = cdiv(blocks, slots);
+                if (rounds > 1 && ns > 1) break;           // never split into a second round
+                const double tstep = f3 ? 1.5 : (blocks <= 256 ? 0.6 : 1.0);
+                const double t = (double)rounds * cdiv(cdiv(rows, ns), BR) * tstep +
+                                 (ns > 1 ? ns * bytes / 1.3e6 : 2.0 * bytes / 4.0e6);
+                if (t < best) { best = t; best_ns = ns; best_f3 = f3; }
+            }
+        }
+        nsplits = best_ns;
+        fused3 = best_f3;
+    }
+    p.nsplits = nsplits;
+    p.rmw = automatic && nsplits == 1;
+    int rps = cdiv(rows, nsplits);
+    rps = cdiv(rps, BR) * BR;
+    p.rows_per_split = rps;
+    if (fused3) return launch_tn<3>(p, (hipStream_t)stream);
     return launch_tn<1>(p, (hipStream_t)stream);
 }
 

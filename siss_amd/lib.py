@@ -123,6 +123,19 @@ def _work(name, a):
     return 0.0
 
 
+def _shape_key(name, a):
+    """Problem shape of a launch, for per-layer breakdowns (tools/step_breakdown.py)."""
+    if name == "siss_gemm_nt":
+        return ("M", a[10], "N", a[11], "K", a[12], "panels", a[13], "batch", a[20])
+    if name == "siss_gemm_tn":
+        return ("N", a[6], "C", a[7], "panels", a[8], "sets", a[11], "rows", a[15] - a[14], "splits", a[16])
+    if name == "siss_groupnorm_fwd":
+        return ("n", a[7], "H", a[8], "C", a[10])
+    if name == "siss_groupnorm_bwd":
+        return ("n2", a[17], "H", a[21], "C", a[23])
+    return ()
+
+
 def call(name, *args):
     """Call a launcher on torch's current stream; tensors are passed as raw pointers."""
     lib = load()
@@ -133,7 +146,7 @@ def call(name, *args):
         s.record()
         rc = fn(*conv, stream_ptr())
         e.record()
-        PROF.append((name, s, e, _work(name, args)))
+        PROF.append((name, s, e, _work(name, args), _shape_key(name, args)))
     else:
         rc = fn(*conv, stream_ptr())
     if rc != 0:

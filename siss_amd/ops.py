@@ -82,15 +82,9 @@ def conv_dgrad(dy: Act, wT_bf16, out: Act, residual: Act = None, ksize=3):
 
 
 def _nsplits(tiles, npanels, nsets, rows, fused3):
-    """Split-K factor of the wgrad GEMM.  The fused 3-tap kernel runs ONE 8-wave block per CU and every
-    block does the same amount of work, so the grid must not spill into a second, mostly empty round:
-    choose the largest split count whose grid still fits one round of 256 CUs (two rounds of 2 blocks/CU
-    for the one-panel kernel), with at least 4 K-steps (256 rows) per block."""
-    groups = npanels // 3 if fused3 else npanels
-    base = tiles * groups * nsets
-    slots = 256 if fused3 else 512
-    ns = max(1, slots // base)
-    return max(1, min(ns, rows // 256))
+    """Split-K factor of the wgrad GEMM: 0 = let siss_gemm_tn choose (kernel variant + split count from its cost
+    model: K-steps per block vs the float-atomic traffic every extra split adds; gemm_tn.hip)."""
+    return 0
 
 
 def is_conv3_panels(shifts, coffs):

@@ -164,6 +164,7 @@ class UNetEngine:
         self.ps.allocate(self.device)
         self._build_temb_tables()
         self.wT = {}
+        self._wds = {}
         self._acts = {}
         self._bufs = {}
         self._pool = {}
@@ -308,12 +309,26 @@ class UNetEngine:
             self._build_wt_jobs()
         lib.call("siss_conv_weight_dgrad_multi", ps.flat, self._wt_all, self._wt_jobs, self._wt_njobs,
                  self._wt_tiles)
+        for pre, (buf, idx) in self._wds.items():
+            torch.index_select(self.wT[pre + ".conv.weight"], 0, idx, out=buf)
         # conv_out dgrad operand: Wn^T, [Cin][K = 9*Cout padded to 64] bf16 (k = tap*Cout + co)
         w = ps.p("conv_out.weight")
         k = w.shape[0] * w.shape[1]
         if getattr(self, "_wd_out", None) is None:
             self._wd_out = torch.zeros(w.shape[2], -(-k // 64) * 64, dtype=torch.bfloat16, device=self.device)
         self._wd_out[:, :k] = w.reshape(k, w.shape[2]).t()
+
+    def _ds_weights(self, pre, order):
+        """Plane-grouped copy [9][Ci][Co] of a stride-2 conv's transposed weights (entry i = W[order[i]]^T); kept
+        in step with the master by refresh_weights()."""
+        ent = self._wds.get(pre)
+        if ent is None:
+            wT = self.wT[pre + ".conv.weight"]          # [9][Ci][Co], index 8 - tap holds W[tap]^T
+            idx = torch.tensor([8 - tap for tap in order], device=self.device)
+            ent = (torch.empty_like(wT), idx)
+            torch.index_select(wT, 0, idx, out=ent[0])
+            self._wds[pre] = ent
+        return ent[0]
 
     def _build_wt_jobs(self):
         """One bf16 buffer holding every dgrad weight copy ([taps][Cin][Cout], tap order reversed) and the
@@ -701,6 +716,13 @@ class UNetEngine:
         y = self._act(self._name(pre + ".y"), B, Ho, Wo, C)
         ops.gemm_nt(lib.ptr(z.data), 4 * C, w, lib.ptr(y.data), C, z.rows, C, C, shifts, coffs,
                     bias=ps.p(pre + ".conv.bias"), rows_per_image=z.rows_per_image, hp=z.hp, wp=z.wp)
+        # dgrad: the taps that read the same space-to-depth plane (py, px) WRITE the same plane of dz, so each
+        # plane is one multi-panel GEMM (4 / 2 / 2 / 1 taps) over a plane-grouped copy of the transposed weights
+        planes = {}
+        for tap in range(9):
+            planes.setdefault(coffs[tap] // C, []).append(tap)
+        order = [tap for pl in sorted(planes) for tap in planes[pl]]
+        wds = self._ds_weights(pre, order)
 
         def bwd():
             nb, gb = self.nb, self.gbase
@@ -708,15 +730,13 @@ class UNetEngine:
             dW = ps.grads[gb:, ps.specs[pre + ".conv.weight"].off:]
             self._wgrad(dy, z, dW, C, C, 3, shifts=shifts, coffs=coffs, ldx=4 * C, dbias=ps.g(pre + ".conv.bias", gb))
             dz = self._get(nb, Ho, Wo, 4 * C)
-            wT = self.wT[pre + ".conv.weight"]          # [9][Ci][Co], index 8 - tap holds W[tap]^T
-            seen = set()
-            for tap in range(9):
-                plane = coffs[tap] // C
-                cptr = lib.ptr(dz.data[:, plane * C:])
-                ops.gemm_nt(lib.ptr(dy.data), C, wT[8 - tap:], cptr, 4 * C, dy.rows, C, C, [-shifts[tap]], [0],
-                            res_ptr=cptr if plane in seen else None, ldr=4 * C,
+            pos = 0
+            for plane in sorted(planes):
+                taps = planes[plane]
+                ops.gemm_nt(lib.ptr(dy.data), C, wds[pos:], lib.ptr(dz.data[:, plane * C:]), 4 * C, dy.rows, C, C,
+                            [-shifts[tap] for tap in taps], [0] * len(taps),
                             rows_per_image=dy.rows_per_image, hp=dy.hp, wp=dy.wp)
-                seen.add(plane)
+                pos += len(taps)
             self._put(dy)
             acc = self.gmap.get(id(x))
             self._wsync(acc)
