@@ -7,6 +7,7 @@
 // Weight layout: native [9][CO][C] f32 (tap = ky*3+kx).  C/8 lanes cover one pixel row
 // (16 B per lane, coalesced); partial dot products are folded with wave shuffles.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -101,6 +102,53 @@ __global__ __launch_bounds__(kThreads) void conv_out_fprop_wave_kernel(
         if (lane == 0) {
 #pragma unroll
             for (int o = 0; o < CO; ++o) pred[(((long)n * CO + o) * H + yy) * W + xx] = acc[o] + bias[o];
+        }
+    }
+}
+
+// MFMA form for C % 32 == 0 (every UNet here): the op reads a C-channel activation to produce <= 4 channels, so it
+// must run at the HBM rate of that one read.  One wave = 16 consecutive pixels of an image row; the weights are the
+// MFMA A operand (rows = output channels, zero above CO), the activations the B operand straight from global
+// memory (lane: pixel l&15, 8 channels at 32*kc + 8*(l>>4): one 16-B load per lane and (tap, kc)); the nine taps
+// re-read neighbouring rows through L1/L2.  Weights are rounded to bf16 like every other convolution of the path
+// (the reference's autocast runs conv_out in bf16 as well).
+template <int CO>
+__global__ __launch_bounds__(kThreads) void conv_out_fprop_mfma_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ pred, int B, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* sw = reinterpret_cast<bf16_t*>(smem_raw);      // [9][CO][C] bf16
+    for (int i = threadIdx.x; i < 9 * CO * C; i += kThreads) sw[i] = f2bf(w[i]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int px = lane & 15, kg = lane >> 4;
+    const int segs = (W + 15) >> 4, Wp = W + 2, kchunks = C >> 5;
+    const long nseg = (long)B * H * segs;
+    const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long seg = (long)blockIdx.x * (kThreads / 64) + wv; seg < nseg; seg += (long)gridDim.x * (kThreads / 64)) {
+        const int sx = seg % segs; long t = seg / segs;
+        const int y = t % H; const int n = t / H;
+        const int xx = sx * 16 + px;
+        const bool ok = xx < W;
+        const int xc = ok ? xx : W - 1;
+        const bf16_t* base = x + (((long)n * (H + 2) + y + 1) * Wp + xc + 1) * C + kg * 8;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bf16_t* bp = base + (long)((tap / 3 - 1) * Wp + (tap % 3 - 1)) * C;
+            const bf16_t* ap = sw + (tap * CO + (px < CO ? px : 0)) * C + kg * 8;
+#pragma unroll 4
+            for (int kc = 0; kc < kchunks; ++kc) {
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(bp + kc * 32);
+                bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ap + kc * 32);
+                if (px >= CO) a = zero;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            }
+        }
+        // acc[r] = output channel 4*(lane>>4) + r of pixel lane&15
+        if (kg == 0 && ok) {
+#pragma unroll
+            for (int r = 0; r < CO; ++r) pred[(((long)n * CO + r) * H + y) * W + xx] = acc[r] + bias[r];
         }
     }
 }
@@ -223,6 +271,14 @@ int siss_conv_out_fprop(const void* x, const float* w, const float* bias, float*
     SISS_CHECK_ARG(x && w && bias && pred && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
     SISS_CHECK_ARG(9L * CO * C * sizeof(float) <= 64 * 1024);
     hipStream_t st = (hipStream_t)stream;
+    static int use_mfma = -1;
+    if (use_mfma < 0) { const char* e = getenv("SISS_CONV_OUT_MFMA"); use_mfma = e ? atoi(e) : 1; }
+    if (use_mfma && C % 32 == 0) {
+        long nb = ((long)B * H * ((W + 15) / 16) + 3) / 4;
+        if (nb > 256 * 8) nb = 256 * 8;
+        DISPATCH_CO(CO, (conv_out_fprop_mfma_kernel<kCO><<<(int)nb, kThreads, 9 * kCO * C * sizeof(bf16_t), st>>>((const bf16_t*)x, w, bias, pred, B, H, W, C)));
+        SISS_LAUNCH_RET();
+    }
     if (!lpp_ok(C)) {
         long nb = ((long)B * H * W + 3) / 4;
         if (nb > 4096) nb = 4096;

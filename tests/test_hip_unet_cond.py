@@ -85,19 +85,24 @@ def test_groupnorm_wide_two_sets(dev, C, H, silu, split):
         _close(grads[k, 4096:4096 + C].cpu(), refs[k][2], 5e-3, f"gn dbeta set {k}")
 
 
-def test_conv_out_fprop_any_channels(dev):
+@pytest.mark.parametrize("C,H,W,CO", [(320, 16, 16, 4), (128, 12, 28, 3), (64, 28, 28, 1), (40, 9, 9, 4)])
+def test_conv_out_fprop_any_channels(dev, C, H, W, CO):
+    """conv_out forward: the MFMA kernel (C % 32 == 0; weights rounded to bf16 like every conv of the path; ragged
+    16-pixel segments at W = 28) and the one-wave-per-pixel f32 kernel for other channel counts."""
     from siss_amd import lib
     from siss_amd.layout import Act
-    g = torch.Generator().manual_seed(5)
-    B, C, H, CO = 2, 320, 16, 4
-    x = _bf(torch.randn(B, C, H, H, generator=g))
+    g = torch.Generator().manual_seed(5 + C)
+    B = 2
+    x = _bf(torch.randn(B, C, H, W, generator=g))
     w = torch.randn(CO, C, 3, 3, generator=g) / 50
     b = torch.randn(CO, generator=g)
-    ref = F.conv2d(x, w, b, padding=1)
+    ref = F.conv2d(x, _bf(w) if C % 32 == 0 else w, b, padding=1)
     wn = w.permute(2, 3, 0, 1).reshape(9, CO, C).contiguous().to(dev)
-    pred = torch.empty(B, CO, H, H, device=dev)
-    lib.call("siss_conv_out_fprop", Act.from_nchw(x, dev).data, wn, b.to(dev), pred, B, H, H, C, CO)
-    _close(pred.cpu(), ref, 1e-4, "conv_out fprop C=320")
+    pred = torch.full((B, CO, H, W), float("nan"), device=dev)
+    xa = Act(B, H, W, C, dev)
+    xa.set_from_nchw(x.to(dev))
+    lib.call("siss_conv_out_fprop", xa.data, wn, b.to(dev), pred, B, H, W, C, CO)
+    _close(pred.cpu(), ref, 1e-4, f"conv_out fprop C={C}")
 
 
 # ---------------------------------------------------------------- SD-shaped UNet, end to end
