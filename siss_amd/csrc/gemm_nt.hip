@@ -89,14 +89,21 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
         wsrc[j] = W + (long)gn * p.Kp + lc * 8;
     }
     const int kchunks = p.Kp / BK;
-    const int steps = p.npanels * kchunks;
     const long wpanel = (long)p.N * p.Kp;
+    // split-K (small grids: the 8x8 / 16x16 layers leave most CUs idle and are bound by the serial K loop):
+    // block (tile, blockIdx.y) runs K-steps [s_begin, s_begin + steps) and parks its raw accumulators in a slab
+    int s_begin = 0, steps = p.npanels * kchunks;
+    if (p.ksplit > 1) {
+        const int all = steps;
+        s_begin = (int)((long)all * blockIdx.y / p.ksplit);
+        steps = (int)((long)all * (blockIdx.y + 1) / p.ksplit) - s_begin;
+    }
 
     // (panel, k-chunk) of the NEXT stage() call; steps are staged in order.  The panel's row shift / channel
     // offset live in the kernel arguments: they are fetched right AFTER a stage's DMA has been issued, so the
     // scalar-load latency hides behind the compute phase instead of sitting between the barrier and the DMA.
-    int st_pn = 0, st_kc = 0;
-    long a_base = (long)p.shift[0] * p.lda + p.coff[0], w_base = 0;
+    int st_pn = s_begin / kchunks, st_kc = s_begin - st_pn * kchunks;
+    long a_base = (long)p.shift[st_pn] * p.lda + p.coff[st_pn], w_base = st_pn * wpanel;
     const unsigned smem_a = lds_addr(smem);
     auto stage = [&](int buf, int step) {
         (void)step;
@@ -218,7 +225,49 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    if (p.ksplit > 1) {
+        // accumulator order, 16 B per lane: fully coalesced, read back the same way by the reduce kernel
+        float* dst = p.slab + ((long)(tm * tiles_n + tn) * p.ksplit + blockIdx.y) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                *reinterpret_cast<f32x4_t*>(dst + ((i * MT + j) * C_::kThreads + tid) * 4) = acc[i][j];
+        return;
+    }
     nt_epilogue<BM, C_::kThreads, MT>(p, acc, smem, m0, n0, bz, tid, wm, wn, frow, fq);
+}
+
+// Second half of a split-K product: sum the ksplit partial tiles of one output tile (L2-resident, written a few
+// microseconds earlier) and run the normal epilogue (alpha / bias / row bias / residual / halo mask, bf16 rows).
+template <int BM, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_reduce_kernel(const NTParams p) {
+    constexpr int kThreads = NW * 64, MT = BM / (NW / 2) / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int frow = lane & 15, fq = lane >> 4;
+    f32x4_t acc[4][MT];
+    const float* src = p.slab + (long)blockIdx.x * p.ksplit * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = *reinterpret_cast<const f32x4_t*>(src + ((i * MT + j) * kThreads + tid) * 4);
+    for (int k = 1; k < p.ksplit; ++k) {
+        src += BM * BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + ((i * MT + j) * kThreads + tid) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += v[r];
+            }
+    }
+    nt_epilogue<BM, kThreads, MT>(p, acc, smem, tm * BM, tn * BN, 0, tid, wm, wn, frow, fq);
 }
 
 template <int BM, int NW, int STAGES>
@@ -231,10 +280,23 @@ int launch_nt(const NTParams& p, int batch, hipStream_t st) {
             return SISS_ERR_LAUNCH;
         attr_set = true;
     }
-    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, batch);
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.ksplit > 1 ? p.ksplit : 1, batch);
     gemm_nt_kernel<BM, NW, STAGES><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
+    if (p.ksplit > 1) {
+        static bool attr2 = false;
+        if (!attr2) {
+            if (hipFuncSetAttribute((const void*)gemm_nt_reduce_kernel<BM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    BM * kCRow) != hipSuccess)
+                return SISS_ERR_LAUNCH;
+            attr2 = true;
+        }
+        gemm_nt_reduce_kernel<BM, NW><<<grid.x, C_::kThreads, BM * kCRow, st>>>(p);
+    }
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
+
+float* g_slab = nullptr;       // split-K workspace handed over by the host (siss_gemm_nt_set_workspace)
+long g_slab_bytes = 0;
 
 }  // namespace
 
@@ -243,6 +305,15 @@ int siss_launch_gemm_nt_c3(const void* params, void* stream);      // gemm_nt_c3
 int siss_launch_gemm_nt_c3p(const void* params, void* stream);     // gemm_nt_c3p.hip
 
 extern "C" {
+
+// Optional device workspace for the split-K path of siss_gemm_nt (small grids).  The library never allocates:
+// without a workspace (or with one that is too small for a launch) that path is simply not taken.  The buffer
+// is used by launches on ONE stream at a time (the partial tiles live from the product kernel to its reduce kernel).
+int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
+    SISS_CHECK_ARG((ptr && bytes > 0 && (uintptr_t)ptr % 16 == 0) || (!ptr && bytes == 0));
+    g_slab = (float*)ptr; g_slab_bytes = bytes;
+    return SISS_OK;
+}
 
 // Flat argument list (ctypes-friendly).  shifts/coffs are HOST arrays of npanels ints.
 // Returns SISS_ERR_ARG for shapes the kernel does not cover (Kp % 64, alignment, panel count).
@@ -265,6 +336,7 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+    p.ksplit = 1; p.slab = nullptr;
     { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     SISS_CHECK_ARG((!rowbias && Hp == 0) || rows_per_image >= 64);   // <= 3 images per 128/256-row tile
     SISS_CHECK_ARG(N % 8 == 0 && (!rowbias || ldrb % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0));
@@ -308,7 +380,30 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     // costs its MFMA time instead of an L2 round trip (the 8x8 .. 32x32 layers are bound by the serial K loop)
     static int deep = -1;
     if (deep < 0) { const char* e = getenv("SISS_NT_DEEP"); deep = e ? atoi(e) : 1; }
-    if (deep && tiles128 <= 256) return launch_nt<128, 4, 4>(p, batch, (hipStream_t)stream);
+    if (deep && tiles128 <= 256) {
+        // Few tiles and a long K loop: split K over up to 8 blocks per tile so that (nearly) every CU holds one
+        // block; each block keeps >= 6 K-steps.  Partial tiles go through the host-provided slab.
+        static int splitk = -1;
+        if (splitk < 0) { const char* e = getenv("SISS_NT_SPLITK"); splitk = e ? atoi(e) : 1; }
+        const int steps = npanels * (Kp / BK);
+        if (splitk && batch == 1 && tiles128 <= 128 && steps >= 12 && g_slab) {
+            int S = (int)(256 / tiles128);
+            if (S > 8) S = 8;
+            if (S > steps / 6) S = steps / 6;
+            if (S >= 2 && (long)tiles128 * S * 128 * BN * (long)sizeof(float) <= g_slab_bytes) {
+                p.ksplit = S; p.slab = g_slab;
+            }
+        }
+        // 129..256 tiles (the 16x16 layers): two double-buffered blocks per CU, each with half the K loop
+        static int split2 = -1;
+        if (split2 < 0) { const char* e = getenv("SISS_NT_SPLIT2"); split2 = e ? atoi(e) : 1; }
+        if (splitk && split2 && batch == 1 && tiles128 > 128 && steps >= 24 && g_slab &&
+            (long)tiles128 * 2 * 128 * BN * (long)sizeof(float) <= g_slab_bytes) {
+            p.ksplit = 2; p.slab = g_slab;
+            return launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
+        }
+        return launch_nt<128, 4, 4>(p, batch, (hipStream_t)stream);
+    }
     // tiny grids (8x8 / 16x16 layers, attention): 64-row tiles double the block count
     static int small = -1;
     if (small < 0) { const char* e = getenv("SISS_NT_SMALL"); small = e ? atoi(e) : 0; }   // opt-in: measured +-5 % (these layers are K-latency-bound, not block-count-bound)

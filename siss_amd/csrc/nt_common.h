@@ -17,6 +17,8 @@ struct NTParams {
     int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
     float alpha, inv_wp;
     int ablate;
+    int ksplit;                       // > 1: split-K -- gridDim.y blocks per tile write f32 partial tiles to `slab`
+    float* slab;                      //      ([tile][split][BM*BN] in accumulator order), gemm_nt_reduce_kernel finishes
     long long* dbg;                   // timing probe buffer (SISS_NT_DEBUG_PTR), normally null
     int shift[kMaxPanels];
     int coff[kMaxPanels];

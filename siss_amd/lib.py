@@ -30,6 +30,7 @@ SIGNATURES = {
     "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],
     "siss_conv_weight_dgrad_multi": [P, P, P, I, I, P],
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
+    "siss_gemm_nt_set_workspace": [P, L],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
@@ -90,6 +91,25 @@ def load():
         fn.restype = C.c_long if name in _RET_LONG else C.c_int
     _lib = lib
     return lib
+
+
+_WORKSPACE = {}
+WORKSPACE_BYTES = 32 << 20      # 512 partial tiles of 128 x 128 f32: the most the split-K paths of siss_gemm_nt ask for
+
+
+def ensure_workspace(device):
+    """Hand the library its split-K scratch (one buffer per process, kept alive here; the C side never allocates).
+    Launches on one stream at a time use it -- the one-process-per-GPU, one-compute-stream schedule of this package."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _WORKSPACE:
+        buf = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _WORKSPACE.clear()                      # the library holds ONE pointer: the newest device wins
+        _WORKSPACE[key] = buf
+        rc = load().siss_gemm_nt_set_workspace(C.c_void_p(buf.data_ptr()), WORKSPACE_BYTES)
+        if rc != 0:
+            raise RuntimeError(f"siss_gemm_nt_set_workspace failed with status {rc}")
+    return _WORKSPACE[key]
 
 
 def ptr(t):

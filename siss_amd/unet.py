@@ -158,6 +158,8 @@ class UNetEngine:
         lib.load()
         self.cfg = cfg
         self.device = torch.device(device)
+        if self.device.type == "cuda":
+            lib.ensure_workspace(self.device)
         self.ps = ParamStore()
         self._declare_params()
         self.ps.relayout(self._grads_final_early)
