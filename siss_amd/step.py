@@ -27,13 +27,17 @@ from .unet import UNetEngine
 
 SISS = "importance_sampling_with_mixture"
 NO_IS = "double_forward_with_neg_del"
+ERASEDIFF = "erasediff"
+NEG_GRAD = "simple_neg_del"
+NAIVE = "naive_del"
+SUBSCORE = "subscore_bernoulli"
 
 
 class SISSStepper:
     def __init__(self, engine: UNetEngine, alphas_cumprod, *, lr, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=1e-2, scaling_norm=None, eta=None, lambd=0.5, train_batch_size,
                  grad_accum=1, max_grad_norm=1.0, loss_fn=SISS, inf_guard=False, process_group=None,
-                 mixed_precision="bf16"):
+                 mixed_precision="bf16", superfactor=1.0):
         self.e = engine
         dev = engine.device
         ac = alphas_cumprod.to(device=dev, dtype=torch.float32).contiguous()
@@ -43,6 +47,9 @@ class SISSStepper:
         self.lambd, self.scaling_norm, self.eta, self.inf_guard = float(lambd), scaling_norm, eta, inf_guard
         self.train_batch_size, self.ga = int(train_batch_size), int(grad_accum)
         self.loss_fn = loss_fn
+        self.superfactor = float(superfactor)
+        if loss_fn == ERASEDIFF:
+            assert eta is not None, "erasediff needs eta (delete_celeb.py:740-742)"
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.io_dtype = torch.bfloat16 if mixed_precision == "bf16" else torch.float32
@@ -59,7 +66,7 @@ class SISSStepper:
             engine.on_early_grads_final = self._early_allreduce
 
     # ------------------------------------------------------------------ one micro-batch
-    def micro_step(self, x0, a0, noise, t, u, conditioning=None):
+    def micro_step(self, x0, a0, noise, t, u, conditioning=None, erase_target=None):
         """Inputs: x0/a0/noise [B,C,H,W] (cast to the io dtype like delete_celeb.py:561-581),
         t [B] int64, u [B] keep/forget uniforms; conditioning: the dict the reference splats into the UNet
         call ({} or {'encoder_hidden_states': [B,77,768]}, delete_sd.py:974-976).  Enqueues fwd + dual
@@ -93,6 +100,52 @@ class SISSStepper:
             cot, _, sums = mse_bwd_seed(pred, tgt, scale)
             e.backward(cot, nsets=2)
             self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums[:B], sum_loss_a=sums[B:], chw=pred[0].numel())
+        elif self.loss_fn == ERASEDIFF:
+            # ddpm_deletion_loss.py:70-78: keep half against the noise, forget half against U[0,1) "noise"; the
+            # recombination is s = -max(eta - <g_x, g_a> / |g_a|^2, 0) (delete_celeb.py:740-742, optimizer mode)
+            m = mixture_fwd(x0, a0, noise, t, torch.ones(B, device=e.device), self.ac, self.gamma_tab,
+                            self.sigma_tab, 0.0)
+            mf = mixture_fwd(x0, a0, noise, t, torch.zeros(B, device=e.device), self.ac, self.gamma_tab,
+                             self.sigma_tab, 0.5)
+            xin = torch.cat([m.x_mix, mf.x_mix], 0)
+            cond2 = {k: torch.cat([v, v], 0) for k, v in cond.items()}
+            pred = e.forward(xin, torch.cat([t, t], 0), **cond2)
+            if erase_target is None:
+                erase_target = torch.rand(noise.shape, device=e.device, dtype=torch.float32)
+            tgt = torch.cat([noise.float(), erase_target.to(device=e.device, dtype=torch.float32)], 0)
+            cot, _, sums = mse_bwd_seed(pred, tgt, scale)
+            e.backward(cot, nsets=2)
+            self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums[:B], sum_loss_a=sums[B:], chw=pred[0].numel())
+        elif self.loss_fn in (NEG_GRAD, NAIVE):
+            # a `loss` is returned (ddpm_deletion_loss.py:82-96): ONE backward, no gradient split
+            # (delete_celeb.py:682-684); NegGrad ascends on the forget batch with -superfactor
+            keep = self.loss_fn == NAIVE
+            m = mixture_fwd(x0, a0, noise, t, torch.full((B,), 1.0 if keep else 0.0, device=e.device), self.ac,
+                            self.gamma_tab, self.sigma_tab, 0.5)
+            pred = e.forward(m.x_mix, t, **cond)
+            cot, _, sums = mse_bwd_seed(pred, noise, scale if keep else -self.superfactor * scale)
+            # the second gradient set stays zero (zero_grad above): g = g_x through the inf-guarded s = 0
+            e.backward(cot, nsets=1)
+            z = torch.zeros_like(sums)
+            self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums if keep else z, sum_loss_a=z if keep else sums,
+                             chw=pred[0].numel())
+        elif self.loss_fn == SUBSCORE:
+            # ddpm_deletion_loss.py:99-122: Bernoulli keep/forget rows against the plain noise target; the row
+            # selection loss[mask] / (1 - lambd), loss[~mask] is a per-sample weight on the shared forward
+            uu = u.to(device=e.device, dtype=torch.float32)
+            m = mixture_fwd(x0, a0, noise, t, uu, self.ac, self.gamma_tab, self.sigma_tab, self.lambd)
+            pred = e.forward(m.x_mix, t, **cond)
+            c, _, sums = mse_bwd_seed(pred, noise, scale)
+            keep = (uu > self.lambd).float()
+            any_keep = (keep.sum() > 0).float()    # no keep rows: BOTH losses are zeroed (:113-116)
+            wx = (keep / (1.0 - self.lambd)).view(B, 1, 1, 1)
+            wa = ((1.0 - keep) * any_keep).view(B, 1, 1, 1)
+            cot = e._buf("cot", (2 * B, *pred.shape[1:]))
+            torch.mul(c, wx, out=cot[:B])
+            torch.mul(c, wa, out=cot[B:])
+            e.backward(cot, nsets=2)
+            self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums * wx.view(B), sum_loss_a=sums * wa.view(B),
+                             chw=pred[0].numel())
         else:
             raise ValueError(f"loss_fn {self.loss_fn!r} is not on the HIP fast path")
         self._micro += 1
@@ -124,13 +177,16 @@ class SISSStepper:
                 self._pending = []
             else:
                 allreduce_flat_grads(g, self.pg)
-        self.opt.launch(g, scaling_norm=self.scaling_norm, eta=self.eta, inf_guard=self.inf_guard)
+        single = self.loss_fn in (NEG_GRAD, NAIVE)
+        self.opt.launch(g, scaling_norm=self.scaling_norm if not single else 1.0,
+                        eta=self.eta if self.loss_fn == ERASEDIFF else None,
+                        inf_guard=self.inf_guard or single)
         self.e.refresh_weights()
 
-    def step(self, x0, a0, noise, t, u, conditioning=None):
+    def step(self, x0, a0, noise, t, u, conditioning=None, erase_target=None):
         """GA=1 convenience."""
         assert self.ga == 1
-        self.micro_step(x0, a0, noise, t, u, conditioning)
+        self.micro_step(x0, a0, noise, t, u, conditioning, erase_target)
 
     # ------------------------------------------------------------------ logging (one small D2H)
     def stats(self):

@@ -114,7 +114,8 @@ class _DeleteBase(Task):
             eta=float(d.eta) if d.loss_fn == "erasediff" else None,
             lambd=float((d.loss_params or {}).get("lambd", 0.5)), train_batch_size=B, grad_accum=ga,
             loss_fn=d.loss_fn, inf_guard=self.inf_guard, process_group=pg,
-            mixed_precision=cfg.get("mixed_precision"))
+            mixed_precision=cfg.get("mixed_precision"),
+            superfactor=float((d.loss_params or {}).get("superfactor", 1.0)))
         shape = (unet.config.in_channels, unet.config.sample_size, unet.config.sample_size)
         ds_all, ds_del = self.datasets(shape)
         it_all = batches(ds_all, InfiniteSampler(ds_all, rank=rank, num_replicas=world), B)

@@ -172,6 +172,44 @@ def test_no_is_fast_path_matches_oracle(setup):
     _check_scalars(ref, st.stats())
 
 
+@pytest.mark.parametrize("loss_fn", ["erasediff", "simple_neg_del", "naive_del", "subscore_bernoulli"])
+def test_baseline_losses_fast_path_matches_oracle(setup, loss_fn):
+    """The other objectives of the class surface (ddpm_deletion_loss.py:70-122) on the fused stepper: EraseDiff
+    (two forwards, U[0,1) target, s = -max(eta - <g_x,g_a>/|g_a|^2, 0)), NegGrad / naive (one backward, no split),
+    Bernoulli sub-score (row selection as per-sample weights)."""
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    eng, net, sd = _fresh(setup)
+    ac = S.alphas_cumprod()
+    okw = dict(lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6)
+    opt = torch.optim.AdamW(net.parameters(), **okw)
+    mb = _batch(torch.Generator().manual_seed(41))
+    name = loss_fn
+    lp = {"lambd": 0.5} if name == "subscore_bernoulli" else ({"superfactor": 3.0} if name == "simple_neg_del" else {})
+    kw = dict(scaling_norm=5.0) if name != "erasediff" else dict(eta=1e-2)
+    st = SISSStepper(eng, ac, lambd=0.5, train_batch_size=4, loss_fn=name, mixed_precision=None, superfactor=3.0,
+                     inf_guard=True, **okw, **kw)
+    torch.manual_seed(99)                                     # erasediff: rand_like is the first draw in the oracle
+    ref, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), name, ac, [mb], train_batch_size=4,
+                              scaling_norm=5.0, eta=1e-2, loss_params=lp, inf_guard=True)
+    torch.manual_seed(99)
+    target = torch.rand(mb["noise"].shape) if name == "erasediff" else None
+    st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"], erase_target=target)
+    got = st.stats()
+    if name in ("simple_neg_del", "naive_del"):
+        assert abs(got["pre_clip_norm"] - ref.pre_clip_norm) <= 5e-2 * ref.pre_clip_norm
+    else:
+        _check_scalars(ref, got)
+    new = eng.state_dict()
+    num = den = 0.0
+    for n, p in net.named_parameters():
+        dr, dh = (p.detach() - sd[n]).flatten(), (new[n] - sd[n]).flatten()
+        num += float((dr * dh).sum()); den += float(dr.norm() * dh.norm()) + 1e-30
+    assert num / den > 0.9, num / den
+
+
 def test_gradient_accumulation_two_micro_batches(setup):
     """GA = 2: gradients of both micro-batches accumulate in the flat [g_x ; g_a] buffer (delete_celeb.py:705-711)."""
     from siss_amd.step import SISSStepper
