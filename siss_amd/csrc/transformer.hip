@@ -149,6 +149,16 @@ __device__ __forceinline__ float dgelu_f(float g) {
     return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
 }
 
+__global__ __launch_bounds__(kThreads) void quick_gelu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long nchunks) {
+    const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= nchunks) return;
+    float v[8];
+    unpack8f(*reinterpret_cast<const u32x4_t*>(x + idx * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sigmoid_f(1.702f * v[e]);
+    *reinterpret_cast<u32x4_t*>(y + idx * 8) = pack8f(v);
+}
+
 // out[r][f] = h[r][f] * gelu(h[r][F + f])
 __global__ __launch_bounds__(kThreads) void geglu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ out, long rows, int F) {
     const long idx = (long)blockIdx.x * kThreads + threadIdx.x;       // one 8-channel chunk per thread
@@ -212,12 +222,99 @@ __global__ __launch_bounds__(kThreads) void head_merge_kernel(const bf16_t* __re
         *reinterpret_cast<const u32x4_t*>(src + (((long)b * H + h) * Sp + s) * Dp + c * 8);
 }
 
-// p[r][k] = softmax over k < valid of s[r][k]; p[r][k] = 0 for valid <= k < ld.  One wave per row, any length.
-__global__ __launch_bounds__(kThreads) void softmax_rows_fwd_kernel(const bf16_t* __restrict__ s, bf16_t* __restrict__ p,
-                                                                    long rows, int valid, int ld) {
+// Rows of up to 64 * 8 * kRowChunks = 4096 elements (ld % 8 == 0): the wave keeps the WHOLE row in registers (16 B per
+// lane and load), so the scores are read once and the probabilities written once.  causal_period > 0: row r may
+// only see keys k <= r % causal_period (CLIP text encoder).
+constexpr int kRowChunks = 8;
+
+template <int NCH>
+__global__ __launch_bounds__(kThreads) void softmax_rows_fwd_vec_kernel(const bf16_t* __restrict__ s, bf16_t* __restrict__ p,
+                                                                        long rows, int valid, int ld, int causal_period) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (r >= rows) return;
+    if (causal_period > 0) { const int lim = (int)(r % causal_period) + 1; valid = valid < lim ? valid : lim; }
+    const int nch = ld >> 3;
+    float x[NCH][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            unpack8f(*reinterpret_cast<const u32x4_t*>(s + r * ld + c * 8), x[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (c * 8 + e >= valid) x[i][e] = -INFINITY;
+                mx = fmaxf(mx, x[i][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + i * 64 < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[i][e] = __expf(x[i][e] - mx); sum += x[i][e]; }
+        }
+    const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[i][e] *= inv;
+            *reinterpret_cast<u32x4_t*>(p + r * ld + c * 8) = pack8f(x[i]);
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(kThreads) void softmax_rows_bwd_vec_kernel(const bf16_t* __restrict__ p, const bf16_t* __restrict__ dp,
+                                                                        bf16_t* __restrict__ ds, long rows, long p_rows, int valid,
+                                                                        int ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bf16_t* pr = p + (r % p_rows) * ld;
+    const bf16_t* dr = dp + r * ld;
+    const int nch = ld >> 3;
+    float a[NCH][8], d[NCH][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            unpack8f(*reinterpret_cast<const u32x4_t*>(pr + c * 8), a[i]);
+            unpack8f(*reinterpret_cast<const u32x4_t*>(dr + c * 8), d[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (c * 8 + e >= valid) a[i][e] = 0.f;       // p is zero there already; never trust dp's padding
+                dot += a[i][e] * (c * 8 + e < valid ? d[i][e] : 0.f);
+            }
+        }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = c * 8 + e < valid ? scale * a[i][e] * (d[i][e] - dot) : 0.f;
+            *reinterpret_cast<u32x4_t*>(ds + r * ld + c * 8) = pack8f(o);
+        }
+    }
+}
+
+// p[r][k] = softmax over k < valid of s[r][k]; p[r][k] = 0 for valid <= k < ld.  One wave per row, any length.
+__global__ __launch_bounds__(kThreads) void softmax_rows_fwd_kernel(const bf16_t* __restrict__ s, bf16_t* __restrict__ p,
+                                                                    long rows, int valid, int ld, int causal_period) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    if (causal_period > 0) { const int lim = (int)(r % causal_period) + 1; valid = valid < lim ? valid : lim; }
     const bf16_t* src = s + r * ld;
     float mx = -INFINITY;
     for (int k = lane; k < valid; k += 64) mx = fmaxf(mx, bf2f(src[k]));
@@ -287,6 +384,13 @@ int siss_geglu_bwd(const void* dout, const void* h, void* dh, long rows2, long r
     SISS_LAUNCH_RET();
 }
 
+// y = x * sigmoid(1.702 x) (CLIP's quick_gelu), in place allowed
+int siss_quick_gelu(const void* x, void* y, long n, void* stream) {
+    SISS_CHECK_ARG(x && y && n > 0 && n % 8 == 0);
+    quick_gelu_kernel<<<cdiv(n / 8, kThreads), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, n / 8);
+    SISS_LAUNCH_RET();
+}
+
 // [B][S][H*D] -> [B*H][Sp][Dp], zero padded (Sp >= S, Dp >= D, all of D, Dp multiples of 8)
 int siss_head_split(const void* src, void* dst, int B, int S, int H, int D, int Sp, int Dp, void* stream) {
     SISS_CHECK_ARG(src && dst && B > 0 && S > 0 && H > 0 && D > 0 && D % 8 == 0 && Dp % 8 == 0 && Sp >= S && Dp >= D);
@@ -303,16 +407,35 @@ int siss_head_merge(const void* src, void* dst, int B, int S, int H, int D, int 
     SISS_LAUNCH_RET();
 }
 
+#define SOFTMAX_DISPATCH(KERNEL, ...)                                                                 \
+    do {                                                                                              \
+        const int nch = cdiv(ld / 8, 64);                                                             \
+        const dim3 grid(cdiv(rows, kThreads / 64));                                                   \
+        if (nch <= 1) KERNEL<1><<<grid, kThreads, 0, (hipStream_t)stream>>>(__VA_ARGS__);             \
+        else if (nch <= 2) KERNEL<2><<<grid, kThreads, 0, (hipStream_t)stream>>>(__VA_ARGS__);        \
+        else if (nch <= 4) KERNEL<4><<<grid, kThreads, 0, (hipStream_t)stream>>>(__VA_ARGS__);        \
+        else KERNEL<8><<<grid, kThreads, 0, (hipStream_t)stream>>>(__VA_ARGS__);                      \
+    } while (0)
+
 // Row softmax over the first `valid` of `ld` columns (the rest is written as zero); s already carries the scale.
-int siss_softmax_rows_fwd(const void* s, void* p, long rows, int valid, int ld, void* stream) {
-    SISS_CHECK_ARG(s && p && rows > 0 && valid > 0 && ld >= valid);
-    softmax_rows_fwd_kernel<<<cdiv(rows, kThreads / 64), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)s, (bf16_t*)p, rows, valid, ld);
+// causal_period > 0: row r additionally sees only columns k <= r % causal_period.
+int siss_softmax_rows_fwd(const void* s, void* p, long rows, int valid, int ld, int causal_period, void* stream) {
+    SISS_CHECK_ARG(s && p && rows > 0 && valid > 0 && ld >= valid && causal_period >= 0);
+    if (ld % 8 == 0 && ld <= 64 * 8 * kRowChunks && ((uintptr_t)s | (uintptr_t)p) % 16 == 0) {
+        SOFTMAX_DISPATCH(softmax_rows_fwd_vec_kernel, (const bf16_t*)s, (bf16_t*)p, rows, valid, ld, causal_period);
+        SISS_LAUNCH_RET();
+    }
+    softmax_rows_fwd_kernel<<<cdiv(rows, kThreads / 64), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)s, (bf16_t*)p, rows, valid, ld, causal_period);
     SISS_LAUNCH_RET();
 }
 
 int siss_softmax_rows_bwd(const void* p, const void* dp, void* ds, long rows, long p_rows, int valid, int ld, float scale,
                           void* stream) {
     SISS_CHECK_ARG(p && dp && ds && rows > 0 && p_rows > 0 && valid > 0 && ld >= valid);
+    if (ld % 8 == 0 && ld <= 64 * 8 * kRowChunks && ((uintptr_t)p | (uintptr_t)dp | (uintptr_t)ds) % 16 == 0) {
+        SOFTMAX_DISPATCH(softmax_rows_bwd_vec_kernel, (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)ds, rows, p_rows, valid, ld, scale);
+        SISS_LAUNCH_RET();
+    }
     softmax_rows_bwd_kernel<<<cdiv(rows, kThreads / 64), kThreads, 0, (hipStream_t)stream>>>(
         (const bf16_t*)p, (const bf16_t*)dp, (bf16_t*)ds, rows, p_rows, valid, ld, scale);
     SISS_LAUNCH_RET();

@@ -61,7 +61,8 @@ SIGNATURES = {
     "siss_geglu_bwd": [P, P, P, L, L, I, P],
     "siss_head_split": [P, P, I, I, I, I, I, I, P],
     "siss_head_merge": [P, P, I, I, I, I, I, I, P],
-    "siss_softmax_rows_fwd": [P, P, L, I, I, P],
+    "siss_softmax_rows_fwd": [P, P, L, I, I, I, P],
+    "siss_quick_gelu": [P, P, L, P],
     "siss_softmax_rows_bwd": [P, P, P, L, L, I, I, F, P],
     "siss_timestep_sincos": [P, P, I, I, I, F, P],
     "siss_linear_small_fwd": [P, P, P, P, I, I, I, I, P],

@@ -174,7 +174,7 @@ class UNetCondEngine(UNetEngine):
         sc, p = tb(".sc", (BH, Sqp, Skp)), bb(".p", (BH, Sqp, Skp))
         ops.gemm_nt(lib.ptr(qh), Dp, kh, lib.ptr(sc), Skp, Sqp, Skp, Dp, [0], [0], alpha=scale, batch=BH,
                     stride_a=Sqp * Dp, stride_w=Skp * Dp, stride_c=Sqp * Skp)
-        lib.call("siss_softmax_rows_fwd", sc, p, BH * Sqp, Sk, Skp)
+        lib.call("siss_softmax_rows_fwd", sc, p, BH * Sqp, Sk, Skp, 0)
         oh = tb(".oh", (BH, Sqp, Dp))
         ops.gemm_nt(lib.ptr(p), Skp, vT, lib.ptr(oh), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
                     stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)

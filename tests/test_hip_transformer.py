@@ -105,7 +105,7 @@ def test_softmax_rows_fwd_bwd(dev, rows, valid, ld):
     p_ref = torch.softmax(sr, dim=-1)
     sd = s.to(dev).to(torch.bfloat16)
     p = torch.full((rows, ld), 5.0, dtype=torch.bfloat16, device=dev)
-    lib.call("siss_softmax_rows_fwd", sd, p, rows, valid, ld)
+    lib.call("siss_softmax_rows_fwd", sd, p, rows, valid, ld, 0)
     _close(p[:, :valid].float().cpu(), p_ref.detach(), 1e-2, "softmax fwd")
     assert float(p[:, valid:].abs().sum()) == 0
     ds = torch.full((2 * rows, ld), 5.0, dtype=torch.bfloat16, device=dev)
@@ -117,3 +117,28 @@ def test_softmax_rows_fwd_bwd(dev, rows, valid, ld):
         ref = scale * pb * (d - (pb * d).sum(-1, keepdim=True))
         _close(ds[k * rows:(k + 1) * rows, :valid].float().cpu(), ref, 2e-2, f"softmax bwd set {k}")
     assert float(ds[:, valid:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("S,ld", [(77, 128), (40, 64)])
+def test_softmax_rows_causal(dev, S, ld):
+    """CLIP text-encoder mask: row r of every (sample, head) block of `ld` rows sees keys k <= r."""
+    from siss_amd import lib
+    g = torch.Generator().manual_seed(S)
+    heads = 3
+    s = _bf(torch.randn(heads, ld, ld, generator=g) * 2)
+    mask = torch.full((ld, ld), float("-inf")).triu(1)
+    ref = torch.softmax(s[:, :S, :S] + mask[:S, :S], dim=-1)
+    p = torch.full((heads * ld, ld), 5.0, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_softmax_rows_fwd", s.reshape(-1, ld).to(dev).to(torch.bfloat16), p, heads * ld, S, ld, ld)
+    p = p.view(heads, ld, ld).float().cpu()
+    _close(p[:, :S, :S], ref, 1e-2, "causal softmax")
+    assert float(p[:, :S, S:].abs().sum()) == 0
+    assert float(p[:, :S, :S].triu(1).abs().sum()) == 0
+
+
+def test_quick_gelu(dev):
+    from siss_amd import lib
+    x = _bf(torch.randn(37, 256) * 3)
+    y = torch.empty(37, 256, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_quick_gelu", x.to(dev).to(torch.bfloat16), y, x.numel())
+    _close(y.float().cpu(), x * torch.sigmoid(1.702 * x), 1e-2, "quick_gelu")
