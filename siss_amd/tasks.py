@@ -94,6 +94,10 @@ class _DeleteBase(Task):
     def seed(self):
         return int(self.cfg.random_seed)
 
+    def prepare_batch(self, x, generator):
+        """Images -> what the loss is taken on (identity for the pixel-space tasks; VAE latents for SD)."""
+        return x
+
     # -- the loop ------------------------------------------------------------------------------
     def run(self):
         cfg = self.cfg
@@ -129,8 +133,8 @@ class _DeleteBase(Task):
         t0 = time.perf_counter()
         for step in range(n_steps):
             for _ in range(ga):
-                x0 = next(it_all).to(device, non_blocking=True)
-                a0 = next(it_del).to(device, non_blocking=True)
+                x0 = self.prepare_batch(next(it_all).to(device, non_blocking=True), g)
+                a0 = self.prepare_batch(next(it_del).to(device, non_blocking=True), g)
                 noise = torch.randn(x0.shape, device=device, generator=g)           # SAME noise for both batches
                 t = torch.randint(self.timestep_low, T, (B,), device=device, generator=g)
                 u = torch.rand(B, device=device, generator=g)
@@ -172,6 +176,24 @@ class DeleteSD(_DeleteBase):
     the reference's own ``using_augmented_prompt`` branch, delete_sd.py:938) and synthetic otherwise."""
     default_unet = staticmethod(UNet2DConditionConfig.sd15)
     VAE_SCALE = 0.18215            # vae.config.scaling_factor (delete_sd.py:883,888)
+    vae = None
+    text_encoder = None
+
+    def load_front_end(self, device):
+        """Frozen VAE encoder + CLIP text encoder from the checkpoint directory, when it is on disk
+        (delete_sd.py:464-474): images are then encoded per micro-batch and the prompt once."""
+        path = str(self.cfg.get("pretrained_model_name_or_path") or "")
+        if os.path.isdir(os.path.join(path, "vae")):
+            from .vae import VAEEncoder
+            self.vae = VAEEncoder.from_pretrained(path, "vae", device)
+        if os.path.isdir(os.path.join(path, "text_encoder")):
+            from .text_encoder import CLIPTextEncoder
+            self.text_encoder = CLIPTextEncoder.from_pretrained(path, "text_encoder", device)
+
+    def prepare_batch(self, x, generator):
+        if self.vae is not None and x.shape[1] == self.vae.cfg.in_channels and x.shape[1] != 4:
+            return self.vae.encode(x, generator=generator)      # latent_dist.sample() * scaling_factor (:879-888)
+        return x
 
     def seed(self):
         return int(self.cfg.get("seed", 42))                   # config/delete_sd.yaml:80
@@ -179,6 +201,7 @@ class DeleteSD(_DeleteBase):
     def load_unet(self, device):
         from .model import UNet2DConditionModel
         cfg = self.cfg
+        self.load_front_end(device)
         path = cfg.get("pretrained_model_name_or_path")
         if path and os.path.isdir(os.path.join(str(path), "unet")):
             return UNet2DConditionModel.from_pretrained(path, subfolder="unet", device=device)   # delete_sd.py:458-462
@@ -200,8 +223,11 @@ class DeleteSD(_DeleteBase):
     def datasets(self, shape):
         cfg = self.cfg
         la, ld = cfg.get("latents_all"), cfg.get("latents_deletion")
+        ia, idl = cfg.get("images_all"), cfg.get("images_deletion")
+        from .data import TensorImages
+        if self.vae is not None and ia and idl and os.path.exists(str(ia)) and os.path.exists(str(idl)):
+            return TensorImages(torch.load(ia)), TensorImages(torch.load(idl))     # [N,3,H,W] in [-1,1]: encoded per batch
         if la and ld and os.path.exists(str(la)) and os.path.exists(str(ld)):
-            from .data import TensorImages
             return TensorImages(torch.load(la)), TensorImages(torch.load(ld))
         print("[siss_amd] no latent files configured (the VAE front end is outside the path): synthetic latents")
         return (SyntheticImages(4096, shape, seed=1, scale=self.VAE_SCALE, normal=True),
@@ -212,8 +238,17 @@ class DeleteSD(_DeleteBase):
         vp = cfg.get("validation_prompts")
         X = int((cfg.get("unet") or {}).get("cross_attention_dim", 768))
         if vp and str(vp[0]).endswith(".pt") and os.path.exists(str(vp[0])):
-            e = torch.load(str(vp[0])).to(device).float()
-            e = e.reshape(-1, e.shape[-2], e.shape[-1])[:1]
+            e = torch.load(str(vp[0])).to(device)
+            if not e.is_floating_point():                       # token ids [77] / [1,77]: run the text encoder
+                assert self.text_encoder is not None, "token ids given but no text_encoder/ in the checkpoint directory"
+                e = self.text_encoder(e.reshape(1, -1))[0]
+            e = e.float().reshape(-1, e.shape[-2], e.shape[-1])[:1]
+        elif vp and self.text_encoder is not None:
+            from transformers import CLIPTokenizer               # delete_sd.py:395-410 tokenize_captions
+            tok = CLIPTokenizer.from_pretrained(str(cfg.pretrained_model_name_or_path), subfolder="tokenizer")
+            ids = tok([str(vp[0])], max_length=tok.model_max_length, padding="max_length", truncation=True,
+                      return_tensors="pt").input_ids
+            e = self.text_encoder(ids)[0].float()
         else:
             e = torch.randn(1, 77, X, generator=torch.Generator().manual_seed(self.seed())).to(device)
         return {"encoder_hidden_states": e.repeat(B, 1, 1)}     # one prompt for the whole batch (delete_sd.py:941-944)

@@ -633,7 +633,10 @@ class UNetEngine:
             lib.call("siss_transpose_bf16", v, vT, B, S, C)
             ops.gemm_nt(lib.ptr(q), C, k, lib.ptr(sc), S, S, S, C, [0], [0], alpha=scale, batch=B,
                         stride_a=S * C, stride_w=S * C, stride_c=S * S)
-            lib.call("siss_softmax_fwd", sc, p, B * S, S)
+            if S <= 1024:
+                lib.call("siss_softmax_fwd", sc, p, B * S, S)
+            else:                                   # long rows (the VAE's 64x64 mid attention): whole-row kernel
+                lib.call("siss_softmax_rows_fwd", sc, p, B * S, S, S, 0)
             ops.gemm_nt(lib.ptr(p), S, vT, lib.ptr(o), C, S, C, S, [0], [0], batch=B,
                         stride_a=S * S, stride_w=C * S, stride_c=S * C)
         lin(o, pre + ".to_out.0", y, rows)
@@ -678,7 +681,10 @@ class UNetEngine:
                     # dV[key][c] = sum_q P[q][key] dO[q][c]
                     lib.call("siss_gemm_tn", p, S, do[g * B * S:], C, dvf[sl], S * C, S, C, 1, lib.int_array([0]),
                              lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
-                lib.call("siss_softmax_bwd", p, dp, ds, nb * S, B * S, S, float(scale))
+                if S <= 1024:
+                    lib.call("siss_softmax_bwd", p, dp, ds, nb * S, B * S, S, float(scale))
+                else:
+                    lib.call("siss_softmax_rows_bwd", p, dp, ds, nb * S, B * S, S, S, float(scale))
                 for g in range(nb // B):
                     sl = slice(g * B, (g + 1) * B)
                     # dQ = dS K
@@ -724,7 +730,7 @@ class UNetEngine:
         for tap in range(9):
             planes.setdefault(coffs[tap] // C, []).append(tap)
         order = [tap for pl in sorted(planes) for tap in planes[pl]]
-        wds = self._ds_weights(pre, order)
+        wds = None if getattr(self, "forward_only", False) else self._ds_weights(pre, order)
 
         def bwd():
             nb, gb = self.nb, self.gbase
