@@ -57,3 +57,19 @@ def test_sample_and_denoise_match_oracle():
     rd = OS.denoise(cpu, sch.alphas_cumprod, x_T, nz, ts).permute(0, 2, 3, 1)
     d2 = (gd - rd).abs()
     assert d2.mean() < 5e-3 and torch.quantile(d2.flatten(), 0.99) < 5e-2, (float(d2.mean()), float(d2.max()))
+
+
+def test_graph_replay_equals_eager_forward():
+    """The captured forward replays to the same eps as the eager launch path (the forward is deterministic)."""
+    from siss_amd.sampler import Evaluator
+    hip, _, sch = _models()
+    g = torch.Generator().manual_seed(4)
+    x_T = torch.randn(2, 3, 16, 16, generator=g)
+    noises = [torch.randn(2, 3, 16, 16, generator=g) for _ in range(4)]
+    a, b = Evaluator(use_graph=True), Evaluator(use_graph=False)
+    a.load_model(hip, sch); b.load_model(hip, sch)
+    ga = a.sample_images(2, num_inference_steps=4, x_T=x_T, noises=noises)
+    gb = b.sample_images(2, num_inference_steps=4, x_T=x_T, noises=noises)
+    assert np.array_equal(ga, gb)
+    ga2 = a.sample_images(2, num_inference_steps=4, x_T=x_T, noises=noises)      # second use of the cached graph
+    assert np.array_equal(ga, ga2)
