@@ -189,6 +189,9 @@ def main():
     for _ in range(max(a.warmup, 1)):
         one_step()
     sync()
+    if world > 1 and os.environ.get("SISS_DP_AUTOTUNE", "1") == "1":
+        st.autotune_overlap(one_step)          # overlapped vs serial gradient exchange: keep the faster (untimed)
+        sync()
     graph = None
     # Multi-GPU: the step contains an RCCL all-reduce; capturing a collective into a hipGraph is not something
     # this repo can test (no multi-GPU box in the build loop), and the eager schedule is GPU-bound anyway
@@ -282,7 +285,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload,
                        "loss_fn": a.loss_fn, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "hipgraph": bool(use_graph)},
+                       "hipgraph": bool(use_graph),
+                       **({"dp_exchange": "overlapped" if st.overlap else "serial",
+                           "dp_autotune": getattr(st, "overlap_timings", None)} if world > 1 else {})},
             "step_tflop_algorithmic": step_tflop,
             "step_mfma_frac": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if step_tflop else None,
             "roofline": roof, "cpu_baseline": cpu,

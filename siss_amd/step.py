@@ -61,9 +61,38 @@ class SISSStepper:
         # Data-parallel overlap: the tail [split, P) of the flat gradient buffer (up / mid / deep down blocks,
         # ~85 % of the bytes) is final long before the high-resolution down blocks finish their backward;
         # its all-reduce is started from a hook inside the backward pass and runs beside the rest of it.
-        self.overlap = self.pg is not None and self.world > 1 and engine.ps.split < engine.ps.total
-        if self.overlap:
-            engine.on_early_grads_final = self._early_allreduce
+        import os
+        self.set_overlap(self.pg is not None and self.world > 1 and engine.ps.split < engine.ps.total
+                         and os.environ.get("SISS_DP_OVERLAP", "1") != "0")
+
+    def set_overlap(self, on):
+        """Overlapped (tail all-reduce started from inside the backward) or serial (one all-reduce after it)."""
+        self.overlap = bool(on)
+        self.e.on_early_grads_final = self._early_allreduce if self.overlap else None
+
+    def autotune_overlap(self, step_fn, iters=3):
+        """Measure, don't guess: the overlapped exchange shares the chip with the persistent one-block-per-CU GEMMs of
+        the high-resolution backward, and whether RCCL's workgroups cost those kernels more than the overlap hides
+        depends on the node.  Times `iters` steps each way (max over ranks) and keeps the faster setting."""
+        if self.pg is None or self.world <= 1 or self.e.ps.split >= self.e.ps.total:
+            return self.overlap
+        import time
+        dist = torch.distributed
+        results = {}
+        for mode in (True, False):
+            self.set_overlap(mode)
+            step_fn()                                            # settle
+            dist.barrier(group=self.pg); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                step_fn()
+            dist.barrier(group=self.pg); torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], device=self.e.device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
+            results[mode] = float(tt.item()) / iters
+        self.set_overlap(results[True] <= results[False])
+        self.overlap_timings = {"overlap_ms": results[True] * 1e3, "serial_ms": results[False] * 1e3}
+        return self.overlap
 
     # ------------------------------------------------------------------ one micro-batch
     def micro_step(self, x0, a0, noise, t, u, conditioning=None, erase_target=None):
