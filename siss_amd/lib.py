@@ -157,6 +157,25 @@ def _shape_key(name, a):
     return ()
 
 
+def kernel_symbol(name, a):
+    """Which device kernel a GEMM launcher call lands on (mirrors the dispatch in gemm_nt.hip / gemm_tn.hip), so
+    that bench.py can report the roofline of the dominant KERNEL under the name rocprofv3 lists it by."""
+    def triples(shifts, coffs, n):
+        return n % 3 == 0 and all(shifts[3 * g + 1] == shifts[3 * g] + 1 and shifts[3 * g + 2] == shifts[3 * g] + 2
+                                  and coffs[3 * g] == coffs[3 * g + 1] == coffs[3 * g + 2] for g in range(n // 3))
+    if name == "siss_gemm_nt":
+        M, N, Kp, npan, batch, rpi = a[10], a[11], a[12], a[13], a[20], a[16]
+        tiles = -(-M // 128) * -(-N // 128)
+        if (npan == 9 and batch == 1 and Kp % 64 == 0 and N % 128 == 0 and rpi >= 256 and tiles >= 2048
+                and triples(a[14], a[15], 9)):
+            return "gemm_nt_c3p_kernel"
+        return "gemm_nt_kernel"
+    if name == "siss_gemm_tn":
+        rows = a[15] - a[14]
+        return "gemm_tn_kernel<3>" if triples(a[9], a[10], a[8]) and (a[16] > 0 or rows >= 8192) else "gemm_tn_kernel<1>"
+    return name
+
+
 def call(name, *args):
     """Call a launcher on torch's current stream; tensors are passed as raw pointers."""
     lib = load()
@@ -167,7 +186,7 @@ def call(name, *args):
         s.record()
         rc = fn(*conv, stream_ptr())
         e.record()
-        PROF.append((name, s, e, _work(name, args), _shape_key(name, args)))
+        PROF.append((name, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args)))
     else:
         rc = fn(*conv, stream_ptr())
     if rc != 0:
