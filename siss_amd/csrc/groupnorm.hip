@@ -231,16 +231,27 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
         const bf16_t* xb = x + (long)n * rpi * s.ld + c0 + cc * 8;
-        for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
-            // all loads of this pixel (x + one dy per set) are issued before the first use
-            const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.ld);
-            u32x4_t rd[SETS];
+        // Software pipeline: the loads of pixel i+1 (x + one dy per set) are issued BEFORE pixel i is consumed, so
+        // the memory pipe never drains while the SiLU' arithmetic runs (4-5 waves per SIMD only).
+        PixelWalk w(s, chunk, slot);
+        u32x4_t nx_x = u32x4_t{0u, 0u, 0u, 0u}, nx_d[SETS];
+        auto issue = [&](const PixelWalk& q, u32x4_t& ox, u32x4_t (&od)[SETS]) {
+            ox = *reinterpret_cast<const u32x4_t*>(xb + q.row() * s.ld);
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
                 const int n2 = k * nx + n;
-                const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : (long)n2 * rpi + w.row();
-                rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.ld + cc * 8);
+                const long drow = dy_compact ? compact_row(n2, q.pi, s.H, s.W) : (long)n2 * rpi + q.row();
+                od[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.ld + cc * 8);
             }
+        };
+        if (w.ok()) issue(w, nx_x, nx_d);
+        while (w.ok()) {
+            const u32x4_t rx = nx_x;
+            u32x4_t rd[SETS];
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) rd[k] = nx_d[k];
+            w.next();
+            if (w.ok()) issue(w, nx_x, nx_d);
             float v[8], xh[8], dsl[8];
             unpack8(rx, v);
 #pragma unroll
@@ -326,26 +337,41 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
         const long rpi = (long)(s.H + 2) * (s.W + 2);
         const bf16_t* xb = x + (long)n * rpi * s.ld + c0 + cc * 8;
         const int ch = c0 + cc * 8;                       // first channel of this lane in the full tensor
-        for (PixelWalk w(s, chunk, slot); w.ok(); w.next()) {
-            const u32x4_t rx = *reinterpret_cast<const u32x4_t*>(xb + w.row() * s.ld);
-            // Output routing: one tensor of C channels, or (dx2 != null: the input was a channel concat)
-            // channels [0, split_c) -> dx (row stride split_c) and [split_c, C) -> dx2 (row stride C - split_c,
-            // optionally accumulated): the concat backward costs no extra pass.
-            const bool second = dx2 != nullptr && ch >= split_c;
-            bf16_t* const obase = second ? dx2 + (ch - split_c) : dx + ch;
-            const int ostride = dx2 ? (second ? s.ld - split_c : split_c) : s.ld;
-            const bool oacc = second && accumulate2;
-            u32x4_t rd[SETS], ra[SETS], rb[SETS], rc[SETS];
+        // Output routing: one tensor of C channels, or (dx2 != null: the input was a channel concat)
+        // channels [0, split_c) -> dx (row stride split_c) and [split_c, C) -> dx2 (row stride C - split_c,
+        // optionally accumulated): the concat backward costs no extra pass.
+        const bool second = dx2 != nullptr && ch >= split_c;
+        bf16_t* const obase = second ? dx2 + (ch - split_c) : dx + ch;
+        const int ostride = dx2 ? (second ? s.ld - split_c : split_c) : s.ld;
+        const bool oacc = second && accumulate2;
+        // Software pipeline (as in the stats kernel): pixel i+1's loads are in flight while pixel i is computed and
+        // stored.  Reading the next pixel's accum / output before this pixel's store is safe: different rows.
+        struct In { u32x4_t x, d[SETS], a[SETS], b[SETS], c[SETS]; };
+        auto issue = [&](const PixelWalk& q, In& o) {
+            o.x = *reinterpret_cast<const u32x4_t*>(xb + q.row() * s.ld);
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
                 const int n2 = k * nx + n;
-                const long orow = (long)n2 * rpi + w.row();
-                const long drow = dy_compact ? compact_row(n2, w.pi, s.H, s.W) : orow;
-                rd[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.ld + ch);
-                ra[k] = accum ? *reinterpret_cast<const u32x4_t*>(accum + orow * s.ld + ch) : u32x4_t{0u, 0u, 0u, 0u};
-                rb[k] = accum2 ? *reinterpret_cast<const u32x4_t*>(accum2 + orow * s.ld + ch) : u32x4_t{0u, 0u, 0u, 0u};
-                rc[k] = oacc ? *reinterpret_cast<const u32x4_t*>(obase + orow * ostride) : u32x4_t{0u, 0u, 0u, 0u};
+                const long orow = (long)n2 * rpi + q.row();
+                const long drow = dy_compact ? compact_row(n2, q.pi, s.H, s.W) : orow;
+                o.d[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.ld + ch);
+                o.a[k] = accum ? *reinterpret_cast<const u32x4_t*>(accum + orow * s.ld + ch) : u32x4_t{0u, 0u, 0u, 0u};
+                o.b[k] = accum2 ? *reinterpret_cast<const u32x4_t*>(accum2 + orow * s.ld + ch) : u32x4_t{0u, 0u, 0u, 0u};
+                o.c[k] = oacc ? *reinterpret_cast<const u32x4_t*>(obase + orow * ostride) : u32x4_t{0u, 0u, 0u, 0u};
             }
+        };
+        PixelWalk w(s, chunk, slot);
+        In nxt;
+        if (w.ok()) issue(w, nxt);
+        while (w.ok()) {
+            const In cur = nxt;
+            const long wrow = w.row();
+            w.next();
+            if (w.ok()) issue(w, nxt);
+            const u32x4_t rx = cur.x;
+            u32x4_t rd[SETS], ra[SETS], rb[SETS], rc[SETS];
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) { rd[k] = cur.d[k]; ra[k] = cur.a[k]; rb[k] = cur.b[k]; rc[k] = cur.c[k]; }
             float v[8], xh[8], dsl[8];
             unpack8(rx, v);
 #pragma unroll
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
             }
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
-                const long orow = (long)(k * nx + n) * rpi + w.row();
+                const long orow = (long)(k * nx + n) * rpi + wrow;
                 float d[8], r[8], r2[8], r3[8], o[8];
                 unpack8(rd[k], d); unpack8(ra[k], r); unpack8(rb[k], r2); unpack8(rc[k], r3);
 #pragma unroll
