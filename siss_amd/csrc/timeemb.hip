@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxM = 64;
+constexpr int kMaxM = 4096;     // sanity cap on the batch rows (the kernels walk rows in chunks)
 
 __global__ void sincos_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim, int flip,
                               float freq_shift) {
@@ -157,6 +157,9 @@ __global__ __launch_bounds__(256) void multi_bwd_dx_kernel(const float* __restri
     __shared__ float shd[64][65];   // [m][col]
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int n0 = blockIdx.y * 64;
+    const int mb = blockIdx.z * 64;                     // 64 cotangent rows per block (any batch size)
+    dy += (long)mb * Ntot; dx += (long)mb * K;
+    M2 = M2 - mb < 64 ? M2 - mb : 64;
     for (int i = threadIdx.x; i < M2 * 64; i += 256) {
         const int m = i / 64, c = i - m * 64;
         shd[m][c] = (n0 + c < Ntot) ? dy[(long)m * Ntot + n0 + c] : 0.f;
@@ -221,11 +224,11 @@ int siss_linear_multi_bwd(const float* dy, const float* x, const float* params, 
                           const long* boff, const long* boff2, float* dx, int M2, int Mx, int set_rows,
                           long set_stride, int Ntot, int K, void* stream) {
     SISS_CHECK_ARG(dy && x && params && grads && woff && boff && boff2 && dx);
-    SISS_CHECK_ARG(M2 > 0 && M2 <= 64 && Mx > 0 && set_rows > 0 && M2 % set_rows == 0 && Ntot > 0 && K > 0);
+    SISS_CHECK_ARG(M2 > 0 && M2 <= kMaxM && Mx > 0 && set_rows > 0 && M2 % set_rows == 0 && Ntot > 0 && K > 0);
     hipStream_t st = (hipStream_t)stream;
     const long tot = (long)(M2 / set_rows) * Ntot * K;
     multi_bwd_dw_kernel<<<cdiv(tot, 256), 256, 0, st>>>(dy, x, grads, woff, boff, boff2, M2, Mx, set_rows, set_stride, Ntot, K);
-    dim3 grid(cdiv(K, 256), cdiv(Ntot, 64));
+    dim3 grid(cdiv(K, 256), cdiv(Ntot, 64), cdiv(M2, 64));
     multi_bwd_dx_kernel<<<grid, 256, 0, st>>>(dy, params, woff, dx, M2, Ntot, K);
     SISS_LAUNCH_RET();
 }

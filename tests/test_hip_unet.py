@@ -309,3 +309,32 @@ def test_mnist_tshirt_config_step_matches_oracle():
                             [mb], train_batch_size=B, scaling_norm=5.0, loss_params={"lambd": 0.5}, inf_guard=True)
     st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
     _check_scalars(r, st.stats())
+
+
+def test_mnist_tshirt_config_at_yaml_batch_64():
+    """config/delete_tshirt.yaml's own train_batch_size (64; BASELINE quotes 32): 128 cotangent rows through the
+    batched time-embedding backward and the per-(sample, head) attention kernels, against the oracle step."""
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.step import SISSStepper
+    from siss_amd.unet import UNetEngine
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    from oracle.unet import OracleUNet2D, UNetConfig
+    eng = UNetEngine(UNet2DConfig.mnist_tshirt(), "cuda:0")
+    sd = eng.init_random(seed=12)
+    net = OracleUNet2D(UNetConfig.mnist_tshirt())
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(47)
+    B = 64
+    ac = S.alphas_cumprod()
+    opt = torch.optim.AdamW(net.parameters(), lr=5e-5, betas=(0.95, 0.999), weight_decay=1e-6)
+    st = SISSStepper(eng, ac, lr=5e-5, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
+                     train_batch_size=B, inf_guard=True, mixed_precision=None)
+    mb = dict(x0=torch.rand(B, 1, 28, 28, generator=g) * 2 - 1, a0=torch.rand(B, 1, 28, 28, generator=g) * 2 - 1,
+              noise=torch.randn(B, 1, 28, 28, generator=g), t=torch.randint(900, 1000, (B,), generator=g),
+              u=torch.rand(B, generator=g))
+    r, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), "importance_sampling_with_mixture", ac,
+                            [mb], train_batch_size=B, scaling_norm=5.0, loss_params={"lambd": 0.5}, inf_guard=True)
+    st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+    _check_scalars(r, st.stats())
