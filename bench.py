@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE: 16)")
+    ap.add_argument("--grad-accum", type=int, default=1,
+                    help="micro-batches per optimizer step (config/delete_celeb.yaml ships 16 x batch 4; BASELINE: 1)")
     ap.add_argument("--config", default="celebahq256", choices=["celebahq256", "small", "sd15"],
                     help="celebahq256 = the BASELINE metric's workload (configs[1]); sd15 = BASELINE configs[4] "
                          "(SD v1.5 UNet, 64x64 latents, text conditioning) as a secondary measurement")
@@ -161,7 +163,7 @@ def main():
         # the VAE scaling factor 0.18215 (delete_sd.py:883,888); ONE prompt embedding repeated (delete_sd.py:941-944)
         ac = torch.cumprod(1.0 - torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2, 0)
         st = SISSStepper(eng, ac, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, scaling_norm=750.0,
-                         lambd=0.5, train_batch_size=B, grad_accum=1, loss_fn=a.loss_fn, process_group=pg,
+                         lambd=0.5, train_batch_size=B, grad_accum=a.grad_accum, loss_fn=a.loss_fn, process_group=pg,
                          mixed_precision="bf16")
         x0 = (0.18215 * torch.randn(B, cin, hw, hw, generator=g, device=dev)).to(torch.bfloat16)
         a0 = (0.18215 * torch.randn(1, cin, hw, hw, generator=g, device=dev)).repeat(B, 1, 1, 1).to(torch.bfloat16)
@@ -170,7 +172,7 @@ def main():
     else:
         ac = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, 1000, dtype=torch.float32), 0)
         st = SISSStepper(eng, ac, lr=5e-6, betas=(0.95, 0.999), eps=1e-8, weight_decay=1e-6,   # delete_celeb.yaml:127-133
-                         scaling_norm=500.0, lambd=0.5, train_batch_size=B, grad_accum=1, loss_fn=a.loss_fn,
+                         scaling_norm=500.0, lambd=0.5, train_batch_size=B, grad_accum=a.grad_accum, loss_fn=a.loss_fn,
                          process_group=pg, mixed_precision="bf16")
         x0 = (torch.rand(B, cin, hw, hw, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
         a0 = (torch.rand(1, cin, hw, hw, generator=g, device=dev) * 2 - 1).repeat(B, 1, 1, 1).to(torch.bfloat16)
@@ -179,7 +181,8 @@ def main():
     u = torch.rand(B, generator=g, device=dev)
 
     def one_step():
-        st.step(x0, a0, noise, t, u, cond)
+        for _ in range(a.grad_accum):              # the same resident micro-batch GA times: one optimizer update
+            st.micro_step(x0, a0, noise, t, u, cond)
 
     def sync():
         if world > 1:
@@ -276,24 +279,25 @@ def main():
 
     if rank == 0:
         steps_per_sec = 1e3 / ms
-        step_tflop = 5 * FWD_GFLOP_PER_SAMPLE * B / 1e3 if a.config == "celebahq256" else (
-            5 * SD_FWD_GFLOP_PER_SAMPLE * B / 1e3 if sd else None)
+        GA = a.grad_accum
+        step_tflop = 5 * FWD_GFLOP_PER_SAMPLE * B * GA / 1e3 if a.config == "celebahq256" else (
+            5 * SD_FWD_GFLOP_PER_SAMPLE * B * GA / 1e3 if sd else None)
         workload = {"celebahq256": "delete_celeb.yaml: CelebA-HQ 256x256 DDPM UNet (113.7M params), SISS lambd=0.5, "
-                                   "t=999, bf16, bs=%d/GPU, GA=1, scaling_norm=500, AdamW lr 5e-6" % B,
+                                   "t=999, bf16, bs=%d/GPU, GA=%d, scaling_norm=500, AdamW lr 5e-6" % (B, GA),
                     "sd15": "delete_sd.yaml: Stable Diffusion v1.5 UNet (859.5M params), 64x64x4 latents + 77x768 text "
-                            "embedding, SISS lambd=0.5, t=999, bf16, bs=%d/GPU, GA=1, scaling_norm=750, AdamW lr 1e-5, "
-                            "no gradient checkpointing (activations kept in HBM)" % B,
+                            "embedding, SISS lambd=0.5, t=999, bf16, bs=%d/GPU, GA=%d, scaling_norm=750, AdamW lr 1e-5, "
+                            "no gradient checkpointing (activations kept in HBM)" % (B, GA),
                     "small": "small 64x64 dev config"}[a.config]
         out = {
             "metric": "unlearning samples/sec (= unlearning-steps/sec x batch x gpus), "
                       + ("SD-v1.5 UNet SISS (secondary; BASELINE metric is the CelebA-HQ line)" if sd else "CelebA-HQ-256 DDPM SISS"),
-            "value": round(steps_per_sec * B * world, 3), "unit": "samples/sec", "n_gpus": world,
+            "value": round(steps_per_sec * B * GA * world, 3), "unit": "samples/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "steps_per_sec": round(steps_per_sec, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": workload,
-                       "loss_fn": a.loss_fn, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "loss_fn": a.loss_fn, "global_batch": B * GA * world, "grad_accum": GA, "parallelism": f"dp{world}",
                        "hipgraph": bool(use_graph),
                        **({"dp_exchange": "overlapped" if st.overlap else "serial",
                            "dp_autotune": getattr(st, "overlap_timings", None)} if world > 1 else {})},
