@@ -338,3 +338,26 @@ def test_mnist_tshirt_config_at_yaml_batch_64():
                             [mb], train_batch_size=B, scaling_norm=5.0, loss_params={"lambd": 0.5}, inf_guard=True)
     st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
     _check_scalars(r, st.stats())
+
+
+@pytest.mark.parametrize("lambd,B", [(0.0, 4), (1.0, 4), (0.5, 1), (0.3, 3)])
+def test_siss_step_edge_cases_match_oracle(setup, lambd, B):
+    """Edges of the defensive mixture: lambd = 0 (every row keeps; iw_x = 1, the forget term still carries
+    iw_a = e^d), lambd = 1 (every row forgets), a single-sample batch, an odd batch with an uneven mask."""
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    eng, net, sd = _fresh(setup)
+    ac = S.alphas_cumprod()
+    okw = dict(lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6)
+    opt = torch.optim.AdamW(net.parameters(), **okw)
+    st = SISSStepper(eng, ac, scaling_norm=5.0, lambd=lambd, train_batch_size=B, mixed_precision=None, **okw)
+    mb = _batch(torch.Generator().manual_seed(int(lambd * 10) + B), B=B)
+    ref, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), "importance_sampling_with_mixture", ac,
+                              [mb], train_batch_size=B, scaling_norm=5.0, loss_params={"lambd": lambd})
+    st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+    got = st.stats()
+    _check_scalars(ref, got)
+    inv = (1 - lambd) * st.last["iw_x"] + lambd * st.last["iw_a"]
+    assert torch.allclose(inv.cpu(), torch.ones(B), atol=1e-4)
