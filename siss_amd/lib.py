@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsiss_hip.so")
+LIB_PATH = os.environ.get("SISS_LIB_PATH") or os.path.join(_HERE, "libsiss_hip.so")   # override: A/B two builds
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
 IP = C.POINTER(C.c_int)
