@@ -142,3 +142,74 @@ def batches(dataset, sampler, batch_size):
             if len(buf) == batch_size:
                 yield torch.stack(buf)
                 buf = []
+
+
+class Prefetcher:
+    """Background batch pipeline for real-image runs: samples are decoded / transformed by a
+    small thread pool (PIL decoding releases the GIL), stacked into PINNED host buffers and copied to the device on a
+    dedicated copy stream, `depth` batches ahead of the consumer -- at 66 ms per step a synchronous loop would spend
+    more time decoding 32 JPEGs than the GPU spends on the step.  The batch ORDER is exactly that of
+    ``batches(dataset, sampler, batch_size)`` (one producer walks the sampler).  Iterating yields device tensors;
+    on a CPU `device` it degrades to plain background loading."""
+
+    def __init__(self, dataset, sampler, batch_size, device="cuda", depth=3, workers=4):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.dataset, self.sampler, self.batch_size = dataset, sampler, int(batch_size)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._stop = threading.Event()
+        self._err = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            idx = []
+            for i in self.sampler:
+                if self._stop.is_set():
+                    return
+                idx.append(i)
+                if len(idx) < self.batch_size:
+                    continue
+                items = list(self.pool.map(self.dataset.__getitem__, idx))
+                idx = []
+                host = torch.stack(items)
+                if self.cuda:
+                    host = host.pin_memory()
+                    with torch.cuda.stream(self.copy_stream):
+                        dev = host.to(self.device, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(self.copy_stream)
+                    item = (dev, ev, host)              # keep the pinned source alive until the copy is consumed
+                else:
+                    item = (host, None, None)
+                while not self._stop.is_set():
+                    try:
+                        self.q.put(item, timeout=0.1)
+                        break
+                    except Exception:
+                        continue
+        except BaseException as e:                      # surfaced to the consumer, never swallowed
+            self._err = e
+            self.q.put(None)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self.q.get()
+        if item is None:
+            raise RuntimeError("data prefetch thread failed") from self._err
+        dev, ev, _ = item
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return dev
+
+    def close(self):
+        self._stop.set()
+        self.pool.shutdown(wait=False, cancel_futures=True)

@@ -15,7 +15,7 @@ import torch
 
 from . import hydra_lite
 from .config import UNet2DConditionConfig, UNet2DConfig
-from .data import InfiniteSampler, RepeatedSampler, SyntheticImages, batches
+from .data import InfiniteSampler, Prefetcher, RepeatedSampler, SyntheticImages, batches
 from .scheduler import DDPMScheduler
 from .step import SISSStepper
 
@@ -122,7 +122,10 @@ class _DeleteBase(Task):
             superfactor=float((d.loss_params or {}).get("superfactor", 1.0)))
         shape = (unet.config.in_channels, unet.config.sample_size, unet.config.sample_size)
         ds_all, ds_del = self.datasets(shape)
-        it_all = batches(ds_all, InfiniteSampler(ds_all, rank=rank, num_replicas=world), B)
+        # keep shard: decoded / pinned / copied in the background, `depth` batches ahead (the forget set is one or a
+        # few images repeated: a plain iterator is enough)
+        it_all = Prefetcher(ds_all, InfiniteSampler(ds_all, rank=rank, num_replicas=world), B, device=device,
+                            workers=int(cfg.get("dataloader_num_workers") or 4))
         it_del = batches(ds_del, self.deletion_sampler(ds_del, B), B)
         n_steps = int(cfg.training_steps) * max(1, len(d.get("img_name") or [1]))
         cond = self.conditioning(B, device)
@@ -147,6 +150,7 @@ class _DeleteBase(Task):
             if rank == 0:
                 print(f"step {step + 1}/{n_steps}  |g_x| {st['norm_loss_x']:.4g}  |g_a| {st['norm_loss_a']:.4g}  "
                       f"s {st['scaling_factor']:.4g}")
+        it_all.close()
         if rank == 0 and cfg.get("save_final", True):
             unet.save_pretrained(os.path.join(cfg.output_dir, "unet"))
         return stepper

@@ -83,3 +83,33 @@ def test_save_and_reload_pretrained(tmp_path):
     assert (a - b).abs().max() <= 2e-2 * a.abs().max()
     sd1, sd2 = m.state_dict(), m2.state_dict()
     assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+
+
+def test_delete_celeb_entry_point_on_a_jpeg_directory(tmp_path):
+    """`python main.py --config-name=delete_celeb ...` end to end on real files: a directory of JPEGs through the
+    reference's dataset / transform targets (CelebAHQ filter all / deletion, ToTensor + Normalize), the rank-sharded
+    infinite sampler and the background prefetcher, two optimizer steps with gradient accumulation, final save in
+    the diffusers layout."""
+    import json
+    import os
+    import sys
+    import numpy as np
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import main as entry
+    data = tmp_path / "celeba"
+    data.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(10):
+        Image.fromarray(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)).save(data / f"{10000 + i}.jpg")
+    out = tmp_path / "out"
+    entry.main(["--config-name=delete_celeb", f"data_dir={data}", f"output_dir={out}", "training_steps=2",
+                "train_batch_size=2", "gradient_accumulation_steps=2", "checkpoint_path=/nonexistent",
+                "unet.sample_size=16", "unet.block_out_channels=[64,128]",
+                "unet.down_block_types=[DownBlock2D,AttnDownBlock2D]", "unet.up_block_types=[AttnUpBlock2D,UpBlock2D]",
+                "unet.layers_per_block=1", "unet.attention_head_dim=null"])
+    run = [d for d in os.listdir(out)][0]                       # main.py appends <timestamp>_<uuid> (main.py:21-28)
+    lines = [json.loads(l) for l in open(out / run / "train_log_rank0.jsonl")]
+    assert len(lines) == 2 and all(abs(s["scaling_factor"] * s["norm_loss_a"] - 500.0) < 0.5 for s in lines)
+    assert os.path.exists(out / run / "unet" / "diffusion_pytorch_model.safetensors")

@@ -87,6 +87,26 @@ def test_samplers_shard_by_rank():
     assert b.shape == (4, 1, 2, 2)
 
 
+def test_prefetcher_keeps_the_batch_order_of_the_plain_iterator():
+    from siss_amd.data import InfiniteSampler, Prefetcher, SyntheticImages, batches
+    ds = SyntheticImages(23, (3, 8, 8), seed=5)
+    ref = batches(ds, InfiniteSampler(ds, rank=1, num_replicas=2), 4)
+    pf = Prefetcher(ds, InfiniteSampler(ds, rank=1, num_replicas=2), 4, device="cpu", depth=2, workers=3)
+    for _ in range(9):
+        assert torch.equal(next(pf), next(ref))
+    pf.close()
+
+    class Broken(SyntheticImages):
+        def __getitem__(self, i):
+            raise OSError("unreadable image")
+    bad = Prefetcher(Broken(4, (1, 2, 2)), InfiniteSampler(ds), 2, device="cpu")
+    try:
+        next(bad)
+        raise AssertionError("the loader error must surface")
+    except RuntimeError as e:
+        assert isinstance(e.__cause__, OSError)
+
+
 def test_param_layout_maps_roundtrip():
     from siss_amd.unet import ParamStore
     ps = ParamStore()
