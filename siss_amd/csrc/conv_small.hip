@@ -123,33 +123,64 @@ __global__ __launch_bounds__(kThreads) void conv_out_fprop_mfma_kernel(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int px = lane & 15, kg = lane >> 4;
     const int segs = (W + 15) >> 4, Wp = W + 2, kchunks = C >> 5;
-    const long nseg = (long)B * H * segs;
     const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long seg = (long)blockIdx.x * (kThreads / 64) + wv; seg < nseg; seg += (long)gridDim.x * (kThreads / 64)) {
-        const int sx = seg % segs; long t = seg / segs;
-        const int y = t % H; const int n = t / H;
+    // Work item = a band of kBand image rows x one 16-pixel column segment, walked top to bottom by ONE wave: rows
+    // y-1 / y / y+1 of consecutive steps overlap, so each input row is fetched from HBM once and re-read from
+    // L1 / L2 (the first version strode whole-image segments over the grid and pulled 6.6x the activation bytes
+    // from HBM: profiles/r01j_hbm_traffic.json).  Items are handed out XCD-contiguously (blocks b, b+8, ... share
+    // an L2), neighbouring column segments to the four waves of a block.
+    constexpr int kBand = 4;
+    const int bands = (H + kBand - 1) / kBand;
+    const long nitems = (long)B * bands * segs;
+    const long nblk = gridDim.x;
+    long bid = blockIdx.x;
+    { const long q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3; bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k; }
+    for (long item = bid * (kThreads / 64) + wv; item < nitems; item += nblk * (kThreads / 64)) {
+      const int sx = item % segs; long tt = item / segs;
+      const int band = tt % bands; const int n = tt / bands;
+      const int y_end = (band + 1) * kBand < H ? (band + 1) * kBand : H;
+      for (int y = band * kBand; y < y_end; ++y) {
         const int xx = sx * 16 + px;
         const bool ok = xx < W;
         const int xc = ok ? xx : W - 1;
         const bf16_t* base = x + (((long)n * (H + 2) + y + 1) * Wp + xc + 1) * C + kg * 8;
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        // One filter row (three kx taps) x four 32-channel chunks at a time: the 12 activation loads are all issued
+        // before the first MFMA consumes one (a load -> MFMA -> load chain exposed a full memory round trip 36
+        // times per pixel row and ran this kernel at 1/5 of the HBM rate); two accumulators break the MFMA chain.
+        f32x4_t acc2 = {0.f, 0.f, 0.f, 0.f};
+        for (int kc0 = 0; kc0 < kchunks; kc0 += 4) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const bf16_t* bp = base + (long)((tap / 3 - 1) * Wp + (tap % 3 - 1)) * C;
-            const bf16_t* ap = sw + (tap * CO + (px < CO ? px : 0)) * C + kg * 8;
-#pragma unroll 4
-            for (int kc = 0; kc < kchunks; ++kc) {
-                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(bp + kc * 32);
-                bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ap + kc * 32);
-                if (px >= CO) a = zero;
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            for (int ky = 0; ky < 3; ++ky) {
+                bf16x8_t bf[3][4];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bf16_t* bp = base + (long)((ky - 1) * Wp + (kx - 1)) * C;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bf[kx][j] = kc0 + j < kchunks ? *reinterpret_cast<const bf16x8_t*>(bp + (kc0 + j) * 32) : zero;
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bf16_t* ap = sw + ((ky * 3 + kx) * CO + (px < CO ? px : 0)) * C + kg * 8;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x8_t a = kc0 + j < kchunks ? *reinterpret_cast<const bf16x8_t*>(ap + (kc0 + j) * 32) : zero;
+                        if (px >= CO) a = zero;
+                        if (j & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[kx][j], acc2, 0, 0, 0);
+                        else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[kx][j], acc, 0, 0, 0);
+                    }
+                }
             }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
         // acc[r] = output channel 4*(lane>>4) + r of pixel lane&15
         if (kg == 0 && ok) {
 #pragma unroll
             for (int r = 0; r < CO; ++r) pred[(((long)n * CO + r) * H + y) * W + xx] = acc[r] + bias[r];
         }
+      }
     }
 }
 
@@ -274,7 +305,7 @@ int siss_conv_out_fprop(const void* x, const float* w, const float* bias, float*
     static int use_mfma = -1;
     if (use_mfma < 0) { const char* e = getenv("SISS_CONV_OUT_MFMA"); use_mfma = e ? atoi(e) : 1; }
     if (use_mfma && C % 32 == 0) {
-        long nb = ((long)B * H * ((W + 15) / 16) + 3) / 4;
+        long nb = ((long)B * ((H + 3) / 4) * ((W + 15) / 16) + 3) / 4;        // 4-row x 16-pixel items, 4 per block
         if (nb > 256 * 8) nb = 256 * 8;
         DISPATCH_CO(CO, (conv_out_fprop_mfma_kernel<kCO><<<(int)nb, kThreads, 9 * kCO * C * sizeof(bf16_t), st>>>((const bf16_t*)x, w, bias, pred, B, H, W, C)));
         SISS_LAUNCH_RET();
