@@ -168,7 +168,10 @@ struct WtJob { long src, dst; int taps, co, ci, tile0; };
 
 __global__ void conv_weight_dgrad_multi_kernel(const float* __restrict__ flat, bf16_t* __restrict__ wt_all,
                                                const WtJob* __restrict__ jobs, int njobs) {
-    __shared__ float tile[32][33];
+    // 64 x 64 tiles (256-B reads, 128-B bf16 writes): with 32 x 32 tiles the per-block job lookup below (a
+    // dependent walk of ~8 L2 reads) cost as much as the tile's own traffic (2.8 TB/s measured)
+    constexpr int TS = 64;
+    __shared__ float tile[TS][TS + 1];
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -176,17 +179,17 @@ __global__ void conv_weight_dgrad_multi_kernel(const float* __restrict__ flat, b
     }
     const WtJob j = jobs[lo];
     int t = blockIdx.x - j.tile0;
-    const int tc = (j.ci + 31) / 32, to = (j.co + 31) / 32;
+    const int tc = (j.ci + TS - 1) / TS, to = (j.co + TS - 1) / TS;
     const int tap = t / (tc * to); t -= tap * tc * to;
-    const int o0 = (t / tc) * 32, c0 = (t % tc) * 32;
+    const int o0 = (t / tc) * TS, c0 = (t % tc) * TS;
     const float* src = flat + j.src + (long)tap * j.co * j.ci;
     bf16_t* dst = wt_all + j.dst + (long)(j.taps - 1 - tap) * j.co * j.ci;
-    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    for (int r = threadIdx.y; r < TS; r += blockDim.y) {
         const int o = o0 + r, c = c0 + threadIdx.x;
         tile[r][threadIdx.x] = (o < j.co && c < j.ci) ? src[(long)o * j.ci + c] : 0.f;
     }
     __syncthreads();
-    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    for (int r = threadIdx.y; r < TS; r += blockDim.y) {
         const int c = c0 + r, o = o0 + threadIdx.x;
         if (c < j.ci && o < j.co) dst[(long)c * j.co + o] = f2bf(tile[threadIdx.x][r]);
     }
@@ -246,11 +249,11 @@ int siss_conv_weight_dgrad_layout(const float* w, void* wt, int taps, int co, in
 }
 
 // jobs: device array of njobs records {long src_off, long dst_off, int taps, int co, int ci, int tile0}
-// (tile0 = running sum of taps*ceil(co/32)*ceil(ci/32)); total_tiles = the grid size.
+// (tile0 = running sum of taps*ceil(co/64)*ceil(ci/64)); total_tiles = the grid size.
 int siss_conv_weight_dgrad_multi(const float* flat, void* wt_all, const void* jobs, int njobs, int total_tiles,
                                  void* stream) {
     SISS_CHECK_ARG(flat && wt_all && jobs && njobs > 0 && total_tiles > 0);
-    conv_weight_dgrad_multi_kernel<<<total_tiles, dim3(32, 8), 0, (hipStream_t)stream>>>(
+    conv_weight_dgrad_multi_kernel<<<total_tiles, dim3(64, 4), 0, (hipStream_t)stream>>>(
         flat, reinterpret_cast<bf16_t*>(wt_all), reinterpret_cast<const WtJob*>(jobs), njobs);
     SISS_LAUNCH_RET();
 }

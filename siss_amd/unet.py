@@ -343,7 +343,7 @@ class UNetEngine:
                 t, co, ci = sp.native_shape if sp.kind == "conv3" else (1, *sp.native_shape)
                 jobs.append((n, sp.off, off, t, co, ci, tiles))
                 off += -(-t * co * ci // 64) * 64
-                tiles += t * (-(-co // 32)) * (-(-ci // 32))
+                tiles += t * (-(-co // 64)) * (-(-ci // 64))        # 64 x 64 tiles: optimizer.hip conv_weight_dgrad_multi_kernel
         self._wt_all = torch.empty(off, dtype=torch.bfloat16, device=self.device)
         rec = np.zeros(len(jobs), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("co", "<i4"),
                                                    ("ci", "<i4"), ("tile0", "<i4")]))
