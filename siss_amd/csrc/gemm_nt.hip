@@ -315,12 +315,13 @@ int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
     return SISS_OK;
 }
 
-// Flat argument list (ctypes-friendly).  shifts/coffs are HOST arrays of npanels ints.
-// Returns SISS_ERR_ARG for shapes the kernel does not cover (Kp % 64, alignment, panel count).
-int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
-                 const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
-                 const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
-                 int batch, long strideA, long strideW, long strideC, void* stream) {
+}  // extern "C"
+
+namespace {
+int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+                     const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
+                     const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
+                     int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
     SISS_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % BK == 0 && npanels >= 1 && npanels <= kMaxPanels);
     SISS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0) && batch >= 1);
@@ -337,6 +338,8 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
     p.ksplit = 1; p.slab = nullptr;
+    p.rowsub = rowsub; p.mul_r = mul_r;
+    SISS_CHECK_ARG(!mul_r || (R && Hp == 0));              // the multiplicative epilogue has no halo form
     { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     SISS_CHECK_ARG((!rowbias && Hp == 0) || rows_per_image >= 64);   // <= 3 images per 128/256-row tile
     SISS_CHECK_ARG(N % 8 == 0 && (!rowbias || ldrb % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0));
@@ -344,7 +347,7 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
     // 3x3 filters on large grids: the fused-tap kernel (A tile shared by the three kx taps)
     {
-        bool conv3 = npanels == 9 && batch == 1 && Kp % 32 == 0;
+        bool conv3 = npanels == 9 && batch == 1 && Kp % 32 == 0 && !rowsub && !mul_r;
         for (int g = 0; conv3 && g < 3; ++g)
             conv3 = p.shift[3 * g + 1] == p.shift[3 * g] + 1 && p.shift[3 * g + 2] == p.shift[3 * g] + 2 &&
                     p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
@@ -409,6 +412,31 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
     if (small < 0) { const char* e = getenv("SISS_NT_SMALL"); small = e ? atoi(e) : 0; }   // opt-in: measured +-5 % (these layers are K-latency-bound, not block-count-bound)
     if (small && tiles128 < 256) return launch_nt<64, 2, 2>(p, batch, (hipStream_t)stream);
     return launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" {
+
+// Flat argument list (ctypes-friendly).  shifts/coffs are HOST arrays of npanels ints.
+// Returns SISS_ERR_ARG for shapes the kernel does not cover (Kp % 64, alignment, panel count).
+int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+                 const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
+                 const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
+                 int batch, long strideA, long strideW, long strideC, void* stream) {
+    return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, Kp, npanels, shifts, coffs,
+                            rows_per_image, Hp, Wp, alpha, batch, strideA, strideW, strideC, nullptr, 0, stream);
+}
+
+// Same product with the attention-backward epilogue  C = R o (alpha * (acc - rowsub[row]))  (R: bf16 [batch][M][N]
+// with C's strides, rowsub: f32 [batch][M]):  dS = scale * P o (dO V^T - delta), delta = rowsum(dO o O), in ONE pass --
+// the dP matrix is never written and the separate softmax-backward pass over P / dP / dS disappears.
+int siss_gemm_nt_mulsub(const void* A, long lda, const void* W, void* C, long ldc, const void* R, long ldr,
+                        const float* rowsub, int M, int N, int Kp, float alpha, int batch, long strideA, long strideW,
+                        long strideC, void* stream) {
+    SISS_CHECK_ARG(R && rowsub);
+    static const int zero = 0;
+    return gemm_nt_dispatch(A, lda, W, C, ldc, nullptr, nullptr, N, R, ldr, M, N, Kp, 1, &zero, &zero, 1, 0, 0, alpha,
+                            batch, strideA, strideW, strideC, rowsub, 1, stream);
 }
 
 }  // extern "C"

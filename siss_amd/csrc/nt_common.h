@@ -17,6 +17,8 @@ struct NTParams {
     int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
     float alpha, inv_wp;
     int ablate;
+    const float* rowsub;              // optional f32 [batch][M]: subtracted from the accumulator row before alpha
+    int mul_r;                        // 1: the epilogue MULTIPLIES by R instead of adding it  (C = R o (alpha (acc - rowsub)))
     int ksplit;                       // > 1: split-K -- gridDim.y blocks per tile write f32 partial tiles to `slab`
     float* slab;                      //      ([tile][split][BM*BN] in accumulator order), gemm_nt_reduce_kernel finishes
     long long* dbg;                   // timing probe buffer (SISS_NT_DEBUG_PTR), normally null
@@ -57,6 +59,8 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const int m = wm * (MT * 16) + j * 16 + frow;
+            float rsub = 0.f;
+            if (p.rowsub) { int gr = m0 + m; gr = gr < p.M ? gr : p.M - 1; rsub = p.rowsub[(long)bz * p.M + gr]; }
             const float* rb = nullptr;
             if (p.rowbias) {                 // rows past M (tile overhang) must not index past the last image's row
                 int img = img0 + (m >= b1) + (m >= b2);
@@ -68,7 +72,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
                 const int nl = wn * 64 + i * 16 + fq * 4;
                 f32x4_t v = acc[i][j];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * p.alpha + bias4[i][r];
+                for (int r = 0; r < 4; ++r) v[r] = (v[r] - rsub) * p.alpha + bias4[i][r];
                 if (rb && n0 + nl + 4 <= p.N) {
                     const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rb + n0 + nl);
 #pragma unroll
@@ -105,9 +109,11 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
         } else if (p.R && nc + 8 <= p.N) {
             const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
-                                __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
+            for (int e = 0; e < 4; ++e) {
+                const float o0 = __builtin_bit_cast(float, o[e] << 16), o1 = __builtin_bit_cast(float, o[e] & 0xffff0000u);
+                const float r0 = __builtin_bit_cast(float, rr[e] << 16), r1 = __builtin_bit_cast(float, rr[e] & 0xffff0000u);
+                o[e] = p.mul_r ? pack_bf2(o0 * r0, o1 * r1) : pack_bf2(o0 + r0, o1 + r1);
+            }
         }
         bf16_t* dst = C + (long)r * p.ldc + nc;
         if (nc + 8 <= p.N) {

@@ -159,6 +159,24 @@ __global__ __launch_bounds__(kThreads) void quick_gelu_kernel(const bf16_t* __re
     *reinterpret_cast<u32x4_t*>(y + idx * 8) = pack8f(v);
 }
 
+// out[r] = sum_d a[r][d] * b[r % rows_b][d]   (delta = rowsum(dO o O) of the attention backward); one thread per row
+__global__ __launch_bounds__(kThreads) void rowdot_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                          float* __restrict__ out, long rows, long rows_b, int D) {
+    const long r = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    const bf16_t* pa = a + r * D;
+    const bf16_t* pb = b + (r % rows_b) * D;
+    float s = 0.f;
+    for (int c = 0; c < D; c += 8) {
+        float x[8], y[8];
+        unpack8f(*reinterpret_cast<const u32x4_t*>(pa + c), x);
+        unpack8f(*reinterpret_cast<const u32x4_t*>(pb + c), y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += x[e] * y[e];
+    }
+    out[r] = s;
+}
+
 // out[r][f] = h[r][f] * gelu(h[r][F + f])
 __global__ __launch_bounds__(kThreads) void geglu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ out, long rows, int F) {
     const long idx = (long)blockIdx.x * kThreads + threadIdx.x;       // one 8-channel chunk per thread
@@ -381,6 +399,13 @@ int siss_geglu_bwd(const void* dout, const void* h, void* dh, long rows2, long r
     SISS_CHECK_ARG(dout && h && dh && rows2 > 0 && rows_x > 0 && F > 0 && F % 8 == 0);
     geglu_bwd_kernel<<<cdiv(rows2 * (F / 8), kThreads), kThreads, 0, (hipStream_t)stream>>>(
         (const bf16_t*)dout, (const bf16_t*)h, (bf16_t*)dh, rows2, rows_x, F);
+    SISS_LAUNCH_RET();
+}
+
+// out[r] = <a[r], b[r % rows_b]> over D contiguous bf16 (D % 8 == 0), f32 result
+int siss_rowdot(const void* a, const void* b, float* out, long rows, long rows_b, int D, void* stream) {
+    SISS_CHECK_ARG(a && b && out && rows > 0 && rows_b > 0 && D > 0 && D % 8 == 0);
+    rowdot_kernel<<<cdiv(rows, kThreads), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, out, rows, rows_b, D);
     SISS_LAUNCH_RET();
 }
 

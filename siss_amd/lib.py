@@ -31,6 +31,8 @@ SIGNATURES = {
     "siss_conv_weight_dgrad_multi": [P, P, P, I, I, P],
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_nt_set_workspace": [P, L],
+    "siss_gemm_nt_mulsub": [P, L, P, P, L, P, L, P, I, I, I, F, I, L, L, L, P],
+    "siss_rowdot": [P, P, P, L, L, I, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
@@ -141,6 +143,8 @@ def _work(name, a):
         return 2.0 * a[10] * a[11] * a[12] * a[13] * a[20]
     if name == "siss_gemm_tn":      # 2 * N * C * npanels * nsets * rows
         return 2.0 * a[6] * a[7] * a[8] * a[11] * (a[15] - a[14])
+    if name == "siss_gemm_nt_mulsub":   # 2 * M * N * Kp * batch
+        return 2.0 * a[8] * a[9] * a[10] * a[12]
     return 0.0
 
 
@@ -169,6 +173,8 @@ def kernel_symbol(name, a):
         if (npan == 9 and batch == 1 and Kp % 64 == 0 and N % 128 == 0 and rpi >= 256 and tiles >= 2048
                 and triples(a[14], a[15], 9)):
             return "gemm_nt_c3p_kernel"
+        return "gemm_nt_kernel"
+    if name == "siss_gemm_nt_mulsub":
         return "gemm_nt_kernel"
     if name == "siss_gemm_tn":
         rows = a[15] - a[14]

@@ -175,7 +175,7 @@ class UNetCondEngine(UNetEngine):
         ops.gemm_nt(lib.ptr(qh), Dp, kh, lib.ptr(sc), Skp, Sqp, Skp, Dp, [0], [0], alpha=scale, batch=BH,
                     stride_a=Sqp * Dp, stride_w=Skp * Dp, stride_c=Sqp * Skp)
         lib.call("siss_softmax_rows_fwd", sc, p, BH * Sqp, Sk, Skp, 0)
-        oh = tb(".oh", (BH, Sqp, Dp))
+        oh = bb(".oh", (BH, Sqp, Dp))                # kept: delta = rowsum(dO o O) in the backward
         ops.gemm_nt(lib.ptr(p), Skp, vT, lib.ptr(oh), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
                     stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
         o = bb(".o", (rq, C))
@@ -194,22 +194,24 @@ class UNetCondEngine(UNetEngine):
             self._linear_bwd(dout, o, pre + ".to_out.0", rows2, rq, C, C, dx_out=do)
             doh = tb(".doh", (nBH, Sqp, Dp))
             lib.call("siss_head_split", do, doh, nb, Sq, Hh, D, Sqp, Dp)
-            dp, ds = tb(".dp", (nBH, Sqp, Skp)), tb(".ds", (nBH, Sqp, Skp))
+            ds = tb(".ds", (nBH, Sqp, Skp))
+            delta = tb(".delta", (nBH * Sqp,), torch.float32)
             dqh = tb(".dqh", (nBH, Sqp, Dp))
             dkf, dvf = tb(".dkf", (nBH, Skp, Dp), torch.float32), tb(".dvf", (nBH, Skp, Dp), torch.float32)
             dkf.zero_(); dvf.zero_()
             khT = tb(".khT", (BH, Dp, Skp))
             lib.call("siss_transpose_bf16", kh, khT, BH, Skp, Dp)
             i0, i1 = lib.int_array([0]), lib.int_array([0])
+            # delta[q] = sum_k P[q][k] dP[q][k] = <dO[q], O[q]> : no pass over the S x S matrices needed for it
+            lib.call("siss_rowdot", doh, oh, delta, nBH * Sqp, BH * Sqp, Dp)
             for g in range(nb // B):             # cotangent groups that share the B forward samples
                 sl = slice(g * BH, (g + 1) * BH)
-                # dP = dO V^T
-                ops.gemm_nt(lib.ptr(doh[sl]), Dp, vh, lib.ptr(dp[sl]), Skp, Sqp, Skp, Dp, [0], [0], batch=BH,
-                            stride_a=Sqp * Dp, stride_w=Skp * Dp, stride_c=Sqp * Skp)
+                # dS = scale * P o (dO V^T - delta) straight from the product's epilogue: dP is never materialised
+                lib.call("siss_gemm_nt_mulsub", doh[sl], Dp, vh, ds[sl], Skp, p, Skp, delta[g * BH * Sqp:], Sqp, Skp, Dp,
+                         float(scale), BH, Sqp * Dp, Skp * Dp, Sqp * Skp)
                 # dV[key][d] = sum_q P[q][key] dO[q][d]
                 lib.call("siss_gemm_tn", p, Skp, doh[sl], Dp, dvf[sl], Skp * Dp, Skp, Dp, 1, i0, i1, BH, Sqp, Sqp,
                          0, Sqp, 1, zp, None, None)
-            lib.call("siss_softmax_rows_bwd", p, dp, ds, nBH * Sqp, BH * Sqp, Sk, Skp, float(scale))
             for g in range(nb // B):
                 sl = slice(g * BH, (g + 1) * BH)
                 # dQ = dS K
