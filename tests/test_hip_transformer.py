@@ -142,3 +142,27 @@ def test_quick_gelu(dev):
     y = torch.empty(37, 256, dtype=torch.bfloat16, device=dev)
     lib.call("siss_quick_gelu", x.to(dev).to(torch.bfloat16), y, x.numel())
     _close(y.float().cpu(), x * torch.sigmoid(1.702 * x), 1e-2, "quick_gelu")
+
+
+def test_gemm_nt_mulsub_and_rowdot(dev):
+    """dS = scale * P o (dO V^T - delta) from the product's epilogue, delta = rowsum(dO o O) (attention backward)."""
+    from siss_amd import lib
+    g = torch.Generator().manual_seed(9)
+    BH, Sq, Sk, D = 3, 192, 128, 64
+    do = _bf(torch.randn(2 * BH, Sq, D, generator=g))          # two cotangent groups over the same forward heads
+    o = _bf(torch.randn(BH, Sq, D, generator=g))
+    v = _bf(torch.randn(BH, Sk, D, generator=g))
+    p = _bf(torch.softmax(torch.randn(BH, Sq, Sk, generator=g), -1))
+    scale = 0.25
+    d_do, d_o, d_v, d_p = (t.to(dev).to(torch.bfloat16).contiguous() for t in (do, o, v, p))
+    delta = torch.empty(2 * BH * Sq, device=dev)
+    lib.call("siss_rowdot", d_do, d_o, delta, 2 * BH * Sq, BH * Sq, D)
+    ref_delta = (do * o.repeat(2, 1, 1)).sum(-1)
+    _close(delta.view(2 * BH, Sq).cpu(), ref_delta, 1e-5, "rowdot")
+    ds = torch.empty(2 * BH, Sq, Sk, dtype=torch.bfloat16, device=dev)
+    for grp in range(2):
+        sl = slice(grp * BH, (grp + 1) * BH)
+        lib.call("siss_gemm_nt_mulsub", d_do[sl], D, d_v, ds[sl], Sk, d_p, Sk, delta[grp * BH * Sq:], Sq, Sk, D, scale,
+                 BH, Sq * D, Sk * D, Sq * Sk)
+        ref = scale * p * (do[sl] @ v.transpose(1, 2) - ref_delta[sl].unsqueeze(-1))
+        _close(ds[sl].float().cpu(), ref, 1.5e-2, f"mulsub group {grp}")
