@@ -113,7 +113,7 @@ def hbm_traffic(launcher):
         if k.startswith(stem):
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             n += v["launches"]
-    return {"bytes_per_launch": round(tot / n), "source": "profiles/latest_hbm_traffic.json (rocprofv3 --pmc)"} if n else None
+    return round(tot / n) if n else None
 
 
 def main():
@@ -255,7 +255,9 @@ def main():
         launcher = "siss_gemm_nt" if dom.startswith("gemm_nt") else "siss_gemm_tn"
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": hbm_traffic(dom) if a.config == "celebahq256" else None,
+                "traffic": hbm_traffic(dom) if a.config == "celebahq256" else None,     # HBM bytes per launch
+                "traffic_source": "profiles/latest_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel from two "
+                                  "separate rocprofv3 --pmc passes of the same command (tools/pmc_traffic.sh)",
                 "launches_per_step": n // ksteps, "avg_launch_us": round(tms / n * 1e3, 2),
                 "tflop_per_launch": round(work / n / 1e12, 4),
                 "share_of_step_kernel_time": round(tms / tot_ms, 3),
