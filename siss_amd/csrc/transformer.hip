@@ -20,7 +20,9 @@ __device__ __forceinline__ u32x4_t pack8f(const float (&v)[8]) {
     return u32x4_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
 }
 
-// One wave per row; lane l owns 8-channel chunks l, l+64, ...
+// One wave per row; lane l owns 8-channel chunks l, l+64, ... (NCH of them: the SD widths 320 / 640 / 1280 need 1 / 2 /
+// 3; a fixed 4 kept 160+ VGPRs live and ran the backward at two waves per SIMD)
+template <int NCH>
 __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                  float* __restrict__ mean, float* __restrict__ rstd,
@@ -29,10 +31,10 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const bf16_t* _
     const long r = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int nch = C >> 3;
-    float v[kMaxChunks][8];
+    float v[NCH][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
             unpack8f(*reinterpret_cast<const u32x4_t*>(x + r * C + c * 8), v[i]);
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const bf16_t* _
     const float mu = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i)
+    for (int i = 0; i < NCH; ++i)
         if (lane + i * 64 < nch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const bf16_t* _
     const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
             float o[8];
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const bf16_t* _
 // dx[r] = (accum[r] +) rstd * (dy*gamma - mean_c(dy*gamma) - xhat * mean_c(dy*gamma*xhat)); saved row = r % rows_x.
 // dgamma / dbeta: per cotangent set (set = r / set_rows), per-lane partial column sums over the block's rows,
 // folded across the block's waves in LDS, one f32 atomic per column and block.
+template <int NCH>
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const bf16_t* __restrict__ accum,
@@ -78,9 +81,9 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* _
     long r1 = r0 + rows_per_block; r1 = r1 < rows2 ? r1 : rows2;
     // a block never straddles two sets (rows_per_block divides set_rows)
     const long set = r0 / set_rows;
-    float dg[kMaxChunks][8], db[kMaxChunks][8], ga[kMaxChunks][8];
+    float dg[NCH][8], db[NCH][8], ga[NCH][8];
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i)
+    for (int i = 0; i < NCH; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             dg[i][e] = 0.f; db[i][e] = 0.f;
@@ -90,10 +93,10 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* _
     for (long r = r0 + w; r < r1; r += kThreads / 64) {
         const long rx = r % rows_x;
         const float mu = mean[rx], rs = rstd[rx];
-        float d[kMaxChunks][8], xh[kMaxChunks][8];
+        float d[NCH][8], xh[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxChunks; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * 64;
             if (c < nch) {
                 float xv[8];
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* _
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-        for (int i = 0; i < kMaxChunks; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int c = lane + i * 64;
             if (c < nch) {
                 float o[8], a[8];
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* _
         }
     }
     if (!dgamma) return;
-    for (int i = 0; i < kMaxChunks; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         if (i * 64 >= nch) break;
         __syncthreads();
 #pragma unroll
@@ -368,8 +371,15 @@ extern "C" {
 int siss_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        long rows, int C, float eps, void* stream) {
     SISS_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * kMaxChunks);
-    layernorm_fwd_kernel<<<cdiv(rows, kThreads / 64), kThreads, 0, (hipStream_t)stream>>>(
-        (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
+#define LN_DISPATCH(KERNEL, GRID, ...)                                                        \
+    do {                                                                                       \
+        const int nchunks = cdiv(C / 8, 64);                                                   \
+        if (nchunks <= 1) KERNEL<1><<<GRID, kThreads, 0, (hipStream_t)stream>>>(__VA_ARGS__);  \
+        else if (nchunks == 2) KERNEL<2><<<GRID, kThreads, 0, (hipStream_t)stream>>>(__VA_ARGS__); \
+        else if (nchunks == 3) KERNEL<3><<<GRID, kThreads, 0, (hipStream_t)stream>>>(__VA_ARGS__); \
+        else KERNEL<4><<<GRID, kThreads, 0, (hipStream_t)stream>>>(__VA_ARGS__);              \
+    } while (0)
+    LN_DISPATCH(layernorm_fwd_kernel, cdiv(rows, kThreads / 64), (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps);
     SISS_LAUNCH_RET();
 }
 
@@ -380,12 +390,11 @@ int siss_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
                        long set_stride, int C, void* stream) {
     SISS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows2 > 0 && rows_x > 0 && set_rows > 0);
     SISS_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 64 * 8 * kMaxChunks && rows2 % set_rows == 0 && (!dgamma || dbeta));
-    // rows per block: a divisor of set_rows near 64 (blocks must not straddle sets)
-    int rpb = 64;
+    // rows per block: a divisor of set_rows near 16 (blocks must not straddle sets)
+    int rpb = 16;        // 4 rows per wave: 4x the blocks of the 64-row form (it left 2 waves per SIMD walking 16 rows each)
     while (rpb > 1 && set_rows % rpb) --rpb;
-    layernorm_bwd_kernel<<<cdiv(rows2, rpb), kThreads, 0, (hipStream_t)stream>>>(
-        (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (const bf16_t*)accum, (bf16_t*)dx, dgamma, dbeta, rows2,
-        rows_x, set_rows, set_stride, C, rpb);
+    LN_DISPATCH(layernorm_bwd_kernel, cdiv(rows2, rpb), (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                (const bf16_t*)accum, (bf16_t*)dx, dgamma, dbeta, rows2, rows_x, set_rows, set_stride, C, rpb);
     SISS_LAUNCH_RET();
 }
 
