@@ -98,6 +98,36 @@ class _DeleteBase(Task):
         """Images -> what the loss is taken on (identity for the pixel-space tasks; VAE latents for SD)."""
         return x
 
+    def evaluate(self, unet, sched, forget_image, step, device):
+        """The image part of the reference's log_metrics (delete_celeb.py:376-436, :484-545): `eval_batch_size`
+        samples from the current model (DDPMPipeline, `pipeline.num_inference_steps`) and the forget image noised to
+        `metrics.denoising_injections.timestep` and denoised back, written as PNG grids instead of wandb images.
+        Runs every `eval_every` optimizer steps -- OPT-IN (null by default): the reference's `sampling_steps: 1`
+        spends ~300 UNet forwards per optimizer step on it."""
+        import numpy as np
+        from PIL import Image
+        from .sampler import Evaluator
+        cfg = self.cfg
+        ev = Evaluator(cfg)
+        ev.load_model(unet, sched)
+        n = int(cfg.get("eval_batch_size") or 4)
+        steps = int(((cfg.get("pipeline") or {}).get("num_inference_steps")) or 50)
+        imgs = ev.sample_images(n, num_inference_steps=steps, set_generator=True)            # [n, H, W, C] in [0, 1]
+        inj = ((cfg.get("metrics") or {}).get("denoising_injections")) or {}
+        t_inj = int(inj.get("timestep", 250))
+        g = torch.Generator(device=device).manual_seed(self.seed())
+        clean = forget_image.to(device).float()
+        noise = torch.randn((n, *clean.shape), generator=g, device=device)
+        noisy = sched.add_noise(clean.expand(n, *clean.shape), noise, torch.full((n,), t_inj, device=device))
+        den = ev.denoise_images(noisy, t_inj).cpu().numpy()
+
+        def grid(a):
+            a = (np.clip(a, 0, 1) * 255).astype(np.uint8)
+            row = np.concatenate(list(a), axis=1)
+            return Image.fromarray(row[..., 0] if row.shape[-1] == 1 else row)
+        grid(imgs).save(os.path.join(cfg.output_dir, f"samples_step{step}.png"))
+        grid(den).save(os.path.join(cfg.output_dir, f"denoised_forget_t{t_inj}_step{step}.png"))
+
     # -- the loop ------------------------------------------------------------------------------
     def run(self):
         cfg = self.cfg
@@ -134,6 +164,7 @@ class _DeleteBase(Task):
         g = torch.Generator(device=device).manual_seed(seed + rank)
         T = sched.config.num_train_timesteps
         t0 = time.perf_counter()
+        eval_every = int(cfg.get("eval_every") or 0)
         for step in range(n_steps):
             for _ in range(ga):
                 x0 = self.prepare_batch(next(it_all).to(device, non_blocking=True), g)
@@ -147,6 +178,8 @@ class _DeleteBase(Task):
             st["elapsed_s"] = time.perf_counter() - t0
             log.write(json.dumps(st) + "\n")
             log.flush()
+            if rank == 0 and eval_every and (step + 1) % eval_every == 0 and not isinstance(self, DeleteSD):
+                self.evaluate(unet, sched, ds_del[0], step + 1, device)
             if rank == 0:
                 print(f"step {step + 1}/{n_steps}  |g_x| {st['norm_loss_x']:.4g}  |g_a| {st['norm_loss_a']:.4g}  "
                       f"s {st['scaling_factor']:.4g}")

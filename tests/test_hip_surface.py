@@ -108,8 +108,13 @@ def test_delete_celeb_entry_point_on_a_jpeg_directory(tmp_path):
                 "train_batch_size=2", "gradient_accumulation_steps=2", "checkpoint_path=/nonexistent",
                 "unet.sample_size=16", "unet.block_out_channels=[64,128]",
                 "unet.down_block_types=[DownBlock2D,AttnDownBlock2D]", "unet.up_block_types=[AttnUpBlock2D,UpBlock2D]",
-                "unet.layers_per_block=1", "unet.attention_head_dim=null"])
+                "unet.layers_per_block=1", "unet.attention_head_dim=null",
+                "eval_every=2", "eval_batch_size=2", "pipeline.num_inference_steps=3",
+                "metrics.denoising_injections.timestep=4"])
     run = [d for d in os.listdir(out)][0]                       # main.py appends <timestamp>_<uuid> (main.py:21-28)
     lines = [json.loads(l) for l in open(out / run / "train_log_rank0.jsonl")]
     assert len(lines) == 2 and all(abs(s["scaling_factor"] * s["norm_loss_a"] - 500.0) < 0.5 for s in lines)
     assert os.path.exists(out / run / "unet" / "diffusion_pytorch_model.safetensors")
+    # opt-in image evaluation (the reference's log_metrics): sample grid + forget image noised to t and denoised back
+    g1, g2 = Image.open(out / run / "samples_step2.png"), Image.open(out / run / "denoised_forget_t4_step2.png")
+    assert g1.size == (32, 16) and g2.size == (32, 16)
