@@ -59,6 +59,25 @@ def main():
         du_ref, du_dp = upd_ref - base, dp_params - base
         cos = float((du_ref * du_dp).sum() / (du_ref.norm() * du_dp.norm()))
         assert cos > 0.98, cos
+    # serial exchange (one all-reduce after the backward) gives the same update as the overlapped one ...
+    eng.load_state_dict(sd)
+    st2 = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, **kw)
+    assert st2.overlap, "the overlapped exchange is the default when the flat layout has an early-final tail"
+    st2.set_overlap(False)
+    st2.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
+    du_serial = eng.ps.flat.clone()
+    base = torch.empty_like(du_serial)
+    eng.load_state_dict(sd)
+    base.copy_(eng.ps.flat)
+    d1, d2 = dp_params - base, du_serial - base
+    cos = float((d1 * d2).sum() / (d1.norm() * d2.norm()))
+    assert cos > 0.999, cos
+    # ... and the measured choice between the two runs on every rank without deadlock and agrees across ranks
+    st3 = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, **kw)
+    choice = st3.autotune_overlap(lambda: st3.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl]), iters=1)
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(choice))
+    assert len(set(flags)) == 1 and set(st3.overlap_timings) == {"overlap_ms", "serial_ms"}
     dist.barrier()
     dist.destroy_process_group()
     print("dp gpu ok", rank)
