@@ -298,7 +298,7 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
-                        old[i][j][r] = (n < p.N && c < p.C) ? out[(long)n * p.C + c] : 0.f;
+                        old[i][j][r] = (p.rmw == 1 && n < p.N && c < p.C) ? out[(long)n * p.C + c] : 0.f;   // rmw 2: overwrite
                     }
                 }
 #pragma unroll
@@ -350,8 +350,10 @@ extern "C" {
 // dW must be zeroed (or hold the running sum for gradient accumulation) before the call.
 // dbias / dbias2 (optional): dbias[set*set_stride + n] += sum over the set's rows of Y[r][n].
 // Rows [row_begin, row_end) of every set are reduced; shifts/coffs are HOST arrays.
-// nsplits <= 0: choose the kernel variant and the split count here (cost model below); when that lands on one split
+// nsplits == 0: choose the kernel variant and the split count here (cost model below); when that lands on one split
 // the block that owns a tile read-add-writes it with plain accesses instead of atomics.
+// nsplits == -1: one split per tile and dW is OVERWRITTEN with the product (no accumulation: the caller needs no zero
+// fill; attention dK / dV).
 int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
                  int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
                  long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
@@ -378,6 +380,8 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
     if (force1 < 0) { const char* e = getenv("SISS_TN_TAPS"); force1 = e ? atoi(e) : 0; }
     bool fused3 = triples && force1 != 1;
     const int rows = row_end - row_begin;
+    const bool overwrite = nsplits == -1;                  // one split per tile, dW = product (no read, no zero fill needed)
+    if (overwrite) nsplits = 1;
     const bool automatic = nsplits <= 0;
     if (nsplits <= 0) {
         // Auto: pick (kernel variant, split count) by a small cost model (us), measured constants:
@@ -415,7 +419,7 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
         fused3 = best_f3;
     }
     p.nsplits = nsplits;
-    p.rmw = automatic && nsplits == 1;
+    p.rmw = overwrite ? 2 : (automatic && nsplits == 1 ? 1 : 0);
     int rps = cdiv(rows, nsplits);
     rps = cdiv(rps, BR) * BR;
     p.rows_per_split = rps;

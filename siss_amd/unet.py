@@ -672,7 +672,6 @@ class UNetEngine:
                 dkf, dvf = tb(".dkf", (nb, S, C), torch.float32), tb(".dvf", (nb, S, C), torch.float32)
                 kT = tb(".kT", (B, C, S))
                 lib.call("siss_transpose_bf16", k, kT, B, S, C)
-                dkf.zero_(); dvf.zero_()
                 for g in range(nb // B):      # cotangent groups that share the B forward samples
                     sl = slice(g * B, (g + 1) * B)
                     # dP = dO V^T
@@ -680,7 +679,7 @@ class UNetEngine:
                                 stride_a=S * C, stride_w=S * C, stride_c=S * S)
                     # dV[key][c] = sum_q P[q][key] dO[q][c]
                     lib.call("siss_gemm_tn", p, S, do[g * B * S:], C, dvf[sl], S * C, S, C, 1, lib.int_array([0]),
-                             lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
+                             lib.int_array([0]), B, S, S, 0, S, -1, zp, None, None)   # -1: overwrite, no zero fill
                 if S <= 1024:
                     lib.call("siss_softmax_bwd", p, dp, ds, nb * S, B * S, S, float(scale))
                 else:
@@ -692,7 +691,7 @@ class UNetEngine:
                                 stride_a=S * S, stride_w=C * S, stride_c=S * C)
                     # dK[key][c] = sum_q dS[q][key] Q[q][c]
                     lib.call("siss_gemm_tn", ds[sl], S, q, C, dkf[sl], S * C, S, C, 1, lib.int_array([0]),
-                             lib.int_array([0]), B, S, S, 0, S, 1, zp, None, None)
+                             lib.int_array([0]), B, S, S, 0, S, -1, zp, None, None)   # -1: overwrite, no zero fill
                 lib.call("siss_cast_f32_bf16", dkf, dk, dkf.numel())
                 lib.call("siss_cast_f32_bf16", dvf, dv, dvf.numel())
             dhn = tb(".dhn", (rows2, C))

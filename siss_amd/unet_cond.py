@@ -198,7 +198,6 @@ class UNetCondEngine(UNetEngine):
             delta = tb(".delta", (nBH * Sqp,), torch.float32)
             dqh = tb(".dqh", (nBH, Sqp, Dp))
             dkf, dvf = tb(".dkf", (nBH, Skp, Dp), torch.float32), tb(".dvf", (nBH, Skp, Dp), torch.float32)
-            dkf.zero_(); dvf.zero_()
             khT = tb(".khT", (BH, Dp, Skp))
             lib.call("siss_transpose_bf16", kh, khT, BH, Skp, Dp)
             i0, i1 = lib.int_array([0]), lib.int_array([0])
@@ -211,7 +210,7 @@ class UNetCondEngine(UNetEngine):
                          float(scale), BH, Sqp * Dp, Skp * Dp, Sqp * Skp)
                 # dV[key][d] = sum_q P[q][key] dO[q][d]
                 lib.call("siss_gemm_tn", p, Skp, doh[sl], Dp, dvf[sl], Skp * Dp, Skp, Dp, 1, i0, i1, BH, Sqp, Sqp,
-                         0, Sqp, 1, zp, None, None)
+                         0, Sqp, -1, zp, None, None)     # -1: one split, dW overwritten (no zero fill)
             for g in range(nb // B):
                 sl = slice(g * BH, (g + 1) * BH)
                 # dQ = dS K
@@ -219,7 +218,7 @@ class UNetCondEngine(UNetEngine):
                             stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
                 # dK[key][d] = sum_q dS[q][key] Q[q][d]
                 lib.call("siss_gemm_tn", ds[sl], Skp, qh, Dp, dkf[sl], Skp * Dp, Skp, Dp, 1, i0, i1, BH, Sqp, Sqp,
-                         0, Sqp, 1, zp, None, None)
+                         0, Sqp, -1, zp, None, None)     # -1: one split, dW overwritten (no zero fill)
             dkh, dvh = tb(".dkh", (nBH, Skp, Dp)), tb(".dvh", (nBH, Skp, Dp))
             lib.call("siss_cast_f32_bf16", dkf, dkh, dkf.numel())
             lib.call("siss_cast_f32_bf16", dvf, dvh, dvf.numel())
