@@ -111,3 +111,119 @@ def recombine_clip_adamw_(g_x: Tensor, g_a: Tensor, p: Tensor, m: Tensor, v: Ten
              float(beta2), partials, scalars)
     lib.call("siss_recombine_clip_adamw", g_x, g_a, p, m, v, None, None, n, float(lr), float(beta1), float(beta2),
              float(eps), float(weight_decay), scalars)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# The two workhorse layers as differentiable ops on ordinary NCHW tensors.  The engine keeps activations in its
+# padded-NHWC bf16 layout between kernels; these ops convert at their boundary (so they are for composing /
+# validating against torch modules, not the fast path) and run the same fprop / dgrad / wgrad and GroupNorm kernels.
+# --------------------------------------------------------------------------------------------------------------
+from . import ops as _ops                     # noqa: E402
+from .layout import Act as _Act              # noqa: E402
+
+
+@torch.library.custom_op("siss::conv2d_3x3", mutates_args=())
+def conv2d_3x3(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    """3x3 'same' convolution (stride 1, zero padding) on the MFMA NT GEMM; bf16 operands, f32 accumulate, f32 out."""
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    xa = _Act.from_nchw(x, x.device)
+    out = _Act(n, h, w, co, x.device)
+    _ops.conv_fprop(xa, _ops.conv_w_to_native(weight.float()).to(torch.bfloat16), out, bias=bias.float().contiguous())
+    return out.to_nchw()
+
+
+@conv2d_3x3.register_fake
+def _(x, weight, bias):
+    return x.new_empty((x.shape[0], weight.shape[0], x.shape[2], x.shape[3]), dtype=torch.float32)
+
+
+@torch.library.custom_op("siss::conv2d_3x3_backward", mutates_args=())
+def conv2d_3x3_backward(dy: Tensor, x: Tensor, weight: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """(dx, dW, dbias): dgrad on the NT GEMM with the transposed taps, wgrad (+ bias gradient) on the TN GEMM."""
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    dev = x.device
+    dya, xa = _Act.from_nchw(dy, dev), _Act.from_nchw(x, dev)
+    wn = _ops.conv_w_to_native(weight.float())
+    dx = _Act(n, h, w, ci, dev)
+    _ops.conv_dgrad(dya, _ops.dgrad_weight(wn), dx)
+    dW = torch.zeros(1, 9, co, ci, device=dev)
+    db = torch.zeros(co, device=dev)
+    _ops.conv_wgrad(dya, xa, dW, nsets=1, dbias=db)
+    return dx.to_nchw(), _ops.conv_w_from_native(dW[0]), db
+
+
+@conv2d_3x3_backward.register_fake
+def _(dy, x, weight):
+    return (x.new_empty(x.shape, dtype=torch.float32), weight.new_empty(weight.shape, dtype=torch.float32),
+            weight.new_empty((weight.shape[0],), dtype=torch.float32))
+
+
+def _conv_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+
+
+def _conv_bwd(ctx, g):
+    x, w = ctx.saved_tensors
+    dx, dW, db = torch.ops.siss.conv2d_3x3_backward(g.contiguous(), x, w)
+    return dx, dW, db
+
+
+conv2d_3x3.register_autograd(_conv_bwd, setup_context=_conv_setup)
+
+
+@torch.library.custom_op("siss::groupnorm_silu", mutates_args=())
+def groupnorm_silu(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, silu: bool) -> Tensor:
+    """y = act(GroupNorm(x)) (act = SiLU or identity) with the fused HBM-bound kernels; f32 statistics."""
+    n, c, h, w = x.shape
+    dev = x.device
+    xa, ya = _Act.from_nchw(x, dev), _Act(n, h, w, c, dev)
+    mean, rstd = torch.empty(n, groups, device=dev), torch.empty(n, groups, device=dev)
+    part = torch.zeros(lib.query("siss_gn_partial_words", n, h, w, c, groups), device=dev)
+    lib.call("siss_groupnorm_fwd", xa.data, gamma.float().contiguous(), beta.float().contiguous(), ya.data, mean, rstd,
+             part, n, h, w, c, groups, float(eps), int(silu), 0)
+    return ya.to_nchw()
+
+
+@groupnorm_silu.register_fake
+def _(x, gamma, beta, groups, eps, silu):
+    return x.new_empty(x.shape, dtype=torch.float32)
+
+
+@torch.library.custom_op("siss::groupnorm_silu_backward", mutates_args=())
+def groupnorm_silu_backward(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float,
+                            silu: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    n, c, h, w = x.shape
+    dev = x.device
+    xa, ya = _Act.from_nchw(x, dev), _Act(n, h, w, c, dev)
+    mean, rstd = torch.empty(n, groups, device=dev), torch.empty(n, groups, device=dev)
+    part = torch.zeros(lib.query("siss_gn_partial_words", n, h, w, c, groups), device=dev)
+    g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+    lib.call("siss_groupnorm_fwd", xa.data, g32, b32, ya.data, mean, rstd, part, n, h, w, c, groups, float(eps),
+             int(silu), 0)                                        # statistics of the saved input
+    dya, dxa = _Act.from_nchw(dy, dev), _Act(n, h, w, c, dev)
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    lib.call("siss_groupnorm_bwd", dya.data, xa.data, g32, b32, mean, rstd, dxa.data, None, None, None, 0, 0, dg, db,
+             None, 0, part, n, n, n, c, h, w, c, groups, int(silu), 0)
+    return dxa.to_nchw(), dg, db
+
+
+@groupnorm_silu_backward.register_fake
+def _(dy, x, gamma, beta, groups, eps, silu):
+    return (x.new_empty(x.shape, dtype=torch.float32), gamma.new_empty(gamma.shape, dtype=torch.float32),
+            gamma.new_empty(gamma.shape, dtype=torch.float32))
+
+
+def _gn_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], inputs[2])
+    ctx.groups, ctx.eps, ctx.silu = inputs[3], inputs[4], inputs[5]
+
+
+def _gn_bwd(ctx, g):
+    x, gamma, beta = ctx.saved_tensors
+    dx, dg, db = torch.ops.siss.groupnorm_silu_backward(g.contiguous(), x, gamma, beta, ctx.groups, ctx.eps, ctx.silu)
+    return dx, dg, db, None, None, None
+
+
+groupnorm_silu.register_autograd(_gn_bwd, setup_context=_gn_setup)

@@ -78,3 +78,35 @@ def test_flat_optimizer_op_matches_torch(dev):
     opt.step()
     torch.ops.siss.recombine_clip_adamw_(gx, ga, p, m, v, scalars, partials, 5.0, 1.0, 1e-3, 0.95, 0.999, 1e-8, 1e-2)
     torch.testing.assert_close(p, ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_conv_and_groupnorm_ops_are_differentiable_and_match_torch(dev):
+    """siss::conv2d_3x3 / siss::groupnorm_silu with autograd through the HIP dgrad / wgrad / GroupNorm-backward
+    kernels, composed like a resnet half (GN -> SiLU -> conv), against the torch modules on bf16-rounded operands."""
+    import torch.nn.functional as F
+    bf = lambda t: t.to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(3)
+    n, c, co, hw = 2, 64, 128, 16
+    x = bf(torch.randn(n, c, hw, hw, generator=g))
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    w = bf(torch.randn(co, c, 3, 3, generator=g) / (3 * c ** 0.5))
+    b = 0.1 * torch.randn(co, generator=g)
+    dy = bf(torch.randn(n, co, hw, hw, generator=g))
+    leaves = [t.clone().requires_grad_(True) for t in (x, gamma, beta, w, b)]
+    ref = F.conv2d(F.silu(F.group_norm(leaves[0], 32, leaves[1], leaves[2], 1e-6)), leaves[3], leaves[4], padding=1)
+    ref.backward(dy)
+    d = [t.to(dev).clone().requires_grad_(True) for t in (x, gamma, beta, w, b)]
+    a = torch.ops.siss.groupnorm_silu(d[0], d[1], d[2], 32, 1e-6, True)
+    y = torch.ops.siss.conv2d_3x3(a, d[3], d[4])
+    y.backward(dy.to(dev))
+
+    def close(got, want, rel, what):
+        err, scale = (got.cpu() - want).abs().max().item(), want.abs().max().item()
+        assert err <= rel * scale, (what, err, scale)
+    close(y.detach(), ref.detach(), 2e-2, "y")
+    for i, (name, rel) in enumerate((("dx", 3e-2), ("dgamma", 1e-2), ("dbeta", 1e-2), ("dW", 1e-2), ("dbias", 5e-3))):
+        close(d[i].grad, leaves[i].grad, rel, name)
+    torch.library.opcheck(torch.ops.siss.conv2d_3x3.default, (a.detach(), d[3].detach(), d[4].detach()),
+                          test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(torch.ops.siss.groupnorm_silu.default, (d[0].detach(), d[1].detach(), d[2].detach(), 32, 1e-6, True),
+                          test_utils=("test_schema", "test_faketensor"))
