@@ -101,20 +101,27 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
     const bf16_t* xsrc[NP];
     const bf16_t* xsrc_extra = nullptr;
     const bf16_t* zsrc = p.zero_page + (lane & 15) * 8;
-    int trow[NP];
+    // trow?[j]: the piece's row within the step, or kNever for lanes whose 16-B column chunk lies past the operand's
+    // last column (N < 128 / C < 128 tiles): those lanes take the zero page, so no byte past a row's end is ever read.
+    constexpr int kNever = 1 << 29;
+    int trowy[NP], trowx[NP];
     const long xrow0 = (long)set * p.x_set_rows + r0 + p.shift[pn];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int row = (w * NP + j) * 4 + (lane >> 4);
         const int lc = (lane & 15) ^ swz(row);
-        trow[j] = row;
+        trowy[j] = n0 + lc * 8 < p.N ? row : kNever;
+        trowx[j] = c0 + lc * 8 < p.C ? row : kNever;
         const long ry = (long)set * p.rows_per_set + r0 + row;
         ysrc[j] = p.Y + ry * p.ldy + n0 + lc * 8;
         xsrc[j] = p.X + (xrow0 + row) * p.ldx + p.coff[pn] + c0 + lc * 8;
     }
+    int trow_extra = kNever;
     if (TAPS == 3) {
         const int row = BR + (lane >> 4);
-        xsrc_extra = p.X + (xrow0 + row) * p.ldx + p.coff[pn] + c0 + ((lane & 15) ^ swz(row)) * 8;
+        const int lc = (lane & 15) ^ swz(row);
+        xsrc_extra = p.X + (xrow0 + row) * p.ldx + p.coff[pn] + c0 + lc * 8;
+        if (c0 + lc * 8 < p.C) trow_extra = row;
     }
     const long ystep = (long)BR * p.ldy, xstep = (long)BR * p.ldx;
     const unsigned smem_a = lds_addr(smem);
@@ -123,18 +130,18 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
         const int rbase = r0 + step * BR;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const bool ok = rbase + trow[j] < r1;
+            const bool ok = rbase + trowy[j] < r1;
             glds16_asm(ok ? ysrc[j] + step * ystep : zsrc, base + j * 1024);
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             // an X row matters only if one of the (up to TAPS) Y rows it meets is in range; everything
             // else comes from the zero page (never read past the operand; 0 * garbage could be NaN)
-            const bool ok = rbase + trow[j] - (TAPS - 1) < r1;
+            const bool ok = rbase + trowx[j] - (TAPS - 1) < r1;
             glds16_asm(ok ? xsrc[j] + step * xstep : zsrc, base + kYTile + j * 1024);
         }
         if (TAPS == 3 && w == 0) {
-            const bool ok = rbase + BR + (lane >> 4) - (TAPS - 1) < r1;
+            const bool ok = rbase + trow_extra - (TAPS - 1) < r1;
             glds16_asm(ok ? xsrc_extra + step * xstep : zsrc, smem_a + buf * C_::kStageBytes + kYTile + BR * 256);
         }
     };

@@ -227,3 +227,117 @@ def _gn_bwd(ctx, g):
 
 
 groupnorm_silu.register_autograd(_gn_bwd, setup_context=_gn_setup)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Multi-head attention  softmax(q k^T * scale) v  on [B, S, heads * D] tokens: batched MFMA GEMMs over head-split,
+# zero-padded operands + the whole-row softmax kernel; the backward uses the fused dS epilogue
+# (dS = scale * P o (dO V^T - rowsum(dO o O))), so neither dP nor a separate softmax-backward pass exists.
+# --------------------------------------------------------------------------------------------------------------
+def _up(n, m):
+    return -(-n // m) * m
+
+
+_SLACK = int(__import__("os").environ.get("SISS_OPS_SLACK", "1024"))
+
+
+def _alloc(shape, dtype, dev):
+    """GEMM operand / result buffer with the engine's slack (unet.py::_buf).  Defensive only: the wgrad kernel used to
+    READ (never use) the 128-column tile's remainder past the last row of a 64-column operand; its staging now takes
+    the zero page for those lanes, and tests/test_hip_torch_ops.py passes with SISS_OPS_SLACK=0."""
+    n = 1
+    for s in shape:
+        n *= s
+    return torch.empty(n + _SLACK, dtype=dtype, device=dev)[:n].view(shape)
+
+
+def _split(t, B, S, H, D, Sp, Dp):
+    out = _alloc((B * H, Sp, Dp), torch.bfloat16, t.device)
+    lib.call("siss_head_split", t, out, B, S, H, D, Sp, Dp)
+    return out
+
+
+def _attn_fwd(q, k, v, heads, scale):
+    B, Sq, C = q.shape
+    Sk = k.shape[1]
+    D = C // heads
+    assert D * heads == C and D % 8 == 0 and k.shape == v.shape and k.shape[0] == B and k.shape[2] == C
+    Dp, Sqp, Skp, BH = _up(D, 64), _up(Sq, 64), _up(Sk, 64), B * heads
+    dev = q.device
+    qb, kb, vb = (t.to(torch.bfloat16).contiguous() for t in (q, k, v))
+    qh, kh, vh = _split(qb, B, Sq, heads, D, Sqp, Dp), _split(kb, B, Sk, heads, D, Skp, Dp), _split(vb, B, Sk, heads, D, Skp, Dp)
+    vT = _alloc((BH, Dp, Skp), torch.bfloat16, dev)
+    lib.call("siss_transpose_bf16", vh, vT, BH, Skp, Dp)
+    sc = _alloc((BH, Sqp, Skp), torch.bfloat16, dev)
+    p = _alloc((BH, Sqp, Skp), torch.bfloat16, dev)
+    _ops.gemm_nt(lib.ptr(qh), Dp, kh, lib.ptr(sc), Skp, Sqp, Skp, Dp, [0], [0], alpha=scale, batch=BH,
+                 stride_a=Sqp * Dp, stride_w=Skp * Dp, stride_c=Sqp * Skp)
+    lib.call("siss_softmax_rows_fwd", sc, p, BH * Sqp, Sk, Skp, 0)
+    oh = _alloc((BH, Sqp, Dp), torch.bfloat16, dev)
+    _ops.gemm_nt(lib.ptr(p), Skp, vT, lib.ptr(oh), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
+                 stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
+    o = torch.empty(B, Sq, C, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_head_merge", oh, o, B, Sq, heads, D, Sqp, Dp)
+    return o, (qh, kh, vh, p, oh)
+
+
+@torch.library.custom_op("siss::attention", mutates_args=())
+def attention(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tensor:
+    return _attn_fwd(q, k, v, heads, scale)[0].float()
+
+
+@attention.register_fake
+def _(q, k, v, heads, scale):
+    return q.new_empty(q.shape, dtype=torch.float32)
+
+
+@torch.library.custom_op("siss::attention_backward", mutates_args=())
+def attention_backward(do: Tensor, q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float) -> Tuple[Tensor, Tensor, Tensor]:
+    B, Sq, C = q.shape
+    Sk = k.shape[1]
+    D = C // heads
+    Dp, Sqp, Skp, BH = _up(D, 64), _up(Sq, 64), _up(Sk, 64), B * heads
+    dev = q.device
+    _, (qh, kh, vh, p, oh) = _attn_fwd(q, k, v, heads, scale)               # recompute the forward's saved tensors
+    doh = _split(do.to(torch.bfloat16).contiguous(), B, Sq, heads, D, Sqp, Dp)
+    delta = _alloc((BH * Sqp,), torch.float32, dev)
+    lib.call("siss_rowdot", doh, oh, delta, BH * Sqp, BH * Sqp, Dp)
+    ds = _alloc((BH, Sqp, Skp), torch.bfloat16, dev)
+    lib.call("siss_gemm_nt_mulsub", doh, Dp, vh, ds, Skp, p, Skp, delta, Sqp, Skp, Dp, float(scale), BH, Sqp * Dp,
+             Skp * Dp, Sqp * Skp)
+    zp, i0 = _ops.zero_page(dev), lib.int_array([0])
+    dvf = _alloc((BH, Skp, Dp), torch.float32, dev)
+    dkf = _alloc((BH, Skp, Dp), torch.float32, dev)
+    lib.call("siss_gemm_tn", p, Skp, doh, Dp, dvf, Skp * Dp, Skp, Dp, 1, i0, i0, BH, Sqp, Sqp, 0, Sqp, -1, zp, None, None)
+    khT = _alloc((BH, Dp, Skp), torch.bfloat16, dev)
+    lib.call("siss_transpose_bf16", kh, khT, BH, Skp, Dp)
+    dqh = _alloc((BH, Sqp, Dp), torch.bfloat16, dev)
+    _ops.gemm_nt(lib.ptr(ds), Skp, khT, lib.ptr(dqh), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
+                 stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
+    lib.call("siss_gemm_tn", ds, Skp, qh, Dp, dkf, Skp * Dp, Skp, Dp, 1, i0, i0, BH, Sqp, Sqp, 0, Sqp, -1, zp, None, None)
+
+    def merge(th, S, Sp):
+        out = torch.empty(B, S, C, dtype=torch.bfloat16, device=dev)
+        lib.call("siss_head_merge", th.to(torch.bfloat16), out, B, S, heads, D, Sp, Dp)
+        return out.float()
+    return merge(dqh, Sq, Sqp), merge(dkf, Sk, Skp), merge(dvf, Sk, Skp)
+
+
+@attention_backward.register_fake
+def _(do, q, k, v, heads, scale):
+    f = lambda t: t.new_empty(t.shape, dtype=torch.float32)
+    return f(q), f(k), f(v)
+
+
+def _attn_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], inputs[2])
+    ctx.heads, ctx.scale = inputs[3], inputs[4]
+
+
+def _attn_bwd(ctx, g):
+    q, k, v = ctx.saved_tensors
+    dq, dk, dv = torch.ops.siss.attention_backward(g.contiguous(), q, k, v, ctx.heads, ctx.scale)
+    return dq, dk, dv, None, None
+
+
+attention.register_autograd(_attn_bwd, setup_context=_attn_setup)
