@@ -13,8 +13,15 @@ launches per call is:
     siss::ddpm_step        x, eps, noise, sqrt_a, sqrt_b, c_x0, c_xt, sigma, clip -> x_prev
     siss::recombine_clip_adamw_   g_x, g_a, p, m, v, scalars, partials, ... -> ()   (in place: p, m, v, scalars)
 
+and, as DIFFERENTIABLE ops (autograd through the HIP backward kernels; layout conversion at the op boundary):
+
+    siss::conv2d_3x3       x [N,Ci,H,W], w [Co,Ci,3,3], bias -> y           (MFMA fprop / dgrad / wgrad)
+    siss::groupnorm_silu   x [N,C,H,W], gamma, beta, groups, eps, silu -> y
+    siss::attention        q [B,Sq,C], k, v [B,Sk,C], heads, scale -> softmax(q k^T scale) v
+
 Import this module to register them (``import siss_amd.torch_ops``).
 """
+import os
 from typing import Tuple
 
 import torch
@@ -238,7 +245,7 @@ def _up(n, m):
     return -(-n // m) * m
 
 
-_SLACK = int(__import__("os").environ.get("SISS_OPS_SLACK", "1024"))
+_SLACK = int(os.environ.get("SISS_OPS_SLACK", "1024"))
 
 
 def _alloc(shape, dtype, dev):

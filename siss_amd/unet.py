@@ -179,6 +179,9 @@ class UNetEngine:
         # blocks leave too few VGPRs for co-resident blocks) while per-kernel times inflate, so it is opt-in.
         import os
         self.side = torch.cuda.Stream(device=self.device) if os.environ.get("SISS_SIDE_STREAM", "0") == "1" else None
+        # only wgrads over at most this many rows per set go to the side stream (the low-resolution levels, whose
+        # grids leave CUs idle); 0 = all of them
+        self.side_max_rows = int(os.environ.get("SISS_SIDE_MAX_ROWS", "0"))
 
     # ------------------------------------------------------------------ parameters
     def _early_blocks(self):
@@ -385,8 +388,8 @@ class UNetEngine:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def _on_side(self, fn, reads):
-        if self.side is None:
+    def _on_side(self, fn, reads, rows=0):
+        if self.side is None or (self.side_max_rows and rows > self.side_max_rows):
             fn()
             return
         ready = torch.cuda.Event()
@@ -511,7 +514,7 @@ class UNetEngine:
         nsets = self.nsets
         self._on_side(lambda: lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or x.c, dW_view, ps.total, co, ci, t,
                                        sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2),
-                      reads=[dy])
+                      reads=[dy, x], rows=re - rb)
 
     # ------------------------------------------------------------------ time embedding
     def time_embed(self, t):
