@@ -198,7 +198,8 @@ def main():
     graph = None
     # Multi-GPU: the step contains an RCCL all-reduce; capturing a collective into a hipGraph is not something
     # this repo can test (no multi-GPU box in the build loop), and the eager schedule is GPU-bound anyway
-    # (86 vs 85 ms at N=1), so N>1 launches eagerly unless SISS_GRAPH_DP=1.
+    # (67.75 ms eager vs 67.71 ms replayed at N=1 on the same box, end of round 1), so N>1 launches eagerly unless
+    # SISS_GRAPH_DP=1.
     use_graph = a.graph and (world == 1 or os.environ.get("SISS_GRAPH_DP") == "1")
     if use_graph:
         side = torch.cuda.Stream()
