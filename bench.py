@@ -214,18 +214,49 @@ def main():
         sync()
     run = graph.replay if graph is not None else one_step
 
+    # one event per step boundary on the launch stream (~1 us each): the per-step distribution SURVEY.md §8d asks for
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        marks[i].record()
         run()
+    marks[a.steps].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)
+    step_ms = {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9), "source": "HIP events between consecutive steps, rank 0"}
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     ms = dt / a.steps * 1e3
     stats = st.stats()
+
+    # ---- N > 1: the exchange on its own (untimed leg): one all-reduce of the flat [g_x ; g_a] buffer, SURVEY.md §8e ----
+    exchange = None
+    if world > 1:
+        from siss_amd.dp import allreduce_flat_grads
+        g = eng.ps.grads
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        allreduce_flat_grads(g, pg)                      # warm the communicator
+        sync()
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            allreduce_flat_grads(g, pg)
+        e1.record()
+        sync()
+        tt = torch.tensor([e0.elapsed_time(e1) / reps], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        ar_ms, nbytes = float(tt.item()), g.numel() * g.element_size()
+        bus = 2 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9
+        exchange = {"payload_bytes": nbytes, "allreduce_ms": round(ar_ms, 3),
+                    "alg_GBps": round(nbytes / (ar_ms * 1e-3) / 1e9, 1), "bus_GBps": round(bus, 1),
+                    "bus_GBps_per_link": round(bus / min(world - 1, 7), 1),
+                    "note": "bus = 2 (N-1)/N x payload / time; per link = bus / min(N-1, 7) xGMI links per GPU"}
+        eng.zero_grad()
 
     # ---- per-kernel timing of the dominant kernels (eager, HIP events on the launch stream) ----
     roof = None
@@ -296,14 +327,15 @@ def main():
                       + ("SD-v1.5 UNet SISS (secondary; BASELINE metric is the CelebA-HQ line)" if sd else "CelebA-HQ-256 DDPM SISS"),
             "value": round(steps_per_sec * B * GA * world, 3), "unit": "samples/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-            "steps_per_sec": round(steps_per_sec, 4),
+            "steps_per_sec": round(steps_per_sec, 4), "step_ms": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": workload,
                        "loss_fn": a.loss_fn, "global_batch": B * GA * world, "grad_accum": GA, "parallelism": f"dp{world}",
                        "hipgraph": bool(use_graph),
                        **({"dp_exchange": "overlapped" if st.overlap else "serial",
-                           "dp_autotune": getattr(st, "overlap_timings", None)} if world > 1 else {})},
+                           "dp_autotune": getattr(st, "overlap_timings", None),
+                           "dp_allreduce": exchange} if world > 1 else {})},
             "step_tflop_algorithmic": step_tflop,
             "step_mfma_frac": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if step_tflop else None,
             "roofline": roof, "cpu_baseline": cpu,
