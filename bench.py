@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 FWD_GFLOP_PER_SAMPLE = 498.35          # SURVEY.md §8d (2*MAC: conv + linear + attention matmuls + GN)
 SD_FWD_GFLOP_PER_SAMPLE = 803.9        # SD v1 UNet at 64x64 latents, 77 text tokens
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0                 # HBM3E (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -271,8 +272,12 @@ def main():
         prof, lib.PROF = lib.PROF, None
     if not a.no_kernel_timing and rank == 0:
         ksym = {}
-        for name, s, e, work, _, sym in prof:
+        hbm = {}
+        for name, s, e, work, _, sym, nbytes in prof:
             dt_ms = s.elapsed_time(e)
+            if nbytes:
+                h = hbm.setdefault(name, [0, 0.0, 0.0])
+                h[0] += 1; h[1] += dt_ms; h[2] += nbytes
             d = kern.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1; d[1] += dt_ms; d[2] += work
             if work:
@@ -293,6 +298,12 @@ def main():
                 "launches_per_step": n // ksteps, "avg_launch_us": round(tms / n * 1e3, 2),
                 "tflop_per_launch": round(work / n / 1e12, 4),
                 "share_of_step_kernel_time": round(tms / tot_ms, 3),
+                # the HBM-bound launchers of the step (K1, K5, K10-12), each against the HBM peak:
+                # ALGORITHMIC bytes (operands read once, results written once; lib.hbm_bytes) / summed launch time
+                "hbm_kernels": {k: {"achieved": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                    "frac": round(v[2] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 3),
+                                    "launches_per_step": v[0] // ksteps, "ms_per_step": round(v[1] / ksteps, 3)}
+                                for k, v in sorted(hbm.items(), key=lambda kv: -kv[1][1])},
                 "all_mfma_kernels": {k: {"achieved": round(v[2] / (v[1] * 1e-3) / 1e12, 2), "launches_per_step": v[0] // ksteps,
                                          "avg_launch_us": round(v[1] / v[0] * 1e3, 2),
                                          "share_of_step_kernel_time": round(v[1] / tot_ms, 3)}
@@ -306,7 +317,12 @@ def main():
                                                 "downsample_padding", "flip_sin_to_cos", "freq_shift")
                   + (("cross_attention_dim",) if sd else ())}
         cdt, cores = cpu_baseline(cfg_kw, 42, sd)
-        cpu = {"value": round(CPU_SAMPLE_BATCH / cdt, 5), "unit": "samples/sec", "cores": cores, "kind": "port",
+        try:
+            model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except Exception:
+            model = None
+        cpu = {"value": round(CPU_SAMPLE_BATCH / cdt, 5), "unit": "samples/sec", "cores": cores, "cpu_model": model,
+               "kind": "port",
                "sample": f"1 optimizer step at batch {CPU_SAMPLE_BATCH} ({CPU_SAMPLE_BATCH}/{B} of the per-GPU "
                          f"batch) of the same UNet/resolution, fp32 torch CPU oracle, {cdt:.1f} s",
                "steps_per_sec_at_bs%d" % B: round(CPU_SAMPLE_BATCH / (cdt * B), 6)}

@@ -148,6 +148,25 @@ def _work(name, a):
     return 0.0
 
 
+def hbm_bytes(name, a):
+    """ALGORITHMIC HBM bytes of one launch of the HBM-bound launchers (every operand read once, every
+    result written once), for bench.py's GB/s-vs-HBM-peak figures.  None for the others."""
+    if name == "siss_groupnorm_fwd":            # read x + write y (bf16)
+        return 2.0 * 2 * a[7] * a[8] * a[9] * a[10]
+    if name == "siss_groupnorm_bwd":            # read x (nx samples), read dy + write dx (n2 samples) (+ accum reads)
+        px = a[21] * a[22] * a[23]
+        n2, nx = a[17], a[18]
+        extra = (1 if a[7] is not None else 0) + (1 if a[8] is not None else 0)
+        return 2.0 * px * (nx + (2 + extra) * n2)
+    if name == "siss_recombine_clip_adamw":     # read g_x, g_a, theta, m, v; write theta, m, v (f32)
+        return 32.0 * a[7]
+    if name == "siss_mixture_fwd":              # read x0, a0, noise; write x_mix
+        return 4.0 * (2 if a[3] else 4) * a[10] * a[11]
+    if name == "siss_loss_bwd_seed":            # read pred (f32), x_mix, x0, a0; write c_x, c_a (f32)
+        return (4 + 3 * (2 if a[4] else 4) + 8.0) * a[10] * a[11]
+    return None
+
+
 def _shape_key(name, a):
     """Problem shape of a launch, for per-layer breakdowns (tools/step_breakdown.py)."""
     if name == "siss_gemm_nt":
@@ -192,7 +211,7 @@ def call(name, *args):
         s.record()
         rc = fn(*conv, stream_ptr())
         e.record()
-        PROF.append((name, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args)))
+        PROF.append((name, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args), hbm_bytes(name, args)))
     else:
         rc = fn(*conv, stream_ptr())
     if rc != 0:

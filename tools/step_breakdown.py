@@ -58,7 +58,7 @@ def main():
     torch.cuda.synchronize()
     prof, lib.PROF = lib.PROF, None
     rows = {}
-    for name, s, e, work, key, _sym in prof:
+    for name, s, e, work, key, _sym, _bytes in prof:
         d = rows.setdefault((name, key), [0, 0.0, 0.0])
         d[0] += 1; d[1] += s.elapsed_time(e); d[2] += work
     tot = sum(v[1] for v in rows.values())
