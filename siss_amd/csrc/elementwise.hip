@@ -84,6 +84,19 @@ __global__ void concat_kernel(const bf16_t* __restrict__ a, const bf16_t* __rest
         *reinterpret_cast<u32x4_t*>(out + row * C + c * 8) = v;
     }
 }
+// out[..., Ca:] = b only: the head columns were written in place by their producer (conv epilogue with ldc = Ca + Cb)
+__global__ void concat_tail_kernel(const bf16_t* __restrict__ b, bf16_t* __restrict__ out, int N, int H, int W,
+                                   int Ca, int Cb) {
+    const int C = Ca + Cb, cb = Cb / 8;
+    const long total = (long)N * H * W * cb;
+    FOR_CHUNKS(total) {
+        const int c = i % cb; long r = i / cb;
+        const int x = r % W; r /= W;
+        const int y = r % H; const int n = r / H;
+        const long row = prow(n, y, x, H, W);
+        *reinterpret_cast<u32x4_t*>(out + row * C + Ca + c * 8) = *reinterpret_cast<const u32x4_t*>(b + row * Cb + c * 8);
+    }
+}
 // da = dcat[..., :Ca] (overwrite) ; db (+)= dcat[..., Ca:]
 __global__ void concat_bwd_kernel(const bf16_t* __restrict__ dcat, bf16_t* __restrict__ da,
                                   bf16_t* __restrict__ db, int accumulate_b, int N, int H, int W, int Ca,
@@ -298,6 +311,12 @@ int siss_upsample2x_bwd(const void* dout, void* din, int N, int H, int W, int C,
 int siss_concat(const void* a, const void* b, void* out, int N, int H, int W, int Ca, int Cb, void* stream) {
     SISS_CHECK_ARG(a && b && out && EW_ARGS_OK(N, H, W, Ca) && Cb > 0 && Cb % 8 == 0);
     concat_kernel<<<grid_for((long)N * H * W * ((Ca + Cb) / 8)), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, N, H, W, Ca, Cb);
+    SISS_LAUNCH_RET();
+}
+/* out[..., Ca:] = b (padded NHWC, interior pixels); out's first Ca columns are left as their producer wrote them. */
+int siss_concat_tail(const void* b, void* out, int N, int H, int W, int Ca, int Cb, void* stream) {
+    SISS_CHECK_ARG(b && out && EW_ARGS_OK(N, H, W, Ca) && Cb > 0 && Cb % 8 == 0);
+    concat_tail_kernel<<<grid_for((long)N * H * W * (Cb / 8)), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)b, (bf16_t*)out, N, H, W, Ca, Cb);
     SISS_LAUNCH_RET();
 }
 int siss_concat_bwd(const void* dcat, void* da, void* db, int accumulate_b, int N, int H, int W, int Ca, int Cb,

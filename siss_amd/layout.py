@@ -79,6 +79,29 @@ class Act:
                      + p[:, :, -1].abs().sum()) == 0)
 
 
+class ActView:
+    """Columns [c0, c0 + c) of a wider padded activation `base` (row stride ld = base.c).  A conv whose result is about
+    to be concatenated writes straight into the concat buffer through one of these (GEMM epilogue with ldc = ld), so
+    the concat only has to copy the other part."""
+
+    __slots__ = ("base", "c0", "n", "h", "w", "c", "ld", "cat_parts", "cat_done")
+
+    def __init__(self, base, c0, c):
+        assert 0 <= c0 and c0 + c <= base.c and c0 % 8 == 0 and c % 8 == 0
+        self.base, self.c0, self.c, self.ld = base, c0, c, base.c
+        self.n, self.h, self.w = base.n, base.h, base.w
+        self.cat_parts, self.cat_done = None, False
+
+    hp = property(lambda self: self.h + 2)
+    wp = property(lambda self: self.w + 2)
+    rows_per_image = property(lambda self: self.hp * self.wp)
+    rows = property(lambda self: self.n * self.rows_per_image)
+
+    @property
+    def data(self):
+        return self.base.data[:, self.c0:self.c0 + self.c]
+
+
 def conv3x3_panels(wp, cin):
     """(shifts, coffs) of the nine 3x3 taps in flat padded row space; tap = ky*3 + kx."""
     shifts = [(ky - 1) * wp + (kx - 1) for ky in range(3) for kx in range(3)]

@@ -40,6 +40,7 @@ SIGNATURES = {
     "siss_upsample2x": [P, P, I, I, I, I, P],
     "siss_upsample2x_bwd": [P, P, I, I, I, I, P],
     "siss_concat": [P, P, P, I, I, I, I, I, P],
+    "siss_concat_tail": [P, P, I, I, I, I, I, P],
     "siss_concat_bwd": [P, P, P, I, I, I, I, I, I, P],
     "siss_add_inplace": [P, P, I, I, I, I, P],
     "siss_space_to_depth": [P, P, I, I, I, I, P],

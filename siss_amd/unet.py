@@ -23,7 +23,7 @@ import torch
 
 from . import lib, ops
 from .config import UNet2DConfig
-from .layout import Act
+from .layout import Act, ActView
 
 ALIGN = 64  # floats; keeps every bf16 shadow slice 128-B aligned
 _BUSY = {}   # id(buffer) -> event recorded on the side stream after the last wgrad that reads the buffer
@@ -182,6 +182,8 @@ class UNetEngine:
         # only wgrads over at most this many rows per set go to the side stream (the low-resolution levels, whose
         # grids leave CUs idle); 0 = all of them
         self.side_max_rows = int(os.environ.get("SISS_SIDE_MAX_ROWS", "0"))
+        # convs that feed a concat write into the concat buffer directly (SISS_DIRECT_CAT=0: copy both parts)
+        self.direct_cat = os.environ.get("SISS_DIRECT_CAT", "1") == "1"
 
     # ------------------------------------------------------------------ parameters
     def _early_blocks(self):
@@ -469,14 +471,20 @@ class UNetEngine:
             return dx
         return y, bwd
 
-    def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None, ldrb=None):
-        """stride-1 'same' conv (3x3 or 1x1) with fused bias / time-embedding row bias / residual."""
+    def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None, ldrb=None, cat_with=None):
+        """stride-1 'same' conv (3x3 or 1x1) with fused bias / time-embedding row bias / residual.  cat_with: the skip
+        activation the result is about to be concatenated with -- the result is then written straight into the head
+        columns of that concat buffer (epilogue with ldc = C + C_skip) and concat() only copies the skip."""
         ps = self.ps
         w = ps.sh(pre + ".weight")
         if ksize == 1:
             w = w.view(1, *w.shape)
         co = w.shape[1]
-        y = self._act(self._name(out_name or pre), x.n, x.h, x.w, co)
+        if cat_with is not None and self.direct_cat:
+            assert (cat_with.n, cat_with.h, cat_with.w) == (x.n, x.h, x.w)
+            y = ActView(self._act(self._name("cat"), x.n, x.h, x.w, co + cat_with.c), 0, co)
+        else:
+            y = self._act(self._name(out_name or pre), x.n, x.h, x.w, co)
         ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
 
         def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None):
@@ -552,7 +560,7 @@ class UNetEngine:
         self.tape.append(bwd)
 
     # ------------------------------------------------------------------ blocks
-    def resnet(self, x: Act, pre):
+    def resnet(self, x: Act, pre, cat_with=None):
         ps = self.ps
         cin = x.c
         cout = ps.specs[pre + ".conv1.weight"].ref_shape[0]
@@ -567,7 +575,7 @@ class UNetEngine:
             res = sc
         else:
             res = x
-        out, c2_b = self.conv(a2, pre + ".conv2", residual=res)
+        out, c2_b = self.conv(a2, pre + ".conv2", residual=res, cat_with=cat_with)
 
         def bwd():
             nb = self.nb
@@ -757,12 +765,12 @@ class UNetEngine:
         self.tape.append(bwd)
         return y
 
-    def upsample(self, x: Act, pre):
+    def upsample(self, x: Act, pre, cat_with=None):
         ps = self.ps
         C, B = x.c, x.n
         u = self._act(self._name(pre + ".u"), B, 2 * x.h, 2 * x.w, C)
         lib.call("siss_upsample2x", x.data, u.data, B, x.h, x.w, C)
-        y, c_b = self.conv(u, pre + ".conv")
+        y, c_b = self.conv(u, pre + ".conv", cat_with=cat_with)
 
         def bwd():
             dy = self._take(y)
@@ -776,8 +784,13 @@ class UNetEngine:
         return y
 
     def concat(self, a: Act, b: Act):
-        out = self._act(self._name("cat"), a.n, a.h, a.w, a.c + b.c)
-        lib.call("siss_concat", a.data, b.data, out.data, a.n, a.h, a.w, a.c, b.c)
+        if isinstance(a, ActView):              # a's producer wrote it into the head columns already (conv(cat_with=b))
+            out = a.base
+            assert a.c0 == 0 and out.c == a.c + b.c and (b.n, b.h, b.w) == (a.n, a.h, a.w)
+            lib.call("siss_concat_tail", b.data, out.data, a.n, a.h, a.w, a.c, b.c)
+        else:
+            out = self._act(self._name("cat"), a.n, a.h, a.w, a.c + b.c)
+            lib.call("siss_concat", a.data, b.data, out.data, a.n, a.h, a.w, a.c, b.c)
         out.cat_parts, out.cat_done = (a, b), False
 
         def bwd():
@@ -825,15 +838,18 @@ class UNetEngine:
                 skips.append(h)
         h = self.resnet(h, "mid_block.resnets.0")
         h = self.attention(h, "mid_block.attentions.0")
-        h = self.resnet(h, "mid_block.resnets.1")
+        h = self.resnet(h, "mid_block.resnets.1", cat_with=skips[-1])
         for (i, cout_b, attn, up, rs) in self.plan_up:
             for j in range(len(rs)):
                 h = self.concat(h, skips.pop())
-                h = self.resnet(h, f"up_blocks.{i}.resnets.{j}")
+                # a resnet whose output goes straight into the next concat (no attention / upsample in between)
+                # writes it into that concat buffer
+                direct = bool(skips) and not attn and not (j == len(rs) - 1 and up)
+                h = self.resnet(h, f"up_blocks.{i}.resnets.{j}", cat_with=skips[-1] if direct else None)
                 if attn:
                     h = self.attention(h, f"up_blocks.{i}.attentions.{j}")
             if up:
-                h = self.upsample(h, f"up_blocks.{i}.upsamplers.0")
+                h = self.upsample(h, f"up_blocks.{i}.upsamplers.0", cat_with=skips[-1] if skips else None)
         assert not skips
         return self._head(h)
 
