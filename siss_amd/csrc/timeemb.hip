@@ -136,27 +136,50 @@ __global__ __launch_bounds__(kThreads) void multi_fwd_kernel(const float* __rest
     }
 }
 
-// dW[set][woff[n] + k] += sum_{m in set} dy[m][n] * silu(x[m % Mx][k]) ; db / db2 likewise (k == 0)
-__global__ void multi_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ G,
-                                    const long* __restrict__ woff, const long* __restrict__ boff,
-                                    const long* __restrict__ boff2, int M2, int Mx, int set_rows, long set_stride,
-                                    int Ntot, int K) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nsets = M2 / set_rows;
-    if (i >= (long)nsets * Ntot * K) return;
-    const int set = i / ((long)Ntot * K);
-    const long rem = i - (long)set * Ntot * K;
-    const int n = rem / K, k = rem - (long)n * K;
-    float acc = 0.f, bsum = 0.f;
-    for (int j = 0; j < set_rows; ++j) {
-        const int m = set * set_rows + j;
-        const float d = dy[(long)m * Ntot + n];
-        acc += d * silu_f(x[(long)(m % Mx) * K + k]);
-        bsum += d;
+// dW[set][woff[n] + k] += sum_{m in set} dy[m][n] * silu(x[m % Mx][k]) ; db / db2 likewise.
+// grid (K / 256, Ntot / 32, nsets); thread = one k, 32 columns per block: silu(x) is evaluated once per (row, k) and
+// block -- not once per (row, k, column) -- and the 32 x 32 cotangent tile of each row chunk sits in LDS (broadcast reads).
+constexpr int kDwCols = 32, kDwRows = 32;
+__global__ __launch_bounds__(256) void multi_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ G,
+                                                           const long* __restrict__ woff, const long* __restrict__ boff,
+                                                           const long* __restrict__ boff2, int Mx, int set_rows, long set_stride,
+                                                           int Ntot, int K) {
+    __shared__ float sdy[kDwRows][kDwCols + 1];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n0 = blockIdx.y * kDwCols, set = blockIdx.z;
+    const int ncols = Ntot - n0 < kDwCols ? Ntot - n0 : kDwCols;
+    float acc[kDwCols];
+#pragma unroll
+    for (int c = 0; c < kDwCols; ++c) acc[c] = 0.f;
+    float bsum = 0.f;                                       // threads < ncols of the blocks with blockIdx.x == 0
+    for (int j0 = 0; j0 < set_rows; j0 += kDwRows) {
+        const int nr = set_rows - j0 < kDwRows ? set_rows - j0 : kDwRows;
+        __syncthreads();
+        for (int i = threadIdx.x; i < kDwRows * kDwCols; i += 256) {
+            const int r = i / kDwCols, c = i - r * kDwCols;
+            sdy[r][c] = (r < nr && c < ncols) ? dy[(long)(set * set_rows + j0 + r) * Ntot + n0 + c] : 0.f;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < ncols)
+            for (int r = 0; r < nr; ++r) bsum += sdy[r][threadIdx.x];
+        if (k < K) {
+            for (int r = 0; r < nr; ++r) {
+                const float sx = silu_f(x[(long)((set * set_rows + j0 + r) % Mx) * K + k]);
+#pragma unroll
+                for (int c = 0; c < kDwCols; ++c) acc[c] += sdy[r][c] * sx;
+            }
+        }
     }
     float* g = G + (long)set * set_stride;
-    g[woff[n] + k] += acc;
-    if (k == 0) { g[boff[n]] += bsum; g[boff2[n]] += bsum; }
+    if (k < K) {
+#pragma unroll
+        for (int c = 0; c < kDwCols; ++c)
+            if (c < ncols) g[woff[n0 + c] + k] += acc[c];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ncols) {
+        g[boff[n0 + threadIdx.x]] += bsum;
+        g[boff2[n0 + threadIdx.x]] += bsum;
+    }
 }
 
 // dx[m][k] += sum_n dy[m][n] * W_n[k]     grid: (K / 256, Ntot / 64); thread = one k, 64 columns per block
@@ -235,8 +258,8 @@ int siss_linear_multi_bwd(const float* dy, const float* x, const float* params, 
     SISS_CHECK_ARG(dy && x && params && grads && woff && boff && boff2 && dx);
     SISS_CHECK_ARG(M2 > 0 && M2 <= kMaxM && Mx > 0 && set_rows > 0 && M2 % set_rows == 0 && Ntot > 0 && K > 0);
     hipStream_t st = (hipStream_t)stream;
-    const long tot = (long)(M2 / set_rows) * Ntot * K;
-    multi_bwd_dw_kernel<<<cdiv(tot, 256), 256, 0, st>>>(dy, x, grads, woff, boff, boff2, M2, Mx, set_rows, set_stride, Ntot, K);
+    const dim3 gw(cdiv(K, 256), cdiv(Ntot, kDwCols), M2 / set_rows);
+    multi_bwd_dw_kernel<<<gw, 256, 0, st>>>(dy, x, grads, woff, boff, boff2, Mx, set_rows, set_stride, Ntot, K);
     dim3 grid(cdiv(K, 256), cdiv(Ntot, 64), cdiv(M2, 64));
     multi_bwd_dx_kernel<<<grid, 256, 0, st>>>(dy, params, woff, dx, M2, Ntot, K);
     SISS_LAUNCH_RET();
