@@ -361,3 +361,40 @@ def test_siss_step_edge_cases_match_oracle(setup, lambd, B):
     _check_scalars(ref, got)
     inv = (1 - lambd) * st.last["iw_x"] + lambd * st.last["iw_a"]
     assert torch.allclose(inv.cpu(), torch.ones(B), atol=1e-4)
+
+
+def test_direct_concat_writes_equal_the_copying_concat(monkeypatch):
+    """Up-path convs write straight into the head columns of the concat buffer (ActView, ldc = C + C_skip) and
+    siss_concat_tail copies only the skip: forward and gradients must be BITWISE what the two-sided copy gives (same
+    kernels, same operand values, different destination stride), and every concat of the ladder must take that path."""
+    from siss_amd import lib
+    from siss_amd.layout import ActView
+    from siss_amd.unet import UNetEngine
+    hc, _ = _cfgs()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 16, 16, generator=g).cuda()
+    t = torch.tensor([999, 500, 3, 999]).cuda()
+    cot = (torch.randn(8, 3, 16, 16, generator=g) * 1e-2).cuda()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SISS_DIRECT_CAT", mode)
+        eng = UNetEngine(hc, "cuda:0")
+        eng.init_random(seed=1)
+        calls = []
+        orig = lib.call
+        monkeypatch.setattr(lib, "call", lambda name, *a, _o=orig, _c=calls: (_c.append(name), _o(name, *a))[1])
+        pred = eng.forward(x, t).clone()
+        monkeypatch.setattr(lib, "call", orig)
+        eng.zero_grad()
+        eng.backward(cot, nsets=2)
+        torch.cuda.synchronize()
+        outs[mode] = (pred, eng.ps.grads.clone(), calls)
+    tails, fulls = outs["1"][2].count("siss_concat_tail"), outs["1"][2].count("siss_concat")
+    # AttnUpBlock2D outputs come from the attention block (no view): only those concats copy both sides
+    assert tails > 0 and tails + fulls == outs["0"][2].count("siss_concat") and outs["0"][2].count("siss_concat_tail") == 0
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    ga, gb = outs["1"][1], outs["0"][1]
+    # wgrad accumulates through f32 atomics: equal up to summation order
+    assert float((ga - gb).norm() / gb.norm()) < 1e-5
+    v = ActView(eng._act("probe", 2, 4, 4, 24), 0, 16)
+    assert v.ld == 24 and tuple(v.data.shape) == (v.rows, 16) and v.data.data_ptr() == v.base.data.data_ptr()
