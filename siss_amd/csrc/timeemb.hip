@@ -182,34 +182,30 @@ __global__ __launch_bounds__(256) void multi_bwd_dw_kernel(const float* __restri
     }
 }
 
-// dx[m][k] += sum_n dy[m][n] * W_n[k]     grid: (K / 256, Ntot / 64); thread = one k, 64 columns per block
+// dx[m][k] += sum_n dy[m][n] * W_n[k]     grid: (K / 256, M2, column splits); thread = one (m, k) output over one split
+// of kDxSplit columns: the cotangent dy[m][n] and the row offset woff[n] are block-uniform (scalar loads), W_n[k] is one
+// coalesced row read, and each thread ends with ONE atomic -- Ntot / kDxSplit-way contention instead of Ntot / 64
+// (the previous form, 64 atomics per thread from 160 column blocks into one [M2][K] array, spent 143 us on them).
+constexpr int kDxSplit = 512;
 __global__ __launch_bounds__(256) void multi_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ P,
                                                            const long* __restrict__ woff, float* __restrict__ dx,
                                                            int M2, int Ntot, int K) {
-    __shared__ float shd[64][65];   // [m][col]
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const int n0 = blockIdx.y * 64;
-    const int mb = blockIdx.z * 64;                     // 64 cotangent rows per block (any batch size)
-    dy += (long)mb * Ntot; dx += (long)mb * K;
-    M2 = M2 - mb < 64 ? M2 - mb : 64;
-    for (int i = threadIdx.x; i < M2 * 64; i += 256) {
-        const int m = i / 64, c = i - m * 64;
-        shd[m][c] = (n0 + c < Ntot) ? dy[(long)m * Ntot + n0 + c] : 0.f;
-    }
-    __syncthreads();
+    const int m = blockIdx.y;
+    const int n0 = blockIdx.z * kDxSplit;
+    const int n1 = n0 + kDxSplit < Ntot ? n0 + kDxSplit : Ntot;
     if (k >= K) return;
-    float acc[64];
-#pragma unroll
-    for (int m = 0; m < 64; ++m) acc[m] = 0.f;
-    for (int c = 0; c < 64 && n0 + c < Ntot; ++c) {
-        const float w = P[woff[n0 + c] + k];
-#pragma unroll
-        for (int m = 0; m < 64; ++m)
-            if (m < M2) acc[m] += shd[m][c] * w;
+    const float* d = dy + (long)m * Ntot;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int n = n0;
+    for (; n + 4 <= n1; n += 4) {
+        a0 += d[n] * P[woff[n] + k];
+        a1 += d[n + 1] * P[woff[n + 1] + k];
+        a2 += d[n + 2] * P[woff[n + 2] + k];
+        a3 += d[n + 3] * P[woff[n + 3] + k];
     }
-#pragma unroll
-    for (int m = 0; m < 64; ++m)
-        if (m < M2) atomicAdd(dx + (long)m * K + k, acc[m]);
+    for (; n < n1; ++n) a0 += d[n] * P[woff[n] + k];
+    atomicAdd(dx + (long)m * K + k, (a0 + a1) + (a2 + a3));
 }
 
 }  // namespace
@@ -260,7 +256,7 @@ int siss_linear_multi_bwd(const float* dy, const float* x, const float* params, 
     hipStream_t st = (hipStream_t)stream;
     const dim3 gw(cdiv(K, 256), cdiv(Ntot, kDwCols), M2 / set_rows);
     multi_bwd_dw_kernel<<<gw, 256, 0, st>>>(dy, x, grads, woff, boff, boff2, Mx, set_rows, set_stride, Ntot, K);
-    dim3 grid(cdiv(K, 256), cdiv(Ntot, 64), cdiv(M2, 64));
+    dim3 grid(cdiv(K, 256), M2, cdiv(Ntot, kDxSplit));
     multi_bwd_dx_kernel<<<grid, 256, 0, st>>>(dy, params, woff, dx, M2, Ntot, K);
     SISS_LAUNCH_RET();
 }
