@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void conv_out_fprop_mfma_kernel(
     // L1 / L2 (the first version strode whole-image segments over the grid and pulled 6.6x the activation bytes
     // from HBM: profiles/r01j_hbm_traffic.json).  Items are handed out XCD-contiguously (blocks b, b+8, ... share
     // an L2), neighbouring column segments to the four waves of a block.
-    constexpr int kBand = 4;
+    constexpr int kBand = 8;
     const int bands = (H + kBand - 1) / kBand;
     const long nitems = (long)B * bands * segs;
     const long nblk = gridDim.x;
@@ -138,48 +138,47 @@ __global__ __launch_bounds__(kThreads) void conv_out_fprop_mfma_kernel(
     for (long item = bid * (kThreads / 64) + wv; item < nitems; item += nblk * (kThreads / 64)) {
       const int sx = item % segs; long tt = item / segs;
       const int band = tt % bands; const int n = tt / bands;
-      const int y_end = (band + 1) * kBand < H ? (band + 1) * kBand : H;
-      for (int y = band * kBand; y < y_end; ++y) {
-        const int xx = sx * 16 + px;
-        const bool ok = xx < W;
-        const int xc = ok ? xx : W - 1;
-        const bf16_t* base = x + (((long)n * (H + 2) + y + 1) * Wp + xc + 1) * C + kg * 8;
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        // One filter row (three kx taps) x four 32-channel chunks at a time: the 12 activation loads are all issued
-        // before the first MFMA consumes one (a load -> MFMA -> load chain exposed a full memory round trip 36
-        // times per pixel row and ran this kernel at 1/5 of the HBM rate); two accumulators break the MFMA chain.
-        f32x4_t acc2 = {0.f, 0.f, 0.f, 0.f};
+      const int y0 = band * kBand;
+      const int y_end = y0 + kBand < H ? y0 + kBand : H;
+      const int xx = sx * 16 + px;
+      const bool ok = xx < W;
+      const int xc = ok ? xx : W - 1;
+      // The wave walks the INPUT rows r = y0-1 .. y_end of its band (padded rows: the halo supplies the zeros).  Input
+      // row r feeds output row r+1 through filter row 0, r through row 1 and r-1 through row 2, so its twelve
+      // fragments (3 kx x 4 channel chunks) are loaded ONCE and used by 36 MFMAs into three rotating accumulators:
+      // a third of the L1 traffic of the per-output-row form (which re-read every input row for each ky and ran at
+      // 1/5 of the HBM rate).
+      f32x4_t accP = {0.f, 0.f, 0.f, 0.f}, accC = accP, accN = accP;      // output rows r-1, r, r+1
+      for (int r = y0 - 1; r <= y_end; ++r) {
+        const bf16_t* base = x + (((long)n * (H + 2) + r + 1) * Wp + xc + 1) * C + kg * 8;
         for (int kc0 = 0; kc0 < kchunks; kc0 += 4) {
+            bf16x8_t bf[3][4];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                bf16x8_t bf[3][4];
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bf16_t* bp = base + (long)((ky - 1) * Wp + (kx - 1)) * C;
+                for (int j = 0; j < 4; ++j)
+                    bf[kx][j] = kc0 + j < kchunks ? *reinterpret_cast<const bf16x8_t*>(base + (long)(kx - 1) * C + (kc0 + j) * 32) : zero;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        bf[kx][j] = kc0 + j < kchunks ? *reinterpret_cast<const bf16x8_t*>(bp + (kc0 + j) * 32) : zero;
-                }
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bf16_t* ap = sw + ((ky * 3 + kx) * CO + (px < CO ? px : 0)) * C + kg * 8;
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int ky = 0; ky < 3; ++ky) {       // innermost: three independent accumulator chains
+                        const bf16_t* ap = sw + ((ky * 3 + kx) * CO + (px < CO ? px : 0)) * C + kg * 8;
                         bf16x8_t a = kc0 + j < kchunks ? *reinterpret_cast<const bf16x8_t*>(ap + (kc0 + j) * 32) : zero;
                         if (px >= CO) a = zero;
-                        if (j & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[kx][j], acc2, 0, 0, 0);
-                        else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[kx][j], acc, 0, 0, 0);
+                        if (ky == 0) accN = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[kx][j], accN, 0, 0, 0);
+                        else if (ky == 1) accC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[kx][j], accC, 0, 0, 0);
+                        else accP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[kx][j], accP, 0, 0, 0);
                     }
-                }
-            }
         }
+        // output row r-1 has now seen its three input rows; acc[q] = output channel 4*(lane>>4) + q of pixel lane&15
+        const int yo = r - 1;
+        if (yo >= y0 && yo < y_end && kg == 0 && ok) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
-        // acc[r] = output channel 4*(lane>>4) + r of pixel lane&15
-        if (kg == 0 && ok) {
-#pragma unroll
-            for (int r = 0; r < CO; ++r) pred[(((long)n * CO + r) * H + y) * W + xx] = acc[r] + bias[r];
+            for (int q = 0; q < CO; ++q) pred[(((long)n * CO + q) * H + yo) * W + xx] = accP[q] + bias[q];
         }
+        accP = accC; accC = accN; accN = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
     }
 }
@@ -305,7 +304,7 @@ int siss_conv_out_fprop(const void* x, const float* w, const float* bias, float*
     static int use_mfma = -1;
     if (use_mfma < 0) { const char* e = getenv("SISS_CONV_OUT_MFMA"); use_mfma = e ? atoi(e) : 1; }
     if (use_mfma && C % 32 == 0) {
-        long nb = ((long)B * ((H + 3) / 4) * ((W + 15) / 16) + 3) / 4;        // 4-row x 16-pixel items, 4 per block
+        long nb = ((long)B * ((H + 7) / 8) * ((W + 15) / 16) + 3) / 4;        // 8-row x 16-pixel items, 4 per block
         if (nb > 256 * 8) nb = 256 * 8;
         DISPATCH_CO(CO, (conv_out_fprop_mfma_kernel<kCO><<<(int)nb, kThreads, 9 * kCO * C * sizeof(bf16_t), st>>>((const bf16_t*)x, w, bias, pred, B, H, W, C)));
         SISS_LAUNCH_RET();
