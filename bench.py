@@ -238,25 +238,32 @@ def main():
     # ---- N > 1: the exchange on its own (untimed leg): one all-reduce of the flat [g_x ; g_a] buffer, SURVEY.md §8e ----
     exchange = None
     if world > 1:
-        from siss_amd.dp import allreduce_flat_grads
+        from siss_amd.dp import EXCHANGES
         g = eng.ps.grads
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        allreduce_flat_grads(g, pg)                      # warm the communicator
-        sync()
-        reps = 5
-        e0.record()
-        for _ in range(reps):
-            allreduce_flat_grads(g, pg)
-        e1.record()
-        sync()
-        tt = torch.tensor([e0.elapsed_time(e1) / reps], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        ar_ms, nbytes = float(tt.item()), g.numel() * g.element_size()
-        bus = 2 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9
-        exchange = {"payload_bytes": nbytes, "allreduce_ms": round(ar_ms, 3),
-                    "alg_GBps": round(nbytes / (ar_ms * 1e-3) / 1e9, 1), "bus_GBps": round(bus, 1),
-                    "bus_GBps_per_link": round(bus / min(world - 1, 7), 1),
-                    "note": "bus = 2 (N-1)/N x payload / time; per link = bus / min(N-1, 7) xGMI links per GPU"}
+        nbytes = g.numel() * g.element_size()
+        exchange = {"payload_bytes": nbytes,
+                    "note": "bus = 2 (N-1)/N x payload / time; per link = bus / min(N-1, 7) xGMI links per GPU; "
+                            "allreduce = RCCL all-reduce, direct = all-to-all reduce-scatter + all-gather (siss_amd/dp.py)"}
+        timings = getattr(st, "overlap_timings", None) or {}
+        for name, fn in EXCHANGES.items():
+            if name == "direct" and "serial_direct_ms" not in timings and timings:
+                continue                                  # the autotune's probe found no all-to-all on this backend
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g.fill_(1e-3)
+            fn(g, pg)                                     # warm the communicator
+            sync()
+            reps = 5
+            e0.record()
+            for _ in range(reps):
+                fn(g, pg)
+            e1.record()
+            sync()
+            tt = torch.tensor([e0.elapsed_time(e1) / reps], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            ms_x = float(tt.item())
+            bus = 2 * (world - 1) / world * nbytes / (ms_x * 1e-3) / 1e9
+            exchange[name] = {"ms": round(ms_x, 3), "alg_GBps": round(nbytes / (ms_x * 1e-3) / 1e9, 1),
+                              "bus_GBps": round(bus, 1), "bus_GBps_per_link": round(bus / min(world - 1, 7), 1)}
         eng.zero_grad()
 
     # ---- per-kernel timing of the dominant kernels (eager, HIP events on the launch stream) ----
@@ -349,7 +356,7 @@ def main():
             "config": {"workload": workload,
                        "loss_fn": a.loss_fn, "global_batch": B * GA * world, "grad_accum": GA, "parallelism": f"dp{world}",
                        "hipgraph": bool(use_graph),
-                       **({"dp_exchange": "overlapped" if st.overlap else "serial",
+                       **({"dp_exchange": "overlapped all-reduce" if st.overlap else "serial " + st.exchange,
                            "dp_autotune": getattr(st, "overlap_timings", None),
                            "dp_allreduce": exchange} if world > 1 else {})},
             "step_tflop_algorithmic": step_tflop,

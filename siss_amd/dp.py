@@ -20,6 +20,40 @@ def allreduce_flat_grads(flat_pair, group=None):
     return flat_pair
 
 
+_SCRATCH = {}
+
+
+def direct_exchange_flat_grads(flat_pair, group=None):
+    """The same sum over ranks as `allreduce_flat_grads`, as a DIRECT reduce-scatter + all-gather:
+    every rank sends slice j of its flat pair straight to rank j (one all-to-all: all 7 xGMI links of a GPU carry
+    S/8 each, concurrently, instead of a ring pushing 2 (N-1)/N S over one link), sums the N slices it received in
+    rank order, and the reduced slices are all-gathered back.  Each element is summed by exactly ONE rank in a fixed
+    order, so the replicas are bit-identical by construction.  Falls back to the all-reduce when the buffer does not
+    split evenly."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_pair
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world <= 1:
+        return flat_pair
+    flat = flat_pair.view(-1)
+    n = flat.numel()
+    if n % world != 0 or not flat_pair.is_contiguous():
+        return allreduce_flat_grads(flat_pair, group)
+    shard = n // world
+    key = (flat.device, flat.dtype, n, world)
+    scratch = _SCRATCH.get(key)
+    if scratch is None:
+        scratch = _SCRATCH[key] = torch.empty(n + shard, dtype=flat.dtype, device=flat.device)
+    recv, mine = scratch[:n], scratch[n:]
+    dist.all_to_all_single(recv, flat, group=group)                 # recv[i*shard:(i+1)*shard] = rank i's slice `rank`
+    torch.sum(recv.view(world, shard), dim=0, out=mine)             # fixed rank order
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    return flat_pair
+
+
+EXCHANGES = {"allreduce": allreduce_flat_grads, "direct": direct_exchange_flat_grads}
+
+
 def recombine_reference(gx, ga, scaling_norm, max_norm=1.0):
     """Closed form of delete_celeb.py:725-767 on flat tensors (host-side check for the DP tests)."""
     nx, na = float(gx.norm()), float(ga.norm())

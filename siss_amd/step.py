@@ -20,7 +20,7 @@ the single-process step on the concatenated batch.
 import torch
 
 from . import lib
-from .dp import allreduce_flat_grads
+from .dp import EXCHANGES, allreduce_flat_grads
 from .loss import loss_bwd_seed, mixture_fwd, mse_bwd_seed
 from .optim import FlatAdamW
 from .unet import UNetEngine
@@ -62,12 +62,18 @@ class SISSStepper:
         # ~85 % of the bytes) is final long before the high-resolution down blocks finish their backward;
         # its all-reduce is started from a hook inside the backward pass and runs beside the rest of it.
         import os
+        self.exchange = os.environ.get("SISS_DP_EXCHANGE", "allreduce")      # serial mode: "allreduce" | "direct"
+        assert self.exchange in EXCHANGES
         self.set_overlap(self.pg is not None and self.world > 1 and engine.ps.split < engine.ps.total
                          and os.environ.get("SISS_DP_OVERLAP", "1") != "0")
 
-    def set_overlap(self, on):
-        """Overlapped (tail all-reduce started from inside the backward) or serial (one all-reduce after it)."""
+    def set_overlap(self, on, exchange=None):
+        """Overlapped (tail all-reduce started from inside the backward) or serial (one exchange after it: RCCL's
+        all-reduce, or the direct all-to-all reduce-scatter + all-gather of dp.direct_exchange_flat_grads)."""
         self.overlap = bool(on)
+        if exchange is not None:
+            assert exchange in EXCHANGES
+            self.exchange = exchange
         self.e.on_early_grads_final = self._early_allreduce if self.overlap else None
 
     def autotune_overlap(self, step_fn, iters=3):
@@ -78,10 +84,20 @@ class SISSStepper:
             return self.overlap
         import time
         dist = torch.distributed
-        results = {}
-        for mode in (True, False):
-            self.set_overlap(mode)
-            step_fn()                                            # settle
+        from .dp import direct_exchange_flat_grads
+        results, errors = {}, {}
+        candidates = {"overlap": (True, "allreduce"), "serial": (False, "allreduce"), "serial_direct": (False, "direct")}
+        try:                                                     # a backend without all-to-all keeps the all-reduce
+            probe = torch.ones(2, 8 * self.world, device=self.e.device)
+            direct_exchange_flat_grads(probe, self.pg)
+            torch.cuda.synchronize()
+            assert float(probe.sum()) == 16.0 * self.world * self.world
+        except (RuntimeError, AssertionError, NotImplementedError) as exc:
+            errors["serial_direct"] = (str(exc) or type(exc).__name__)[:200]
+            del candidates["serial_direct"]
+        for name, (mode, exch) in candidates.items():
+            self.set_overlap(mode, exch)
+            step_fn()                                            # settle (scratch buffers, communicator channels)
             dist.barrier(group=self.pg); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(iters):
@@ -89,9 +105,12 @@ class SISSStepper:
             dist.barrier(group=self.pg); torch.cuda.synchronize()
             tt = torch.tensor([time.perf_counter() - t0], device=self.e.device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
-            results[mode] = float(tt.item()) / iters
-        self.set_overlap(results[True] <= results[False])
-        self.overlap_timings = {"overlap_ms": results[True] * 1e3, "serial_ms": results[False] * 1e3}
+            results[name] = float(tt.item()) / iters
+        best = min(results, key=results.get)
+        self.set_overlap(best == "overlap", "direct" if best == "serial_direct" else "allreduce")
+        self.overlap_timings = {k + "_ms": v * 1e3 for k, v in results.items()}
+        if errors:
+            self.overlap_timings["errors"] = errors
         return self.overlap
 
     # ------------------------------------------------------------------ one micro-batch
@@ -205,7 +224,7 @@ class SISSStepper:
                     w.wait()
                 self._pending = []
             else:
-                allreduce_flat_grads(g, self.pg)
+                EXCHANGES[self.exchange](g, self.pg)
         single = self.loss_fn in (NEG_GRAD, NAIVE)
         self.opt.launch(g, scaling_norm=self.scaling_norm if not single else 1.0,
                         eta=self.eta if self.loss_fn == ERASEDIFF else None,

@@ -77,7 +77,21 @@ def main():
     choice = st3.autotune_overlap(lambda: st3.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl]), iters=1)
     flags = [None] * world
     dist.all_gather_object(flags, bool(choice))
-    assert len(set(flags)) == 1 and set(st3.overlap_timings) == {"overlap_ms", "serial_ms"}
+    keys = set(st3.overlap_timings)
+    # the direct exchange (all-to-all reduce-scatter + all-gather) is timed too when the backend has an all-to-all for
+    # device tensors; otherwise the probe's error is recorded and the all-reduce kept
+    assert len(set(flags)) == 1 and {"overlap_ms", "serial_ms"} <= keys <= {"overlap_ms", "serial_ms", "serial_direct_ms", "errors"}
+    assert ("serial_direct_ms" in keys) != ("errors" in keys), st3.overlap_timings
+    if "serial_direct_ms" in keys:
+        # ... and gives the all-reduce's update
+        eng.load_state_dict(sd)
+        st4 = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, **kw)
+        st4.set_overlap(False, "direct")
+        st4.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
+        d3 = eng.ps.flat - base
+        cos = float((d3 * d2).sum() / (d3.norm() * d2.norm()))
+        assert cos > 0.999, cos
+    print("dp exchange timings", rank, st3.overlap_timings)
     dist.barrier()
     dist.destroy_process_group()
     print("dp gpu ok", rank)

@@ -169,7 +169,7 @@ sys.path.insert(0, sys.argv[1])
 from oracle import schedule as S
 from oracle.loss import OracleDeletionLoss, siss_terms, mix
 from oracle.toy import ToyEps
-from siss_amd.dp import allreduce_flat_grads, recombine_reference
+from siss_amd.dp import allreduce_flat_grads, direct_exchange_flat_grads, recombine_reference
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 ac = S.alphas_cumprod(); gam, sig = S.gamma_sigma(ac)
@@ -191,7 +191,15 @@ def flat_pair(sl):
     return torch.stack([torch.cat([v.flatten() for v in gx]), torch.cat([v.flatten() for v in ga])])
 per = Bg // world
 mine = flat_pair(slice(rank * per, (rank + 1) * per))
+direct = mine.clone()
 allreduce_flat_grads(mine)
+# the direct exchange (all-to-all reduce-scatter + all-gather) is the same sum, replicas bit-identical
+if direct.numel() % world:
+    direct = torch.cat([direct, torch.zeros(2, 1)], 1).contiguous()
+direct_exchange_flat_grads(direct)
+torch.testing.assert_close(direct[:, :mine.shape[1]], mine, rtol=1e-6, atol=1e-7)
+both = [torch.zeros_like(direct) for _ in range(world)]; dist.all_gather(both, direct)
+assert all(torch.equal(both[0], q) for q in both)
 whole = flat_pair(slice(0, Bg))                       # single-process global-batch oracle
 torch.testing.assert_close(mine, whole, rtol=1e-4, atol=1e-6)
 g1, s1 = recombine_reference(mine[0], mine[1], 5.0); g2, s2 = recombine_reference(whole[0], whole[1], 5.0)
