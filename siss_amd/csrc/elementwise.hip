@@ -134,7 +134,7 @@ __global__ void add_inplace_kernel(bf16_t* __restrict__ a, const bf16_t* __restr
 }
 
 // space-to-depth: Z[n, i, j, (py*2+px)*C + c] = in[n, 2i+py, 2j+px, c]     (Z is H/2 x W/2 x 4C)
-__global__ void s2d_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ z, int N, int H, int W, int C) {
+__global__ void s2d_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ z, int N, int H, int W, int C, int ld_in) {
     const int cc = C / 8, Ho = H / 2, Wo = W / 2;
     const long total = (long)N * H * W * cc;
     FOR_CHUNKS(total) {
@@ -143,7 +143,7 @@ __global__ void s2d_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ z
         const int y = r % H; const int n = r / H;
         const int plane = (y & 1) * 2 + (x & 1);
         *reinterpret_cast<u32x4_t*>(z + prow(n, y >> 1, x >> 1, Ho, Wo) * (4 * C) + plane * C + c * 8) =
-            *reinterpret_cast<const u32x4_t*>(in + prow(n, y, x, H, W) * C + c * 8);
+            *reinterpret_cast<const u32x4_t*>(in + prow(n, y, x, H, W) * ld_in + c * 8);
     }
 }
 // inverse (depth-to-space) with optional accumulation into din
@@ -330,10 +330,14 @@ int siss_add_inplace(void* a, const void* b, int N, int H, int W, int C, void* s
     add_inplace_kernel<<<grid_for((long)N * H * W * (C / 8)), kThreads, 0, (hipStream_t)stream>>>((bf16_t*)a, (const bf16_t*)b, N, H, W, C);
     SISS_LAUNCH_RET();
 }
-int siss_space_to_depth(const void* in, void* z, int N, int H, int W, int C, void* stream) {
-    SISS_CHECK_ARG(in && z && EW_ARGS_OK(N, H, W, C) && H % 2 == 0 && W % 2 == 0);
-    s2d_kernel<<<grid_for((long)N * H * W * (C / 8)), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)in, (bf16_t*)z, N, H, W, C);
+/* ld_in: row stride of `in` in elements (0 = C; > C when `in` is a column view of a wider concat buffer) */
+int siss_space_to_depth_ld(const void* in, void* z, int N, int H, int W, int C, int ld_in, void* stream) {
+    SISS_CHECK_ARG(in && z && EW_ARGS_OK(N, H, W, C) && H % 2 == 0 && W % 2 == 0 && (ld_in == 0 || (ld_in >= C && ld_in % 8 == 0)));
+    s2d_kernel<<<grid_for((long)N * H * W * (C / 8)), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)in, (bf16_t*)z, N, H, W, C, ld_in ? ld_in : C);
     SISS_LAUNCH_RET();
+}
+int siss_space_to_depth(const void* in, void* z, int N, int H, int W, int C, void* stream) {
+    return siss_space_to_depth_ld(in, z, N, H, W, C, 0, stream);
 }
 int siss_depth_to_space(const void* dz, void* din, int accumulate, int N, int H, int W, int C, void* stream) {
     SISS_CHECK_ARG(dz && din && EW_ARGS_OK(N, H, W, C) && H % 2 == 0 && W % 2 == 0);

@@ -28,6 +28,7 @@ struct GNShape {
     int H, W, C, G, cpg, lpp, ppi;     // lanes per pixel (C/8), pixels per iteration
     int chunk_px, nchunks;             // interior pixels per block, blocks per sample
     int ld, Gf, nslices;               // row stride (= full channel count), full group count, channel slices
+    int ldx;                           // row stride of the INPUT x (> ld when x is a column view of a concat buffer)
 };
 
 __device__ __forceinline__ long compact_row(int n, int pi, int H, int W) { return (long)n * H * W + pi; }
@@ -92,14 +93,14 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const bf16_t* __rest
     const bool active = slot < s.ppi;
     float a[8] = {}, b[8] = {};
     if (active) {
-        const bf16_t* base = x + (long)n * (s.H + 2) * (s.W + 2) * s.ld + c0 + cc * 8;
+        const bf16_t* base = x + (long)n * (s.H + 2) * (s.W + 2) * s.ldx + c0 + cc * 8;
         PixelWalk w(s, chunk, slot);
         while (w.ok()) {                       // two pixels per trip: both loads are in flight together
-            const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ld);
+            const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ldx);
             w.next();
             const bool two = w.ok();
             u32x4_t r1 = u32x4_t{0u, 0u, 0u, 0u};
-            if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ld); w.next(); }
+            if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ldx); w.next(); }
             float v[8], u[8];
             unpack8(r0, v); unpack8(r1, u);
 #pragma unroll
@@ -175,18 +176,18 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
         sf[e] = beta[c0 + c] - sh_mean[g] * sc[e];
     }
     const long img = (long)n * (s.H + 2) * (s.W + 2);
-    const bf16_t* base = x + img * s.ld + c0 + cc * 8;
+    const bf16_t* base = x + img * s.ldx + c0 + cc * 8;
     y += c0;
     auto out_row = [&](const PixelWalk& w) { return out_compact ? compact_row(n, w.pi, s.H, s.W) : img + w.row(); };
     PixelWalk w(s, chunk, slot);
     while (w.ok()) {
-        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ld);
+        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ldx);
         const long o0 = out_row(w);
         w.next();
         const bool two = w.ok();
         u32x4_t r1 = u32x4_t{0u, 0u, 0u, 0u};
         long o1 = 0;
-        if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ld); o1 = out_row(w); w.next(); }
+        if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ldx); o1 = out_row(w); w.next(); }
         float v[8], u[8];
         unpack8(r0, v); unpack8(r1, u);
 #pragma unroll
@@ -230,13 +231,13 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
             ga[e] = gamma[c]; be[e] = beta[c];
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
-        const bf16_t* xb = x + (long)n * rpi * s.ld + c0 + cc * 8;
+        const bf16_t* xb = x + (long)n * rpi * s.ldx + c0 + cc * 8;
         // Software pipeline: the loads of pixel i+1 (x + one dy per set) are issued BEFORE pixel i is consumed, so
         // the memory pipe never drains while the SiLU' arithmetic runs (4-5 waves per SIMD only).
         PixelWalk w(s, chunk, slot);
         u32x4_t nx_x = u32x4_t{0u, 0u, 0u, 0u}, nx_d[SETS];
         auto issue = [&](const PixelWalk& q, u32x4_t& ox, u32x4_t (&od)[SETS]) {
-            ox = *reinterpret_cast<const u32x4_t*>(xb + q.row() * s.ld);
+            ox = *reinterpret_cast<const u32x4_t*>(xb + q.row() * s.ldx);
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
                 const int n2 = k * nx + n;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
             for (int k = 0; k < SETS; ++k) { m1[k][e] = sh_s1[k][g]; m2[k][e] = sh_s2[k][g]; }
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
-        const bf16_t* xb = x + (long)n * rpi * s.ld + c0 + cc * 8;
+        const bf16_t* xb = x + (long)n * rpi * s.ldx + c0 + cc * 8;
         const int ch = c0 + cc * 8;                       // first channel of this lane in the full tensor
         // Output routing: one tensor of C channels, or (dx2 != null: the input was a channel concat)
         // channels [0, split_c) -> dx (row stride split_c) and [split_c, C) -> dx2 (row stride C - split_c,
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
         // stored.  Reading the next pixel's accum / output before this pixel's store is safe: different rows.
         struct In { u32x4_t x, d[SETS], a[SETS], b[SETS], c[SETS]; };
         auto issue = [&](const PixelWalk& q, In& o) {
-            o.x = *reinterpret_cast<const u32x4_t*>(xb + q.row() * s.ld);
+            o.x = *reinterpret_cast<const u32x4_t*>(xb + q.row() * s.ldx);
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
                 const int n2 = k * nx + n;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
 
 bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16) {
     if (H <= 0 || W <= 0 || C <= 0 || G <= 0 || G > kMaxG || C % G || C % 8) return false;
-    s.H = H; s.W = W; s.ld = C; s.Gf = G; s.cpg = C / G;
+    s.H = H; s.W = W; s.ld = C; s.ldx = C; s.Gf = G; s.cpg = C / G;
     int gs = G;                                         // groups per slice
     if (C > kMaxC) {
         // the largest whole-group slice of <= kMaxC channels (a multiple of 8) that keeps >= 90 % of the
@@ -452,12 +453,15 @@ long siss_gn_partial_words(int n, int H, int W, int C, int G) {
 }
 
 // y = act(GroupNorm(x)); x padded NHWC; y padded or compact ([N][H*W][C]).  Writes mean/rstd [N][G].
-int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                       float* rstd, float* partial, int N, int H, int W, int C, int G, float eps,
-                       int silu, int out_compact, void* stream) {
+// ldx: row stride of x in elements (0 = C; > C when x is a column view of a wider concat buffer).
+int siss_groupnorm_fwd_ld(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                          float* rstd, float* partial, int N, int H, int W, int C, int G, float eps,
+                          int silu, int out_compact, int ldx, void* stream) {
     GNShape s;
     SISS_CHECK_ARG(x && gamma && beta && y && mean && rstd && partial && N > 0);
     SISS_CHECK_ARG(make_shape(H, W, C, G, s, N));
+    SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
+    if (ldx) s.ldx = ldx;
     SISS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, N, s.nslices);
@@ -468,6 +472,12 @@ int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, voi
         gn_apply_kernel<false><<<grid, kThreads, 0, st>>>((const bf16_t*)x, gamma, beta, partial, s, eps, out_compact, (bf16_t*)y, mean, rstd);
     SISS_LAUNCH_RET();
 }
+/* the same with ldx = C */
+int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                       float* rstd, float* partial, int N, int H, int W, int C, int G, float eps,
+                       int silu, int out_compact, void* stream) {
+    return siss_groupnorm_fwd_ld(x, gamma, beta, y, mean, rstd, partial, N, H, W, C, G, eps, silu, out_compact, 0, stream);
+}
 
 // dx (padded, n2 samples) from dy (n2 samples, padded or compact) and the saved x (nx samples,
 // x index = n2 % nx).  dgamma/dbeta: [sets][...] accumulated atomically at set = n2 / set_images
@@ -475,11 +485,12 @@ int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, voi
 // dx2 (optional): the normalised input was a channel concat -- channels [0, split_c) of the result go to dx
 // (row stride split_c), channels [split_c, C) to dx2 (row stride C - split_c; += when accumulate2);
 // colsum (optional, f32 rows of colsum_ld floats, pre-zeroed) receives the per-sample channel sums of dx.
-int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
-                       const float* mean, const float* rstd, void* dx, const void* accum, const void* accum2,
-                       void* dx2, int split_c, int accumulate2, float* dgamma,
-                       float* dbeta, float* colsum, long colsum_ld, float* partial, int n2, int nx, int set_images,
-                       long set_stride, int H, int W, int C, int G, int silu, int dy_compact, void* stream) {
+// ldx: row stride of the saved x in elements (0 = C).
+int siss_groupnorm_bwd_ld(const void* dy, const void* x, const float* gamma, const float* beta,
+                          const float* mean, const float* rstd, void* dx, const void* accum, const void* accum2,
+                          void* dx2, int split_c, int accumulate2, float* dgamma,
+                          float* dbeta, float* colsum, long colsum_ld, float* partial, int n2, int nx, int set_images,
+                          long set_stride, int H, int W, int C, int G, int silu, int dy_compact, int ldx, void* stream) {
     GNShape s;
     SISS_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && partial);
     SISS_CHECK_ARG(n2 > 0 && nx > 0 && set_images > 0 && n2 % set_images == 0);
@@ -487,6 +498,8 @@ int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const 
     SISS_CHECK_ARG(make_shape(H, W, C, G, s, nx));
     SISS_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)accum | (uintptr_t)accum2 | (uintptr_t)dx2) % 16 == 0);
     SISS_CHECK_ARG(!dx2 || (split_c > 0 && split_c < C && split_c % 8 == 0));
+    SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
+    if (ldx) s.ldx = ldx;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, nx, s.nslices);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;
@@ -500,6 +513,16 @@ int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const 
     else          { if (silu) { GN_BWD(true, 2); } else { GN_BWD(false, 2); } }
 #undef GN_BWD
     SISS_LAUNCH_RET();
+}
+/* the same with ldx = C */
+int siss_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
+                       const float* mean, const float* rstd, void* dx, const void* accum, const void* accum2,
+                       void* dx2, int split_c, int accumulate2, float* dgamma,
+                       float* dbeta, float* colsum, long colsum_ld, float* partial, int n2, int nx, int set_images,
+                       long set_stride, int H, int W, int C, int G, int silu, int dy_compact, void* stream) {
+    return siss_groupnorm_bwd_ld(dy, x, gamma, beta, mean, rstd, dx, accum, accum2, dx2, split_c, accumulate2, dgamma, dbeta,
+                                 colsum, colsum_ld, partial, n2, nx, set_images, set_stride, H, W, C, G, silu, dy_compact, 0,
+                                 stream);
 }
 
 }  // extern "C"

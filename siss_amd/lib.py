@@ -36,7 +36,9 @@ SIGNATURES = {
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
+    "siss_groupnorm_fwd_ld": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, I, P],
     "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],
+    "siss_groupnorm_bwd_ld": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, I, P],
     "siss_upsample2x": [P, P, I, I, I, I, P],
     "siss_upsample2x_bwd": [P, P, I, I, I, I, P],
     "siss_concat": [P, P, P, I, I, I, I, I, P],
@@ -44,6 +46,7 @@ SIGNATURES = {
     "siss_concat_bwd": [P, P, P, I, I, I, I, I, I, P],
     "siss_add_inplace": [P, P, I, I, I, I, P],
     "siss_space_to_depth": [P, P, I, I, I, I, P],
+    "siss_space_to_depth_ld": [P, P, I, I, I, I, I, P],
     "siss_depth_to_space": [P, P, I, I, I, I, I, P],
     "siss_pad_to_compact": [P, P, I, I, I, I, P],
     "siss_compact_add_to_pad": [P, P, P, I, I, I, I, P],
@@ -152,9 +155,9 @@ def _work(name, a):
 def hbm_bytes(name, a):
     """ALGORITHMIC HBM bytes of one launch of the HBM-bound launchers (every operand read once, every
     result written once), for bench.py's GB/s-vs-HBM-peak figures.  None for the others."""
-    if name == "siss_groupnorm_fwd":            # read x + write y (bf16)
+    if name in ("siss_groupnorm_fwd", "siss_groupnorm_fwd_ld"):            # read x + write y (bf16)
         return 2.0 * 2 * a[7] * a[8] * a[9] * a[10]
-    if name == "siss_groupnorm_bwd":            # read x (nx samples), read dy + write dx (n2 samples) (+ accum reads)
+    if name in ("siss_groupnorm_bwd", "siss_groupnorm_bwd_ld"):            # read x (nx samples), read dy + write dx (n2 samples) (+ accum reads)
         px = a[21] * a[22] * a[23]
         n2, nx = a[17], a[18]
         extra = (1 if a[7] is not None else 0) + (1 if a[8] is not None else 0)
@@ -174,9 +177,9 @@ def _shape_key(name, a):
         return ("M", a[10], "N", a[11], "K", a[12], "panels", a[13], "batch", a[20])
     if name == "siss_gemm_tn":
         return ("N", a[6], "C", a[7], "panels", a[8], "sets", a[11], "rows", a[15] - a[14], "splits", a[16])
-    if name == "siss_groupnorm_fwd":
+    if name in ("siss_groupnorm_fwd", "siss_groupnorm_fwd_ld"):
         return ("n", a[7], "H", a[8], "C", a[10])
-    if name == "siss_groupnorm_bwd":
+    if name in ("siss_groupnorm_bwd", "siss_groupnorm_bwd_ld"):
         return ("n2", a[17], "H", a[21], "C", a[23])
     return ()
 
@@ -212,7 +215,8 @@ def call(name, *args):
         s.record()
         rc = fn(*conv, stream_ptr())
         e.record()
-        PROF.append((name, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args), hbm_bytes(name, args)))
+        base = name[:-3] if name.endswith("_ld") else name          # row-stride variants count as their plain form
+        PROF.append((base, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args), hbm_bytes(name, args)))
     else:
         rc = fn(*conv, stream_ptr())
     if rc != 0:

@@ -58,9 +58,10 @@ def conv_fprop(x: Act, w_bf16, out: Act, bias=None, rowbias=None, residual: Act 
     else:
         shifts, coffs = [0], [0]
     assert t == len(shifts)
-    gemm_nt(lib.ptr(x.data), x.c, w_bf16, lib.ptr(out.data), getattr(out, "ld", out.c), x.rows, co, ci, shifts, coffs,
+    gemm_nt(lib.ptr(x.data), getattr(x, "ld", x.c), w_bf16, lib.ptr(out.data), getattr(out, "ld", out.c), x.rows, co, ci,
+            shifts, coffs,
             bias=bias, rowbias=rowbias, ldrb=ldrb, res_ptr=lib.ptr(residual.data) if residual is not None else None,
-            ldr=residual.c if residual is not None else 0,
+            ldr=getattr(residual, "ld", residual.c) if residual is not None else 0,
             rows_per_image=x.rows_per_image, hp=x.hp, wp=x.wp)
     return out
 

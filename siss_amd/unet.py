@@ -402,7 +402,7 @@ class UNetEngine:
             done = torch.cuda.Event()
             done.record(self.side)
         for a in reads:
-            _BUSY[id(a.buf)] = done
+            _BUSY[id(getattr(a, "base", a).buf)] = done
 
     def _put(self, a):
         if a is not None:
@@ -444,8 +444,10 @@ class UNetEngine:
         else:
             y = self._act(nm + ".y", x.n, x.h, x.w, x.c)
             yptr = y.data
-        lib.call("siss_groupnorm_fwd", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
-                 self._gn_partial(x.n, x.h, x.w, x.c), x.n, x.h, x.w, x.c, G, float(eps), int(silu), int(compact_out))
+        ldx = getattr(x, "ld", x.c)                 # x may be a column view of a concat buffer (ActView)
+        lib.call("siss_groupnorm_fwd_ld", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
+                 self._gn_partial(x.n, x.h, x.w, x.c), x.n, x.h, x.w, x.c, G, float(eps), int(silu), int(compact_out),
+                 0 if ldx == x.c else ldx)
 
         def bwd(dy, colsum=None, accum: Act = None, colsum_ld=0, accum2: Act = None, split=None):
             """dy: Act (padded) or compact tensor, nb samples.  Returns dx Act (nb samples).
@@ -462,16 +464,17 @@ class UNetEngine:
                 dx = accum if accum is not None else self._get(nb, x.h, x.w, x.c)
                 dx2p, split_c, accb = None, 0, False
             dyp = dy.data if isinstance(dy, Act) else dy
-            lib.call("siss_groupnorm_bwd", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
+            lib.call("siss_groupnorm_bwd_ld", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
                      dx.data, accum.data if accum is not None else None,
                      accum2.data if accum2 is not None else None, dx2p, split_c, int(accb),
                      ps.g(pre + ".weight", self.gbase), ps.g(pre + ".bias", self.gbase), colsum, colsum_ld,
                      self._gn_partial(nb, x.h, x.w, x.c), nb, x.n, self.set_images, ps.total,
-                     x.h, x.w, x.c, G, int(silu), int(not isinstance(dy, Act)))
+                     x.h, x.w, x.c, G, int(silu), int(not isinstance(dy, Act)), 0 if ldx == x.c else ldx)
             return dx
         return y, bwd
 
-    def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None, ldrb=None, cat_with=None):
+    def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None, ldrb=None, cat_with=None,
+             skip_head=None):
         """stride-1 'same' conv (3x3 or 1x1) with fused bias / time-embedding row bias / residual.  cat_with: the skip
         activation the result is about to be concatenated with -- the result is then written straight into the head
         columns of that concat buffer (epilogue with ldc = C + C_skip) and concat() only copies the skip."""
@@ -482,7 +485,15 @@ class UNetEngine:
         co = w.shape[1]
         if cat_with is not None and self.direct_cat:
             assert (cat_with.n, cat_with.h, cat_with.w) == (x.n, x.h, x.w)
-            y = ActView(self._act(self._name("cat"), x.n, x.h, x.w, co + cat_with.c), 0, co)
+            if isinstance(cat_with, ActView):       # the skip already lives in the tail columns of its concat buffer
+                assert cat_with.c0 == co and cat_with.base.c == co + cat_with.c
+                y = ActView(cat_with.base, 0, co)
+            else:
+                y = ActView(self._act(self._name("cat"), x.n, x.h, x.w, co + cat_with.c), 0, co)
+        elif skip_head is not None and self.direct_cat:
+            # this result is a SKIP: it goes straight into the tail columns of the concat buffer it will meet its
+            # up-path partner (skip_head channels) in; every down-path reader takes the row stride (ld)
+            y = ActView(self._act(self._name("cat"), x.n, x.h, x.w, skip_head + co), skip_head, co)
         else:
             y = self._act(self._name(out_name or pre), x.n, x.h, x.w, co)
         ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
@@ -520,7 +531,7 @@ class UNetEngine:
         ns = ops._nsplits(tiles, t, self.nsets, re - rb, ops.is_conv3_panels(shifts, coffs))
         sh, cf, zp = lib.int_array(shifts), lib.int_array(coffs), ops.zero_page(self.device)
         nsets = self.nsets
-        self._on_side(lambda: lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or x.c, dW_view, ps.total, co, ci, t,
+        self._on_side(lambda: lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or getattr(x, "ld", x.c), dW_view, ps.total, co, ci, t,
                                        sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2),
                       reads=[dy, x], rows=re - rb)
 
@@ -560,7 +571,7 @@ class UNetEngine:
         self.tape.append(bwd)
 
     # ------------------------------------------------------------------ blocks
-    def resnet(self, x: Act, pre, cat_with=None):
+    def resnet(self, x: Act, pre, cat_with=None, skip_head=None):
         ps = self.ps
         cin = x.c
         cout = ps.specs[pre + ".conv1.weight"].ref_shape[0]
@@ -575,7 +586,7 @@ class UNetEngine:
             res = sc
         else:
             res = x
-        out, c2_b = self.conv(a2, pre + ".conv2", residual=res, cat_with=cat_with)
+        out, c2_b = self.conv(a2, pre + ".conv2", residual=res, cat_with=cat_with, skip_head=skip_head)
 
         def bwd():
             nb = self.nb
@@ -714,12 +725,13 @@ class UNetEngine:
         self.tape.append(bwd)
         return out
 
-    def downsample(self, x: Act, pre):
+    def downsample(self, x: Act, pre, skip_head=None):
         """3x3 stride-2 conv (Downsample2D) as nine row-shifted panels over a space-to-depth copy."""
         ps, cfg = self.ps, self.cfg
         C, B, Ho, Wo = x.c, x.n, x.h // 2, x.w // 2
         z = self._act(self._name(pre + ".z"), B, Ho, Wo, 4 * C)
-        lib.call("siss_space_to_depth", x.data, z.data, B, x.h, x.w, C)
+        ldx = getattr(x, "ld", C)
+        lib.call("siss_space_to_depth_ld", x.data, z.data, B, x.h, x.w, C, 0 if ldx == C else ldx)
         wp = Wo + 2
         shifts, coffs = [], []
         for ky in range(3):
@@ -731,8 +743,11 @@ class UNetEngine:
                 shifts.append(dy_ * wp + dx_)
                 coffs.append((py * 2 + px) * C)
         w = ps.sh(pre + ".conv.weight")
-        y = self._act(self._name(pre + ".y"), B, Ho, Wo, C)
-        ops.gemm_nt(lib.ptr(z.data), 4 * C, w, lib.ptr(y.data), C, z.rows, C, C, shifts, coffs,
+        if skip_head is not None and self.direct_cat:
+            y = ActView(self._act(self._name("cat"), B, Ho, Wo, skip_head + C), skip_head, C)
+        else:
+            y = self._act(self._name(pre + ".y"), B, Ho, Wo, C)
+        ops.gemm_nt(lib.ptr(z.data), 4 * C, w, lib.ptr(y.data), getattr(y, "ld", C), z.rows, C, C, shifts, coffs,
                     bias=ps.p(pre + ".conv.bias"), rows_per_image=z.rows_per_image, hp=z.hp, wp=z.wp)
         # dgrad: the taps that read the same space-to-depth plane (py, px) WRITE the same plane of dz, so each
         # plane is one multi-panel GEMM (4 / 2 / 2 / 1 taps) over a plane-grouped copy of the transposed weights
@@ -784,10 +799,18 @@ class UNetEngine:
         return y
 
     def concat(self, a: Act, b: Act):
-        if isinstance(a, ActView):              # a's producer wrote it into the head columns already (conv(cat_with=b))
+        if isinstance(a, ActView) and a.c0 == 0 and a.base.c == a.c + b.c:
+            # a's producer wrote it into the head columns already (conv(cat_with=b))
             out = a.base
-            assert a.c0 == 0 and out.c == a.c + b.c and (b.n, b.h, b.w) == (a.n, a.h, a.w)
-            lib.call("siss_concat_tail", b.data, out.data, a.n, a.h, a.w, a.c, b.c)
+            assert (b.n, b.h, b.w) == (a.n, a.h, a.w)
+            if isinstance(b, ActView):          # ... and the skip was produced in the tail columns: nothing to copy
+                assert b.base is out and b.c0 == a.c
+            else:
+                lib.call("siss_concat_tail", b.data, out.data, a.n, a.h, a.w, a.c, b.c)
+        elif isinstance(b, ActView):            # skip in place, head from a producer without a view (attention)
+            out = b.base
+            assert b.c0 == a.c and out.c == a.c + b.c and not isinstance(a, ActView)
+            out.data[:, :a.c].copy_(a.data)
         else:
             out = self._act(self._name("cat"), a.n, a.h, a.w, a.c + b.c)
             lib.call("siss_concat", a.data, b.data, out.data, a.n, a.h, a.w, a.c, b.c)
@@ -821,7 +844,8 @@ class UNetEngine:
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
-        h = self._conv_in(x)
+        heads = self._skip_heads()                     # per skip, in push order: channels of its up-path partner
+        h = self._conv_in(x, skip_head=heads[0])
         skips = [h]
         early = self._early_blocks()
         self._early_mark = None
@@ -829,12 +853,13 @@ class UNetEngine:
             if self._early_mark is None and f"down_blocks.{i}." in early:
                 self._early_mark = len(self.tape)      # closures from here on belong to the early-final group
             for j in range(cfg.layers_per_block):
-                h = self.resnet(h, f"down_blocks.{i}.resnets.{j}")
+                # a conv-produced skip is written straight into the tail columns of the concat buffer it ends up in
+                h = self.resnet(h, f"down_blocks.{i}.resnets.{j}", skip_head=None if attn else heads[len(skips)])
                 if attn:
                     h = self.attention(h, f"down_blocks.{i}.attentions.{j}")
                 skips.append(h)
             if down:
-                h = self.downsample(h, f"down_blocks.{i}.downsamplers.0")
+                h = self.downsample(h, f"down_blocks.{i}.downsamplers.0", skip_head=heads[len(skips)])
                 skips.append(h)
         h = self.resnet(h, "mid_block.resnets.0")
         h = self.attention(h, "mid_block.attentions.0")
@@ -853,7 +878,25 @@ class UNetEngine:
         assert not skips
         return self._head(h)
 
-    def _conv_in(self, x):
+    def _skip_heads(self):
+        """For every skip connection, in PUSH order: the channel count of the up-path activation it will be concatenated
+        behind -- or None when that partner is not written through a view (attention output), in which case the skip
+        stays an ordinary activation and concat() copies.  Mirrors the up-path loop of forward()."""
+        cfg = self.cfg
+        remaining = 1 + sum(cfg.layers_per_block + (1 if down else 0) for (_, _, _, _, down) in self.plan_down)
+        heads, hc, direct = [], cfg.block_out_channels[-1], True        # mid_block.resnets.1 writes through a view
+        for (i, cout_b, attn, up, rs) in self.plan_up:
+            for j in range(len(rs)):
+                heads.append(hc if direct and self.direct_cat else None)
+                remaining -= 1
+                direct = remaining > 0 and not attn and not (j == len(rs) - 1 and up)
+                hc = cout_b
+            if up:
+                direct = remaining > 0                                     # the upsample conv writes through a view
+        assert remaining == 0
+        return heads[::-1]
+
+    def _conv_in(self, x, skip_head=None):
         """conv_in: im2col rows (K = 9*Cin padded to 64) then a one-panel GEMM."""
         cfg, ps = self.cfg, self.ps
         N, cin, H, W = x.shape
@@ -861,8 +904,11 @@ class UNetEngine:
         col = self._act("conv_in.col", N, H, W, kp)
         lib.call("siss_im2col3x3", x, int(x.dtype == torch.bfloat16), col.data, N, cin, H, W, kp, 0)
         c0 = cfg.block_out_channels[0]
-        h = self._act("conv_in.out", N, H, W, c0)
-        ops.gemm_nt(lib.ptr(col.data), kp, ps.sh("conv_in.weight"), lib.ptr(h.data), c0, col.rows, c0, kp, [0], [0],
+        if skip_head is not None and self.direct_cat:
+            h = ActView(self._act(self._name("cat"), N, H, W, skip_head + c0), skip_head, c0)
+        else:
+            h = self._act("conv_in.out", N, H, W, c0)
+        ops.gemm_nt(lib.ptr(col.data), kp, ps.sh("conv_in.weight"), lib.ptr(h.data), getattr(h, "ld", c0), col.rows, c0, kp, [0], [0],
                     bias=ps.p("conv_in.bias"), rows_per_image=col.rows_per_image, hp=col.hp, wp=col.wp)
         h0 = h
 

@@ -364,9 +364,9 @@ def test_siss_step_edge_cases_match_oracle(setup, lambd, B):
 
 
 def test_direct_concat_writes_equal_the_copying_concat(monkeypatch):
-    """Up-path convs write straight into the head columns of the concat buffer (ActView, ldc = C + C_skip) and
-    siss_concat_tail copies only the skip: forward and gradients must be BITWISE what the two-sided copy gives (same
-    kernels, same operand values, different destination stride), and every concat of the ladder must take that path."""
+    """Up-path convs write straight into the head columns of the concat buffer (ActView, ldc = C + C_skip), conv-produced
+    skips into its tail columns (every down-path reader takes the row stride): forward and gradients must be BITWISE
+    what the copying concat gives (same kernels, same operand values, different strides)."""
     from siss_amd import lib
     from siss_amd.layout import ActView
     from siss_amd.unet import UNetEngine
@@ -390,8 +390,10 @@ def test_direct_concat_writes_equal_the_copying_concat(monkeypatch):
         torch.cuda.synchronize()
         outs[mode] = (pred, eng.ps.grads.clone(), calls)
     tails, fulls = outs["1"][2].count("siss_concat_tail"), outs["1"][2].count("siss_concat")
-    # AttnUpBlock2D outputs come from the attention block (no view): only those concats copy both sides
-    assert tails > 0 and tails + fulls == outs["0"][2].count("siss_concat") and outs["0"][2].count("siss_concat_tail") == 0
+    # conv-produced skips live in the tail columns of their concat buffer from the start and conv-produced partners are
+    # written into its head columns: those concats copy NOTHING; attention outputs (no view) still copy
+    total = outs["0"][2].count("siss_concat")
+    assert total == 6 and outs["0"][2].count("siss_concat_tail") == 0 and tails + fulls < total, (tails, fulls, total)
     assert torch.equal(outs["1"][0], outs["0"][0])
     ga, gb = outs["1"][1], outs["0"][1]
     # wgrad accumulates through f32 atomics: equal up to summation order
