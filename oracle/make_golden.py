@@ -46,6 +46,37 @@ def inject_uniforms(u):
         torch.rand = real
 
 
+@contextlib.contextmanager
+def inject_rand_like(target):
+    """ErasEDiff draws its uniform target with torch.rand_like (ddpm_deletion_loss.py:75): hand back a recorded one."""
+    real = torch.rand_like
+
+    def fake(t, **kw):
+        assert tuple(t.shape) == tuple(target.shape), (t.shape, target.shape)
+        return target.clone().to(t.dtype)
+    torch.rand_like = fake
+    try:
+        yield
+    finally:
+        torch.rand_like = real
+
+
+@contextlib.contextmanager
+def seeded_rand_like(seed):
+    """torch.rand_like drawn from a private seeded generator: the same target sequence for the reference (when the
+    fixture is made) and for the oracle (when it is checked), across the micro-batches of a step."""
+    real = torch.rand_like
+    gen = torch.Generator().manual_seed(seed)
+
+    def fake(t, **kw):
+        return torch.rand(t.shape, generator=gen).to(t.dtype)
+    torch.rand_like = fake
+    try:
+        yield
+    finally:
+        torch.rand_like = real
+
+
 class RefLossWithU:
     """Adapter: same surface, but accepts ``u=`` and injects it into the reference."""
 
@@ -127,10 +158,22 @@ def loss_cases():
         cases[name].update(_np(dict(neg_loss=o3[0])))
         o4 = ref.naive_del(net, t, noise, {}, keep, forget)
         cases[name].update(_np(dict(naive_loss=o4[0])))
+        et = torch.rand(pred.shape, generator=g)           # ErasEDiff's uniform target, recorded (a-4)
+        with inject_rand_like(et):
+            o6 = ref.erasediff(net, t, noise, {}, keep, forget)
+        cases[name].update(_np(dict(erase_target=et, erase_loss_x=o6[1], erase_loss_a=o6[2])))
         if lambd < 1.0:   # the reference raises ZeroDivisionError at lambd == 1 (:110)
             o5 = ref.subscore_bernoulli(net, t, noise, {}, keep, forget, lambd, u=u)
             cases[name].update(_np(dict(bern_loss_x=o5[1], bern_loss_a=o5[2])))
     return cases
+
+
+STEP_ETA = 1.5        # large enough that the ErasEDiff branch s = -max(eta - <g_x, g_a> / |g_a|^2, 0) is non-zero in the fixture
+
+
+def step_loss_params(loss_fn):
+    return {"importance_sampling_with_mixture": {"lambd": 0.5}, "subscore_bernoulli": {"lambd": 0.5},
+            "simple_neg_del": {"superfactor": 2.0}}.get(loss_fn, {})
 
 
 def step_cases():
@@ -145,7 +188,12 @@ def step_cases():
             ("siss_step_ga1", "importance_sampling_with_mixture", 1, "t999"),
             ("siss_step_ga2", "importance_sampling_with_mixture", 2, "t999"),
             ("siss_step_tuniform", "importance_sampling_with_mixture", 1, "uniform"),
-            ("no_is_step", "double_forward_with_neg_del", 1, "t999")]:
+            ("no_is_step", "double_forward_with_neg_del", 1, "t999"),
+            # the baselines of delete_celeb.yaml's `deletion.loss_fn` choices (a-4), GA = 2 where the loop differs
+            ("erasediff_step", "erasediff", 2, "t999"),
+            ("neg_grad_step", "simple_neg_del", 1, "t999"),
+            ("naive_step", "naive_del", 2, "uniform"),
+            ("bernoulli_step", "subscore_bernoulli", 1, "t999")]:
         g = torch.Generator().manual_seed(4242 + ga + len(name))
         B, c, hw = 4, 3, 8
         net = ToyEps(c, seed=11)
@@ -164,15 +212,17 @@ def step_cases():
                 mbs.append(dict(x0=x0, a0=a0, noise=noise, t=t, u=u))
                 for kk, vv in mbs[-1].items():
                     rec[f"s{step}_m{k}_{kk}"] = vv
-            lp = {"lambd": 0.5} if "mixture" in loss_fn else {}
-            st, gx, ga_, gfin = unlearning_step(
-                net, opt, ref, loss_fn, ac, mbs, train_batch_size=B, scaling_norm=5.0,
-                loss_params=lp)
+            lp = step_loss_params(loss_fn)
+            with seeded_rand_like(977 + step):
+                st, gx, ga_, gfin = unlearning_step(
+                    net, opt, ref, loss_fn, ac, mbs, train_batch_size=B, scaling_norm=5.0,
+                    loss_params=lp, eta=STEP_ETA if loss_fn == "erasediff" else None)
             rec[f"s{step}_stats"] = np.array([st.norm_loss_x, st.norm_loss_a, st.scaling_factor,
                                               st.pre_clip_norm, st.weighted_loss_x, st.weighted_loss_a])
-            for n in gx:
-                rec[f"s{step}_gx/{n}"] = gx[n]
-                rec[f"s{step}_ga/{n}"] = ga_[n]
+            for n in gfin:
+                if gx is not None:
+                    rec[f"s{step}_gx/{n}"] = gx[n]
+                    rec[f"s{step}_ga/{n}"] = ga_[n]
                 rec[f"s{step}_g/{n}"] = gfin[n]
             for n, p in net.named_parameters():
                 rec[f"s{step}_param/{n}"] = p.detach().clone()

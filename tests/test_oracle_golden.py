@@ -28,7 +28,7 @@ def _loss_obj():
 
 
 def test_fixture_inventory():
-    assert len(LOSS_FILES) == 7 and len(STEP_FILES) == 4
+    assert len(LOSS_FILES) == 7 and len(STEP_FILES) == 8
 
 
 def test_schedule_known_answers():
@@ -64,6 +64,13 @@ def test_loss_matches_reference(path):
     torch.testing.assert_close(o3[0], _t(z["neg_loss"]), rtol=1e-6, atol=0)
     o4 = L.naive_del(net, t, noise, {}, keep, forget)
     torch.testing.assert_close(o4[0], _t(z["naive_loss"]), rtol=1e-6, atol=0)
+    # ErasEDiff (:70-78): loss_a against the recorded uniform target the reference drew with torch.rand_like
+    from oracle.make_golden import inject_rand_like
+    with inject_rand_like(_t(z["erase_target"])):
+        o6 = L.erasediff(net, t, noise, {}, keep, forget)
+    torch.testing.assert_close(o6[1], _t(z["erase_loss_x"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(o6[2], _t(z["erase_loss_a"]), rtol=1e-6, atol=0)
+    assert o6[0] is None and o6[5] is o6[1] and o6[6] is o6[2]
     if lambd < 1.0:
         o5 = L.subscore_bernoulli(net, t, noise, {}, keep, forget, lambd, u=u)
         torch.testing.assert_close(o5[1], _t(z["bern_loss_x"]), rtol=1e-6, atol=0)
@@ -85,21 +92,29 @@ def test_step_matches_reference(path):
     z = np.load(path)
     ac, L = _loss_obj()
     ga = int(z["ga"])
-    loss_fn = "double_forward_with_neg_del" if "no_is" in path else "importance_sampling_with_mixture"
+    from oracle.make_golden import STEP_ETA, seeded_rand_like, step_loss_params
+    loss_fn = {"no_is_step": "double_forward_with_neg_del", "erasediff_step": "erasediff", "neg_grad_step": "simple_neg_del",
+               "naive_step": "naive_del", "bernoulli_step": "subscore_bernoulli"}.get(
+        os.path.basename(path)[:-4], "importance_sampling_with_mixture")
     net = ToyEps(3, seed=int(z["net_seed"]))
     opt = torch.optim.AdamW(net.parameters(), lr=float(z["lr"]), betas=(0.95, 0.999),
                             weight_decay=1e-6, eps=1e-8)
     for step in range(2):
         mbs = [{k: _t(z[f"s{step}_m{m}_{k}"]) for k in ("x0", "a0", "noise", "t", "u")}
                for m in range(ga)]
-        lp = {"lambd": float(z["lambd"])} if "mixture" in loss_fn else {}
-        st, gx, ga_, g = unlearning_step(net, opt, L, loss_fn, ac, mbs, train_batch_size=4,
-                                         scaling_norm=float(z["scaling_norm"]), loss_params=lp)
+        lp = step_loss_params(loss_fn)
+        with seeded_rand_like(977 + step):           # ErasEDiff's uniform targets: the sequence the fixture was made with
+            st, gx, ga_, g = unlearning_step(net, opt, L, loss_fn, ac, mbs, train_batch_size=4,
+                                             scaling_norm=float(z["scaling_norm"]), loss_params=lp,
+                                             eta=STEP_ETA if loss_fn == "erasediff" else None)
         ref = z[f"s{step}_stats"]
         got = np.array([st.norm_loss_x, st.norm_loss_a, st.scaling_factor, st.pre_clip_norm,
                         st.weighted_loss_x, st.weighted_loss_a])
-        np.testing.assert_allclose(got, ref, rtol=2e-5)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, equal_nan=True)      # single-loss objectives have no g_x / g_a norms
         for n, p in net.named_parameters():
             torch.testing.assert_close(g[n], _t(z[f"s{step}_g/{n}"]), rtol=1e-4, atol=1e-7)
-            torch.testing.assert_close(gx[n], _t(z[f"s{step}_gx/{n}"]), rtol=1e-4, atol=1e-7)
+            if gx is not None:
+                torch.testing.assert_close(gx[n], _t(z[f"s{step}_gx/{n}"]), rtol=1e-4, atol=1e-7)
+            else:
+                assert f"s{step}_gx/{n}" not in z.files
             torch.testing.assert_close(p.detach(), _t(z[f"s{step}_param/{n}"]), rtol=1e-5, atol=1e-7)
