@@ -280,8 +280,14 @@ def main():
     if not a.no_kernel_timing and rank == 0:
         ksym = {}
         hbm = {}
-        for name, s, e, work, _, sym, nbytes in prof:
+        dom_split = {}
+        for name, s, e, work, shape, sym, nbytes in prof:
             dt_ms = s.elapsed_time(e)
+            if sym == "gemm_nt_c3p_kernel":      # the same kernel on the large grids it was built for vs the mid-size layers
+                sh = dict(zip(shape[::2], shape[1::2]))
+                big = -(-sh["M"] // 128) * -(-sh["N"] // 128) >= 2048
+                b = dom_split.setdefault("grids >= 2048 tiles" if big else "grids < 2048 tiles", [0, 0.0, 0.0])
+                b[0] += 1; b[1] += dt_ms; b[2] += work
             if nbytes:
                 h = hbm.setdefault(name, [0, 0.0, 0.0])
                 h[0] += 1; h[1] += dt_ms; h[2] += nbytes
@@ -304,6 +310,9 @@ def main():
                                   "separate rocprofv3 --pmc passes of the same command (tools/pmc_traffic.sh)",
                 "launches_per_step": n // ksteps, "avg_launch_us": round(tms / n * 1e3, 2),
                 "tflop_per_launch": round(work / n / 1e12, 4),
+                **({"by_grid": {k: {"achieved": round(v[2] / (v[1] * 1e-3) / 1e12, 2), "launches_per_step": v[0] // ksteps,
+                                    "avg_launch_us": round(v[1] / v[0] * 1e3, 2)} for k, v in sorted(dom_split.items())}}
+                   if dom == "gemm_nt_c3p_kernel" and dom_split else {}),
                 "share_of_step_kernel_time": round(tms / tot_ms, 3),
                 # the HBM-bound launchers of the step (K1, K5, K10-12), each against the HBM peak:
                 # ALGORITHMIC bytes (operands read once, results written once; lib.hbm_bytes) / summed launch time

@@ -193,7 +193,8 @@ def kernel_symbol(name, a):
     if name == "siss_gemm_nt":
         M, N, Kp, npan, batch, rpi = a[10], a[11], a[12], a[13], a[20], a[16]
         tiles = -(-M // 128) * -(-N // 128)
-        if (npan == 9 and batch == 1 and Kp % 64 == 0 and N % 128 == 0 and rpi >= 256 and tiles >= 2048
+        if (npan == 9 and batch == 1 and Kp % 64 == 0 and N % 128 == 0 and rpi >= 256
+                and tiles >= int(os.environ.get("SISS_NT_C3_MIN_TILES", "256"))
                 and triples(a[14], a[15], 9)):
             return "gemm_nt_c3p_kernel"
         return "gemm_nt_kernel"
