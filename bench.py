@@ -365,7 +365,8 @@ def main():
             "config": {"workload": workload,
                        "loss_fn": a.loss_fn, "global_batch": B * GA * world, "grad_accum": GA, "parallelism": f"dp{world}",
                        "hipgraph": bool(use_graph),
-                       **({"dp_exchange": "overlapped all-reduce" if st.overlap else "serial " + st.exchange,
+                       **({"dp_exchange": ("overlapped all-reduce, persistent 3x3 kernel on %d CUs" % getattr(st, "c3p_blocks", 256))
+                           if st.overlap else "serial " + st.exchange,
                            "dp_autotune": getattr(st, "overlap_timings", None),
                            "dp_allreduce": exchange} if world > 1 else {})},
             "step_tflop_algorithmic": step_tflop,

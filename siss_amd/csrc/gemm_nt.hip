@@ -304,6 +304,12 @@ int siss_launch_gemm_nt_conv3(const void* params, void* stream);   // gemm_nt_co
 int siss_launch_gemm_nt_c3(const void* params, void* stream);      // gemm_nt_c3.hip
 int siss_launch_gemm_nt_c3p(const void* params, void* stream);     // gemm_nt_c3p.hip
 
+static int g_c3p_blocks = 0;
+int nt_c3p_blocks() {
+    if (g_c3p_blocks == 0) { const char* e = getenv("SISS_NT_C3P_BLOCKS"); const int n = e ? atoi(e) : 256; g_c3p_blocks = (n >= 8 && n <= 256 && n % 8 == 0) ? n : 256; }
+    return g_c3p_blocks;
+}
+
 extern "C" {
 
 // Optional device workspace for the split-K path of siss_gemm_nt (small grids).  The library never allocates:
@@ -313,6 +319,18 @@ int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
     SISS_CHECK_ARG((ptr && bytes > 0 && (uintptr_t)ptr % 16 == 0) || (!ptr && bytes == 0));
     g_slab = (float*)ptr; g_slab_bytes = bytes;
     return SISS_OK;
+}
+
+/* Number of CUs the persistent 3x3 kernel (gemm_nt_c3p) occupies: a multiple of 8 in [8, 256]; 0 restores the default
+   (256, or $SISS_NT_C3P_BLOCKS).  That kernel takes all 160 KiB of LDS of every CU it runs on for its whole duration,
+   so a data-parallel run that overlaps RCCL's all-reduce with the backward may leave a few CUs to the collective
+   (SISSStepper.autotune_overlap measures whether that pays on the node).  Returns the value now in effect, -1 for a
+   value out of range.  Takes no stream: it only changes how LATER launches are shaped. */
+int siss_gemm_nt_set_c3p_blocks(int n) {
+    if (n == 0) { const char* e = getenv("SISS_NT_C3P_BLOCKS"); n = e ? atoi(e) : 256; }
+    if (n < 8 || n > 256 || n % 8) return -1;
+    g_c3p_blocks = n;
+    return n;
 }
 
 }  // extern "C"

@@ -323,6 +323,6 @@ int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
             return SISS_ERR_LAUNCH;
         attr_set = true;
     }
-    gemm_nt_c3p_kernel<<<dim3(256), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
+    gemm_nt_c3p_kernel<<<dim3(nt_c3p_blocks()), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }

@@ -130,3 +130,6 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
 }
 
 }  // namespace
+
+// persistent grid of gemm_nt_c3p (one block per CU, a multiple of 8): gemm_nt.hip owns the setting (siss_gemm_nt_set_c3p_blocks)
+int nt_c3p_blocks();

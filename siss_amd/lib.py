@@ -31,6 +31,7 @@ SIGNATURES = {
     "siss_conv_weight_dgrad_multi": [P, P, P, I, I, P],
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_nt_set_workspace": [P, L],
+    "siss_gemm_nt_set_c3p_blocks": [I],
     "siss_gemm_nt_mulsub": [P, L, P, P, L, P, L, P, I, I, I, F, I, L, L, L, P],
     "siss_rowdot": [P, P, P, L, L, I, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],

@@ -86,7 +86,10 @@ class SISSStepper:
         dist = torch.distributed
         from .dp import direct_exchange_flat_grads
         results, errors = {}, {}
-        candidates = {"overlap": (True, "allreduce"), "serial": (False, "allreduce"), "serial_direct": (False, "direct")}
+        # overlap_cu248: the overlapped exchange with the persistent 3x3 kernel on 248 of the 256 CUs -- it holds all
+        # the LDS of every CU it runs on for its whole duration, so RCCL's workgroups otherwise wait for kernel gaps
+        candidates = {"overlap": (True, "allreduce", 256), "overlap_cu248": (True, "allreduce", 248),
+                      "serial": (False, "allreduce", 256), "serial_direct": (False, "direct", 256)}
         try:                                                     # a backend without all-to-all keeps the all-reduce
             probe = torch.ones(2, 8 * self.world, device=self.e.device)
             direct_exchange_flat_grads(probe, self.pg)
@@ -95,8 +98,9 @@ class SISSStepper:
         except (RuntimeError, AssertionError, NotImplementedError) as exc:
             errors["serial_direct"] = (str(exc) or type(exc).__name__)[:200]
             del candidates["serial_direct"]
-        for name, (mode, exch) in candidates.items():
+        for name, (mode, exch, cus) in candidates.items():
             self.set_overlap(mode, exch)
+            lib.query("siss_gemm_nt_set_c3p_blocks", cus)
             step_fn()                                            # settle (scratch buffers, communicator channels)
             dist.barrier(group=self.pg); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -107,7 +111,8 @@ class SISSStepper:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
             results[name] = float(tt.item()) / iters
         best = min(results, key=results.get)
-        self.set_overlap(best == "overlap", "direct" if best == "serial_direct" else "allreduce")
+        self.set_overlap(best.startswith("overlap"), "direct" if best == "serial_direct" else "allreduce")
+        self.c3p_blocks = lib.query("siss_gemm_nt_set_c3p_blocks", candidates[best][2])
         self.overlap_timings = {k + "_ms": v * 1e3 for k, v in results.items()}
         if errors:
             self.overlap_timings["errors"] = errors

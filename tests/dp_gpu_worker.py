@@ -80,7 +80,9 @@ def main():
     keys = set(st3.overlap_timings)
     # the direct exchange (all-to-all reduce-scatter + all-gather) is timed too when the backend has an all-to-all for
     # device tensors; otherwise the probe's error is recorded and the all-reduce kept
-    assert len(set(flags)) == 1 and {"overlap_ms", "serial_ms"} <= keys <= {"overlap_ms", "serial_ms", "serial_direct_ms", "errors"}
+    assert len(set(flags)) == 1 and {"overlap_ms", "overlap_cu248_ms", "serial_ms"} <= keys <= {
+        "overlap_ms", "overlap_cu248_ms", "serial_ms", "serial_direct_ms", "errors"}
+    assert st3.c3p_blocks in (248, 256)
     assert ("serial_direct_ms" in keys) != ("errors" in keys), st3.overlap_timings
     if "serial_direct_ms" in keys:
         # ... and gives the all-reduce's update
