@@ -74,3 +74,27 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- host-side launcher state, PER DEVICE (a process may drive several GPUs; nothing here is shared between them) ----
+constexpr int kMaxDevices = 64;
+static inline int siss_current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices ? dev : -1;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device).
+// `done` is the caller's own per-kernel flag array (one byte per device; racing threads at worst set it twice).
+static inline int siss_ensure_smem(const void* kernel, int bytes, unsigned char (&done)[kMaxDevices]) {
+    const int dev = siss_current_device();
+    if (dev < 0) return SISS_ERR_LAUNCH;
+    if (!__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return SISS_ERR_LAUNCH;
+        __atomic_store_n(&done[dev], (unsigned char)1, __ATOMIC_RELEASE);
+    }
+    return SISS_OK;
+}
+
+// ---- dispatch counters (diagnostics): which DEVICE KERNEL a launcher call landed on.  Tests read them through
+//      siss_dispatch_count() to prove that a parity case really exercised e.g. gemm_nt_c3p_kernel. ----
+enum SissKernelId { SISS_K_NT = 0, SISS_K_NT_C3P, SISS_K_NT_C3, SISS_K_NT_CONV3, SISS_K_NT_SPLITK, SISS_K_TN1, SISS_K_TN3,
+                    SISS_K_GN_FUSED_STATS, SISS_K_COUNT };
+void siss_count_dispatch(int kernel_id);   // gemm_nt.hip

@@ -273,30 +273,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_reduce_kernel(const NTParams 
 template <int BM, int NW, int STAGES>
 int launch_nt(const NTParams& p, int batch, hipStream_t st) {
     using C_ = Cfg<BM, NW, STAGES>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, NW, STAGES>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, C_::kSmemBytes) != hipSuccess)
-            return SISS_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned char attr_set[kMaxDevices];
+    if (siss_ensure_smem((const void*)gemm_nt_kernel<BM, NW, STAGES>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    siss_count_dispatch(p.ksplit > 1 ? SISS_K_NT_SPLITK : SISS_K_NT);
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.ksplit > 1 ? p.ksplit : 1, batch);
     gemm_nt_kernel<BM, NW, STAGES><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
     if (p.ksplit > 1) {
-        static bool attr2 = false;
-        if (!attr2) {
-            if (hipFuncSetAttribute((const void*)gemm_nt_reduce_kernel<BM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    BM * kCRow) != hipSuccess)
-                return SISS_ERR_LAUNCH;
-            attr2 = true;
-        }
+        static unsigned char attr2[kMaxDevices];
+        if (siss_ensure_smem((const void*)gemm_nt_reduce_kernel<BM, NW>, BM * kCRow, attr2) != SISS_OK) return SISS_ERR_LAUNCH;
         gemm_nt_reduce_kernel<BM, NW><<<grid.x, C_::kThreads, BM * kCRow, st>>>(p);
     }
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
 
-float* g_slab = nullptr;       // split-K workspace handed over by the host (siss_gemm_nt_set_workspace)
-long g_slab_bytes = 0;
+// split-K workspace handed over by the host (siss_gemm_nt_set_workspace), one per device
+float* g_slab_dev[kMaxDevices];
+long g_slab_bytes_dev[kMaxDevices];
 
 }  // namespace
 
@@ -304,20 +296,40 @@ int siss_launch_gemm_nt_conv3(const void* params, void* stream);   // gemm_nt_co
 int siss_launch_gemm_nt_c3(const void* params, void* stream);      // gemm_nt_c3.hip
 int siss_launch_gemm_nt_c3p(const void* params, void* stream);     // gemm_nt_c3p.hip
 
-static int g_c3p_blocks = 0;
+static int g_c3p_blocks[kMaxDevices];      // per device; 0 = not set yet
 int nt_c3p_blocks() {
-    if (g_c3p_blocks == 0) { const char* e = getenv("SISS_NT_C3P_BLOCKS"); const int n = e ? atoi(e) : 256; g_c3p_blocks = (n >= 8 && n <= 256 && n % 8 == 0) ? n : 256; }
-    return g_c3p_blocks;
+    const int dev = siss_current_device();
+    if (dev < 0) return 256;
+    if (g_c3p_blocks[dev] == 0) { const char* e = getenv("SISS_NT_C3P_BLOCKS"); const int n = e ? atoi(e) : 256; g_c3p_blocks[dev] = (n >= 8 && n <= 256 && n % 8 == 0) ? n : 256; }
+    return g_c3p_blocks[dev];
 }
+
+static long g_dispatch[SISS_K_COUNT];
+void siss_count_dispatch(int k) { if (k >= 0 && k < SISS_K_COUNT) __atomic_fetch_add(&g_dispatch[k], 1L, __ATOMIC_RELAXED); }
 
 extern "C" {
 
 // Optional device workspace for the split-K path of siss_gemm_nt (small grids).  The library never allocates:
 // without a workspace (or with one that is too small for a launch) that path is simply not taken.  The buffer
 // is used by launches on ONE stream at a time (the partial tiles live from the product kernel to its reduce kernel).
+// The workspace belongs to the CURRENT device (hipGetDevice) -- a second device in the process gets its own.
 int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
     SISS_CHECK_ARG((ptr && bytes > 0 && (uintptr_t)ptr % 16 == 0) || (!ptr && bytes == 0));
-    g_slab = (float*)ptr; g_slab_bytes = bytes;
+    const int dev = siss_current_device();
+    if (dev < 0) return SISS_ERR_LAUNCH;
+    g_slab_dev[dev] = (float*)ptr; g_slab_bytes_dev[dev] = bytes;
+    return SISS_OK;
+}
+
+// Diagnostics: number of launches dispatched to device kernel `kernel_id` since the last reset (process-wide):
+// 0 gemm_nt_kernel, 1 gemm_nt_c3p_kernel, 2 gemm_nt_c3_kernel, 3 gemm_nt_conv3_kernel, 4 gemm_nt_kernel split-K (+ reduce),
+// 5 gemm_tn_kernel<1>, 6 gemm_tn_kernel<3>, 7 gemm_nt_c3p_kernel launches that also emitted GroupNorm statistics.
+// -1 for an unknown id.  siss_dispatch_reset() zeroes them all.  (Tests use these to prove which kernel a case ran on.)
+long siss_dispatch_count(int kernel_id) {
+    return kernel_id >= 0 && kernel_id < SISS_K_COUNT ? __atomic_load_n(&g_dispatch[kernel_id], __ATOMIC_RELAXED) : -1;
+}
+int siss_dispatch_reset() {
+    for (int k = 0; k < SISS_K_COUNT; ++k) __atomic_store_n(&g_dispatch[k], 0L, __ATOMIC_RELAXED);
     return SISS_OK;
 }
 
@@ -329,7 +341,9 @@ int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
 int siss_gemm_nt_set_c3p_blocks(int n) {
     if (n == 0) { const char* e = getenv("SISS_NT_C3P_BLOCKS"); n = e ? atoi(e) : 256; }
     if (n < 8 || n > 256 || n % 8) return -1;
-    g_c3p_blocks = n;
+    const int dev = siss_current_device();
+    if (dev < 0) return -1;
+    g_c3p_blocks[dev] = n;
     return n;
 }
 
@@ -358,6 +372,9 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.ksplit = 1; p.slab = nullptr;
     p.rowsub = rowsub; p.mul_r = mul_r;
     SISS_CHECK_ARG(!mul_r || (R && Hp == 0));              // the multiplicative epilogue has no halo form
+    const int dev_ = siss_current_device();
+    float* const g_slab = dev_ >= 0 ? g_slab_dev[dev_] : nullptr;
+    const long g_slab_bytes = dev_ >= 0 ? g_slab_bytes_dev[dev_] : 0;
     { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     SISS_CHECK_ARG((!rowbias && Hp == 0) || rows_per_image >= 64);   // <= 3 images per 128/256-row tile
     SISS_CHECK_ARG(N % 8 == 0 && (!rowbias || ldrb % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0));

@@ -163,12 +163,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_nt_c3_kernel(const NTParams
 // batch == 1 and rows_per_image >= 256 (a 256-row tile then spans at most two images).
 int siss_launch_gemm_nt_c3(const void* params, void* stream) {
     const NTParams& p = *reinterpret_cast<const NTParams*>(params);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_c3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
-            return SISS_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned char attr_set[kMaxDevices];
+    if (siss_ensure_smem((const void*)gemm_nt_c3_kernel, G_SMEM, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    siss_count_dispatch(SISS_K_NT_C3);
     dim3 grid(cdiv(p.M, G_VALID) * cdiv(p.N, BN));
     gemm_nt_c3_kernel<<<grid, G_THREADS, G_SMEM, (hipStream_t)stream>>>(p);
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;

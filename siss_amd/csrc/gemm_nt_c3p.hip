@@ -317,12 +317,9 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
 // N % 128 == 0, batch == 1, rows_per_image >= 256.
 int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     const NTParams& p = *reinterpret_cast<const NTParams*>(params);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_c3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_SMEM) != hipSuccess)
-            return SISS_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned char attr_set[kMaxDevices];
+    if (siss_ensure_smem((const void*)gemm_nt_c3p_kernel, P_SMEM, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    siss_count_dispatch(SISS_K_NT_C3P);
     // Grid = the FEWEST blocks (a multiple of 8: XCD runs) that finish in the same number of tile rounds as the full
     // chip: 550 tiles are 3 rounds on 256 CUs (38 CUs with three tiles, 218 with two) and exactly 3 on 184 -- the idle
     // CUs' power goes to the busy ones (measured: the mid-size grids run 4 % faster on 208 CUs than on 256).

@@ -130,12 +130,9 @@ __global__ __launch_bounds__(F_THREADS, 4) void gemm_nt_conv3_kernel(const NTPar
 // Called by siss_gemm_nt() when the panel list is a 3x3 filter (three row-consecutive triples).
 int siss_launch_gemm_nt_conv3(const void* params, void* stream) {
     const NTParams& p = *reinterpret_cast<const NTParams*>(params);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_conv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM) != hipSuccess)
-            return SISS_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned char attr_set[kMaxDevices];
+    if (siss_ensure_smem((const void*)gemm_nt_conv3_kernel, F_SMEM, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    siss_count_dispatch(SISS_K_NT_CONV3);
     dim3 grid(cdiv(p.M, F_BM) * cdiv(p.N, BN));
     gemm_nt_conv3_kernel<<<grid, F_THREADS, F_SMEM, (hipStream_t)stream>>>(p);
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;

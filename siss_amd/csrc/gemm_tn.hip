@@ -338,13 +338,9 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
 template <int TAPS>
 int launch_tn(const TNParams& p, hipStream_t st) {
     using C_ = TCfg<TAPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_tn_kernel<TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C_::kSmemBytes) != hipSuccess)
-            return SISS_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static unsigned char attr_set[kMaxDevices];
+    if (siss_ensure_smem((const void*)gemm_tn_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
     dim3 grid(cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits);
     gemm_tn_kernel<TAPS><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;

@@ -32,6 +32,8 @@ SIGNATURES = {
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_nt_set_workspace": [P, L],
     "siss_gemm_nt_set_c3p_blocks": [I],
+    "siss_dispatch_count": [I],
+    "siss_dispatch_reset": [],
     "siss_gemm_nt_mulsub": [P, L, P, P, L, P, L, P, I, I, I, F, I, L, L, L, P],
     "siss_rowdot": [P, P, P, L, L, I, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
@@ -78,7 +80,20 @@ SIGNATURES = {
     "siss_linear_small_bwd": [P, P, P, P, P, I, P, P, P, I, I, I, L, L, I, I, I, P],
 }
 _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words",
-             "siss_gn_partial_words"}
+             "siss_gn_partial_words", "siss_dispatch_count"}
+
+# siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
+KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "gemm_nt_c3_kernel": 2, "gemm_nt_conv3_kernel": 3,
+              "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gemm_nt_c3p_kernel/gn_stats": 7}
+
+
+def dispatch_counts(reset=False):
+    """{kernel symbol: launches since the last reset} from the library's own dispatch counters."""
+    lib = load()
+    out = {k: int(lib.siss_dispatch_count(i)) for k, i in KERNEL_IDS.items()}
+    if reset:
+        lib.siss_dispatch_reset()
+    return out
 
 _lib = None
 
@@ -106,17 +121,19 @@ WORKSPACE_BYTES = 32 << 20      # 512 partial tiles of 128 x 128 f32: the most t
 
 
 def ensure_workspace(device):
-    """Hand the library its split-K scratch (one buffer per process, kept alive here; the C side never allocates).
-    Launches on one stream at a time use it -- the one-process-per-GPU, one-compute-stream schedule of this package."""
+    """Hand the library its split-K scratch for `device` (one buffer per device, kept alive here; the C side never
+    allocates and keeps one pointer PER DEVICE).  Launches on one stream at a time use it -- the one-compute-stream
+    schedule of this package."""
     device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, index)
     if key not in _WORKSPACE:
-        buf = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
-        _WORKSPACE.clear()                      # the library holds ONE pointer: the newest device wins
-        _WORKSPACE[key] = buf
-        rc = load().siss_gemm_nt_set_workspace(C.c_void_p(buf.data_ptr()), WORKSPACE_BYTES)
+        with torch.cuda.device(index):           # the library files the pointer under hipGetDevice()
+            buf = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=torch.device("cuda", index))
+            rc = load().siss_gemm_nt_set_workspace(C.c_void_p(buf.data_ptr()), WORKSPACE_BYTES)
         if rc != 0:
             raise RuntimeError(f"siss_gemm_nt_set_workspace failed with status {rc}")
+        _WORKSPACE[key] = buf
     return _WORKSPACE[key]
 
 

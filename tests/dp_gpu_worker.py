@@ -54,11 +54,15 @@ def main():
         for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm"):
             assert abs(dp_stats[k] - rs[k]) <= 2e-2 * abs(rs[k]), (k, dp_stats[k], rs[k])
         upd_ref = eng.ps.flat.clone()
+        # update-direction cosine >= 0.99 over the elements with a significant gradient
+        # (|g| > 1e-6 |g|_inf; AdamW's first step is sign-like, numerically-zero gradients move at random)
+        g_fin = eng.ps.grads[0] - rs["scaling_factor"] * eng.ps.grads[1]
+        mask = g_fin.abs() > 1e-6 * g_fin.abs().max()
         eng.load_state_dict(sd)
         base = eng.ps.flat.clone()
-        du_ref, du_dp = upd_ref - base, dp_params - base
+        du_ref, du_dp = (upd_ref - base)[mask].double(), (dp_params - base)[mask].double()
         cos = float((du_ref * du_dp).sum() / (du_ref.norm() * du_dp.norm()))
-        assert cos > 0.98, cos
+        assert float(mask.float().mean()) > 0.5 and cos >= 0.99, (cos, float(mask.float().mean()))
     # serial exchange (one all-reduce after the backward) gives the same update as the overlapped one ...
     eng.load_state_dict(sd)
     st2 = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, **kw)

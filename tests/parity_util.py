@@ -1,0 +1,41 @@
+"""Shared parity metrics for the GPU tests (SURVEY.md §8c tolerances, stated once).
+
+  * step scalars (||g_x||, ||g_a||, s, pre-clip ||g||): rel 5e-2, bf16 compute vs the fp32 oracle;
+  * parameter update: cosine >= 0.99 between the two updates over the elements with a significant gradient,
+    |g| > 1e-6 * ||g||_inf.  AdamW's first steps are sign-like (dtheta ~ -lr g / (|g| + eps)), so an element whose
+    gradient is numerically zero moves by +-lr at random on either side; those -- and only those -- are masked out.
+"""
+import torch
+
+SCALAR_RTOL = 5e-2
+UPDATE_COS = 0.99
+MASK_REL = 1e-6
+
+
+def check_scalars(ref, got, keys=("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm"), tol=SCALAR_RTOL):
+    for k in keys:
+        r = getattr(ref, k) if not isinstance(ref, dict) else ref[k]
+        v = got[k] if isinstance(got, dict) else getattr(got, k)
+        assert abs(v - r) <= tol * abs(r), (k, v, r)
+
+
+def masked_update_cosine(before, after_ref, after_got, grads_ref):
+    """before / after_*: {name: tensor} in reference layout; grads_ref: the oracle's final (recombined, clipped)
+    gradient of that step.  Returns (cosine over the masked elements, fraction of elements kept)."""
+    ginf = max(float(g.abs().max()) for g in grads_ref.values())
+    num = nr = ng = 0.0
+    kept = total = 0
+    for n, g in grads_ref.items():
+        m = g.abs().flatten() > MASK_REL * ginf
+        dr = (after_ref[n].detach().double() - before[n].double()).flatten()[m]
+        dg = (after_got[n].detach().double().cpu() - before[n].double()).flatten()[m]
+        num += float((dr * dg).sum()); nr += float(dr.square().sum()); ng += float(dg.square().sum())
+        kept += int(m.sum()); total += m.numel()
+    return num / ((nr * ng) ** 0.5 + 1e-300), kept / max(total, 1)
+
+
+def assert_update_direction(before, after_ref, after_got, grads_ref, what=""):
+    cos, frac = masked_update_cosine(before, after_ref, after_got, grads_ref)
+    assert frac > 0.5, (what, "mask kept only", frac)
+    assert cos >= UPDATE_COS, (what, "masked update cosine", cos, "kept", frac)
+    return cos

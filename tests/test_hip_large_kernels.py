@@ -1,0 +1,211 @@
+"""Element-wise parity of the kernels that CARRY the step, at shapes that really dispatch to them.
+
+The small cases of test_hip_kernels.py all land on the generic `gemm_nt_kernel` / `gemm_tn_kernel<1>`.  The CelebA-HQ step
+spends 31 % of its time in `gemm_nt_c3p_kernel` (persistent 3x3 kernel: grids of >= 256 128-row tiles, >= 256 padded rows
+per image, N % 128 == 0) and 22 % in `gemm_tn_kernel<3>` (fused three-tap wgrad, >= 8192 reduction rows).  Every case
+below is sized to be eligible for them, and the library's own dispatch counters (siss_dispatch_count) are asserted, so a
+change of the dispatch thresholds cannot silently turn these back into small-kernel tests.
+
+What the shapes stress (gemm_nt_c3p.hip): 254-row tiles whose seams fall anywhere in an image row; tiles that span TWO
+images (per-image row bias select + halo mask of both, `park(two_images)` / `store_tile`); several tile rounds per
+block with an uneven last round (balanced persistent grid); a narrowed grid (siss_gemm_nt_set_c3p_blocks) as the
+data-parallel autotune uses it.
+
+Reference = torch fp32 conv2d on the CPU over the SAME bf16-rounded operands (reference provider: the cuDNN convs behind
+diffusers' ResnetBlock2D, reached from losses/ddpm_deletion_loss.py:24 and differentiated at delete_celeb.py:691,:702).
+Tolerances: bf16 outputs rel 1e-2 of the tensor's scale (a wrong / dropped / mis-masked row is an O(0.2) error);
+f32 wgrad rel 2e-3 of scale (a dropped 254-row tile of a 65 k-row reduction is > 1e-2).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    from siss_amd import lib
+    lib.load()
+    lib.ensure_workspace("cuda:0")
+    return torch.device("cuda:0")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _close(got, ref, rel, what=""):
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g} (rel {err / scale:.3g} > {rel})"
+
+
+# (n, h, w, cin, cout, nsets, c3p_blocks): padded rows M = n (h+2)(w+2); 254-row c3p tiles = ceil(M / 254) * cout / 128
+CASES = [
+    (2, 128, 128, 128, 128, 1, 0),      # 134 c3p tiles in one round; tile 66/67 crosses the image boundary
+    (1, 256, 256, 256, 128, 2, 0),      # 263 tiles: two rounds on a balanced 136-block grid; residual + row bias; K = 256
+    (4, 64, 64, 256, 256, 1, 0),        # 69 x 2 tiles (two column tiles share an A tile), three image seams
+    (5, 160, 160, 128, 128, 1, 0),      # 517 tiles: three rounds, uneven last round, 5 images with row bias
+    (2, 128, 128, 128, 128, 1, 248),    # the same product on a grid held to 248 CUs (data-parallel overlap knob)
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,nsets,blocks", CASES)
+def test_conv3x3_on_the_persistent_and_fused_wgrad_kernels(dev, n, h, w, ci, co, nsets, blocks):
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act
+    g = torch.Generator().manual_seed(n * 1000 + h + ci + blocks)
+    x = _bf(torch.randn(n, ci, h, w, generator=g))
+    wt = _bf(torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3 * ci ** 0.5)))
+    bias = torch.randn(co, generator=g)
+    temb = torch.randn(n, co, generator=g)                 # per-image row bias: DIFFERENT per image on purpose
+    res = _bf(torch.randn(n, co, h, w, generator=g))
+    dy = _bf(torch.randn(nsets * n, co, h, w, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wt, bias, padding=1) + temb[:, :, None, None] + res
+    # dgrad runs at batch nsets * n (the dual-cotangent backward), wgrad per set against the SAME saved activation
+    dx_ref = torch.cat([torch.autograd.grad(F.conv2d(xr, wt, padding=1), xr, dy[s * n:(s + 1) * n])[0] for s in range(nsets)])
+    dw_ref = []
+    for s in range(nsets):
+        wr = wt.clone().requires_grad_(True)
+        dw_ref.append(torch.autograd.grad(F.conv2d(x, wr, padding=1), wr, dy[s * n:(s + 1) * n])[0])
+
+    assert lib.query("siss_gemm_nt_set_c3p_blocks", blocks) == (blocks or 256)
+    try:
+        lib.dispatch_counts(reset=True)
+        xa, ra = Act.from_nchw(x, dev), Act.from_nchw(res, dev)
+        wn = ops.conv_w_to_native(wt).to(dev)
+        out = Act(n, h, w, co, dev)
+        out.buf.fill_(7.0)                                  # poison: the kernel must write the zero halo itself
+        out.buf[: out.guard * co] = 0
+        out.buf[-out.guard * co:] = 0
+        ops.conv_fprop(xa, wn.to(torch.bfloat16), out, bias=bias.to(dev), rowbias=temb.to(dev), residual=ra)
+        torch.cuda.synchronize()
+        cnt = lib.dispatch_counts(reset=True)
+        assert cnt["gemm_nt_c3p_kernel"] == 1 and cnt["gemm_nt_kernel"] == 0, cnt
+        assert out.halo_is_zero()
+        _close(out.to_nchw().cpu(), y_ref.detach(), 1e-2, "fprop")
+
+        dya = Act.from_nchw(dy, dev)
+        dx = Act(nsets * n, h, w, ci, dev)
+        dx.buf.fill_(-3.0)
+        dx.buf[: dx.guard * ci] = 0
+        dx.buf[-dx.guard * ci:] = 0
+        ops.conv_dgrad(dya, ops.dgrad_weight(wn), dx)
+        torch.cuda.synchronize()
+        cnt = lib.dispatch_counts(reset=True)
+        assert cnt["gemm_nt_c3p_kernel"] == 1 and cnt["gemm_nt_kernel"] == 0, cnt
+        assert dx.halo_is_zero()
+        _close(dx.to_nchw().cpu(), dx_ref, 1e-2, "dgrad")
+    finally:
+        lib.query("siss_gemm_nt_set_c3p_blocks", 0)
+
+    dW = torch.zeros(nsets, 9, co, ci, device=dev)
+    dB = torch.zeros(nsets, co, device=dev)
+    lib.dispatch_counts(reset=True)
+    ops.conv_wgrad(dya, xa, dW, nsets=nsets, dbias=dB) if nsets == 1 else _wgrad_sets(ops, lib, dya, xa, dW, dB, nsets)
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    assert cnt["gemm_tn_kernel<3>"] == 1 and cnt["gemm_tn_kernel<1>"] == 0, cnt
+    for s in range(nsets):
+        _close(ops.conv_w_from_native(dW[s]).cpu(), dw_ref[s], 2e-3, f"wgrad set {s}")
+        _close(dB[s].cpu(), dy[s * n:(s + 1) * n].sum(dim=(0, 2, 3)), 2e-3, f"bias grad set {s}")
+
+
+def _wgrad_sets(ops, lib, dya, xa, dW, dB, nsets):
+    """conv_wgrad with a bias-gradient buffer per set (set stride = co floats)."""
+    from siss_amd.layout import conv3x3_panels
+    co, ci = dya.c, xa.c
+    b = dya.n // nsets
+    shifts, coffs = conv3x3_panels(dya.wp, ci)
+    rows_per_set = b * dya.rows_per_image
+    # dbias[set * set_stride + n] uses dW's set stride (9*co*ci floats), so give it a buffer laid out that way
+    big = torch.zeros(nsets, 9 * co * ci, device=dW.device)
+    lib.call("siss_gemm_tn", dya.data, dya.c, xa.data, xa.c, dW, 9 * co * ci, co, ci, 9, lib.int_array(shifts),
+             lib.int_array(coffs), nsets, rows_per_set, 0, dya.wp + 1, rows_per_set - (dya.wp + 1), 0,
+             ops.zero_page(dW.device), big, None)
+    dB.copy_(big[:, :co])
+
+
+def test_dispatch_counters_tell_small_from_large(dev):
+    """The counters themselves: a 16x16 conv is NOT on the persistent kernel, a 128x128 one is."""
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act
+    for hw, want in ((16, "gemm_nt_kernel"), (128, "gemm_nt_c3p_kernel")):
+        x = Act(2, hw, hw, 128, dev)
+        y = Act(2, hw, hw, 128, dev)
+        wn = torch.zeros(9, 128, 128, dtype=torch.bfloat16, device=dev)
+        lib.dispatch_counts(reset=True)
+        ops.conv_fprop(x, wn, y)
+        torch.cuda.synchronize()
+        cnt = lib.dispatch_counts(reset=True)
+        assert cnt[want] + (cnt["gemm_nt_kernel/splitk"] if hw == 16 else 0) == 1, (hw, cnt)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-size network: BASELINE configs[1] (CelebA-HQ 256x256 UNet, 113.7 M parameters, 450 tensors), forward + ONE
+# dual-cotangent backward on HIP against the oracle network (oracle/unet.py, fp32, torch autograd: two backward calls
+# with retain_graph like delete_celeb.py:686-711) evaluated on the same GPU through PyTorch-ROCm's own fp32 kernels.
+# Tolerances: pred max-err <= 3e-2 * max|pred|; per-tensor gradient cosine >= 0.99 for all 450 tensors
+# of both sets; set norms within 5e-2.
+# ---------------------------------------------------------------------------------------------------------------------
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("B", [4])
+def test_full_size_forward_and_dual_backward_match_the_fp32_oracle(dev, B):
+    from siss_amd import lib
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.unet import UNetEngine
+    from oracle.unet import OracleUNet2D, UNetConfig
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    HW = 256
+    eng = UNetEngine(UNet2DConfig.celebahq256(), dev)
+    sd = eng.init_random(seed=42)
+    assert len(sd) == 450 and sum(v.numel() for v in sd.values()) == 113_673_219
+    net = OracleUNet2D(UNetConfig.celebahq256())
+    net.load_state_dict(sd)
+    net = net.to(dev).float()
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(B, 3, HW, HW, generator=g, device=dev).to(torch.bfloat16)      # bf16 I/O mode (configs[1])
+    t = torch.tensor([999, 999, 250, 3][:B] + [999] * max(0, B - 4), device=dev)
+    cx = torch.randn(B, 3, HW, HW, generator=g, device=dev) * 1e-3
+    ca = torch.randn(B, 3, HW, HW, generator=g, device=dev) * 1e-3
+
+    lib.dispatch_counts(reset=True)
+    pred = eng.forward(x, t).clone()
+    eng.zero_grad()
+    eng.backward(torch.cat([cx, ca]).contiguous(), nsets=2)
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    # the kernels under test really ran: fprop + dgrad of the >= 64x64 levels on c3p, their wgrads on <3>
+    assert cnt["gemm_nt_c3p_kernel"] >= 40 and cnt["gemm_tn_kernel<3>"] >= 40, cnt
+
+    ref = net(x.float(), t)[0]
+    err = (pred - ref.detach()).abs().max().item()
+    scale = ref.detach().abs().max().item()
+    assert err <= 3e-2 * scale, (err, scale)
+
+    names = [n for n, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    bad, worst = [], (1.0, None)
+    for s, c in enumerate((cx, ca)):
+        grads = torch.autograd.grad(ref, params, c, retain_graph=(s == 0))
+        got = {n: v.to(dev) for n, v in eng.ps.grads_ref(s).items()}
+        tot_r = torch.sqrt(sum(v.double().square().sum() for v in grads))
+        tot_g = torch.sqrt(sum(v.double().square().sum() for v in got.values()))
+        assert abs(float(tot_g / tot_r) - 1) < 5e-2, (s, float(tot_g), float(tot_r))
+        for n, r in zip(names, grads):
+            c_ = _cos(got[n], r)
+            if c_ < worst[0]:
+                worst = (c_, (s, n))
+            if c_ < 0.99:
+                bad.append((s, n, round(c_, 4), float(r.norm() / tot_r)))
+        del grads
+    print(f"\nfull-size parity: pred rel err {err / scale:.3g}; worst per-tensor gradient cosine {worst[0]:.5f} at {worst[1]}")
+    assert not bad, (len(bad), bad[:12])

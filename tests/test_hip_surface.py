@@ -58,13 +58,9 @@ def test_reference_style_loop_on_hip_surface(loss_fn):
     for k in keys:
         r, v = getattr(ref, k), getattr(got, k)
         assert abs(v - r) <= 5e-2 * abs(r), (k, v, r)
-    # updated parameters, reference layout: same direction as the oracle's update
-    new = hip.state_dict()
-    num = den = 0.0
-    for n, p in cpu.named_parameters():
-        dr, dh = (p.detach() - sd[n]).flatten(), (new[n] - sd[n]).flatten()
-        num += float((dr * dh).sum()); den += float(dr.norm() * dh.norm())
-    assert num / den > 0.9, num / den
+    # updated parameters, reference layout: same direction as the oracle's update (masked cosine >= 0.99)
+    from parity_util import assert_update_direction
+    assert_update_direction(sd, dict(cpu.named_parameters()), hip.state_dict(), g_r, loss_fn)
 
 
 def test_save_and_reload_pretrained(tmp_path):
@@ -78,9 +74,8 @@ def test_save_and_reload_pretrained(tmp_path):
     t = torch.tensor([999, 3])
     with torch.no_grad():
         a, b = m(x, t)[0], m2(x, t)[0]
-    # same weights after the safetensors round trip; the forward itself is not bitwise reproducible
-    # (GroupNorm statistics fold through LDS float atomics), so compare at bf16 resolution
-    assert (a - b).abs().max() <= 2e-2 * a.abs().max()
+    # same weights after the safetensors round trip, and the forward pass is deterministic: bitwise equal
+    assert torch.equal(a, b)
     sd1, sd2 = m.state_dict(), m2.state_dict()
     assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
 

@@ -107,7 +107,10 @@ def test_siss_step_matches_oracle(setup):
     st = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, eps=1e-8, scaling_norm=5.0,
                      lambd=0.5, train_batch_size=4, mixed_precision=None)
     g = torch.Generator().manual_seed(7)
+    from parity_util import assert_update_direction
     for step in range(2):
+        before_ref = {n: p.detach().clone() for n, p in net.named_parameters()}
+        before_got = eng.state_dict()
         x0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
         a0 = (torch.rand(1, 3, 16, 16, generator=g) * 2 - 1).repeat(4, 1, 1, 1)
         noise = torch.randn(4, 3, 16, 16, generator=g)
@@ -122,14 +125,10 @@ def test_siss_step_matches_oracle(setup):
                              ("scaling_factor", "scaling_factor"), ("pre_clip_norm", "pre_clip_norm")):
             r, v = getattr(ref, k_ref), got[k_got]
             assert abs(v - r) <= 5e-2 * abs(r), (step, k_ref, v, r)
-    # parameters moved in the same direction (AdamW step 1 is sign-like: compare on significant grads)
-    new = eng.state_dict()
-    num = den = 0.0
-    for n, p in net.named_parameters():
-        d_ref = (p.detach() - sd[n]).flatten()
-        d_got = (new[n] - sd[n]).flatten()
-        num += float((d_ref * d_got).sum()); den += float(d_ref.norm() ** 2)
-    assert num / den > 0.9, num / den
+        # this step's parameter update, per side from its own starting point: masked direction cosine
+        new = eng.state_dict()
+        d_got = {n: before_ref[n] + (new[n] - before_got[n]) for n in new}
+        assert_update_direction(before_ref, dict(net.named_parameters()), d_got, gfin, f"step {step}")
 
 
 def _fresh(setup):
@@ -192,8 +191,8 @@ def test_baseline_losses_fast_path_matches_oracle(setup, loss_fn):
     st = SISSStepper(eng, ac, lambd=0.5, train_batch_size=4, loss_fn=name, mixed_precision=None, superfactor=3.0,
                      inf_guard=True, **okw, **kw)
     torch.manual_seed(99)                                     # erasediff: rand_like is the first draw in the oracle
-    ref, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), name, ac, [mb], train_batch_size=4,
-                              scaling_norm=5.0, eta=1e-2, loss_params=lp, inf_guard=True)
+    ref, _, _, gfin = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), name, ac, [mb], train_batch_size=4,
+                                      scaling_norm=5.0, eta=1e-2, loss_params=lp, inf_guard=True)
     torch.manual_seed(99)
     target = torch.rand(mb["noise"].shape) if name == "erasediff" else None
     st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"], erase_target=target)
@@ -202,12 +201,8 @@ def test_baseline_losses_fast_path_matches_oracle(setup, loss_fn):
         assert abs(got["pre_clip_norm"] - ref.pre_clip_norm) <= 5e-2 * ref.pre_clip_norm
     else:
         _check_scalars(ref, got)
-    new = eng.state_dict()
-    num = den = 0.0
-    for n, p in net.named_parameters():
-        dr, dh = (p.detach() - sd[n]).flatten(), (new[n] - sd[n]).flatten()
-        num += float((dr * dh).sum()); den += float(dr.norm() * dh.norm()) + 1e-30
-    assert num / den > 0.9, num / den
+    from parity_util import assert_update_direction
+    assert_update_direction(sd, dict(net.named_parameters()), eng.state_dict(), gfin, name)
 
 
 def test_gradient_accumulation_two_micro_batches(setup):
@@ -251,7 +246,7 @@ def test_bf16_io_mode_and_graph_replay(setup):
     t, u = mb["t"].to(dev), mb["u"].to(dev)
     st.step(x0, a0, noise, t, u)
     eager = st.stats()
-    _check_scalars(ref, eager, tol=8e-2)     # + bf16 noising / bf16 targets on top of bf16 compute
+    _check_scalars(ref, eager)               # rel 5e-2 also with bf16 noising / bf16 targets
     # graph: same inputs, parameters restored -> identical schedule replayed from a hipGraph
     eng.load_state_dict(sd)
     st2 = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
