@@ -149,14 +149,15 @@ def test_dispatch_counters_tell_small_from_large(dev):
 # dual-cotangent backward on HIP against the oracle network (oracle/unet.py, fp32, torch autograd: two backward calls
 # with retain_graph like delete_celeb.py:686-711) evaluated on the same GPU through PyTorch-ROCm's own fp32 kernels.
 # Tolerances: pred max-err <= 3e-2 * max|pred|; per-tensor gradient cosine >= 0.99 for all 450 tensors
-# of both sets; set norms within 5e-2.
+# of both sets (the six attention key biases have an identically zero gradient: |g| < 1e-6 of the total instead);
+# set norms within 5e-2.
 # ---------------------------------------------------------------------------------------------------------------------
 def _cos(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
 
 
-@pytest.mark.parametrize("B", [4])
+@pytest.mark.parametrize("B", [4, 16])
 def test_full_size_forward_and_dual_backward_match_the_fp32_oracle(dev, B):
     from siss_amd import lib
     from siss_amd.config import UNet2DConfig
@@ -173,7 +174,7 @@ def test_full_size_forward_and_dual_backward_match_the_fp32_oracle(dev, B):
     net = net.to(dev).float()
     g = torch.Generator(device=dev).manual_seed(7)
     x = torch.randn(B, 3, HW, HW, generator=g, device=dev).to(torch.bfloat16)      # bf16 I/O mode (configs[1])
-    t = torch.tensor([999, 999, 250, 3][:B] + [999] * max(0, B - 4), device=dev)
+    t = torch.tensor(([999, 999, 250, 3] + [999] * B)[:B], device=dev)
     cx = torch.randn(B, 3, HW, HW, generator=g, device=dev) * 1e-3
     ca = torch.randn(B, 3, HW, HW, generator=g, device=dev) * 1e-3
 
@@ -184,7 +185,7 @@ def test_full_size_forward_and_dual_backward_match_the_fp32_oracle(dev, B):
     torch.cuda.synchronize()
     cnt = lib.dispatch_counts(reset=True)
     # the kernels under test really ran: fprop + dgrad of the >= 64x64 levels on c3p, their wgrads on <3>
-    assert cnt["gemm_nt_c3p_kernel"] >= 40 and cnt["gemm_tn_kernel<3>"] >= 40, cnt
+    assert cnt["gemm_nt_c3p_kernel"] >= 40 and cnt["gemm_tn_kernel<3>"] >= 30, cnt
 
     ref = net(x.float(), t)[0]
     err = (pred - ref.detach()).abs().max().item()
@@ -201,6 +202,13 @@ def test_full_size_forward_and_dual_backward_match_the_fp32_oracle(dev, B):
         tot_g = torch.sqrt(sum(v.double().square().sum() for v in got.values()))
         assert abs(float(tot_g / tot_r) - 1) < 5e-2, (s, float(tot_g), float(tot_r))
         for n, r in zip(names, grads):
+            if float(r.norm()) < 1e-8 * float(tot_r):
+                # a mathematically ZERO gradient (to_k.bias: softmax is invariant to a constant added to every key's
+                # logit): the oracle's value is f32 rounding noise, so the direction means nothing -- the HIP value
+                # must be just as negligible
+                assert n.endswith("to_k.bias"), (n, float(r.norm()))
+                assert float(got[n].norm()) < 1e-6 * float(tot_r), (n, float(got[n].norm()), float(tot_r))
+                continue
             c_ = _cos(got[n], r)
             if c_ < worst[0]:
                 worst = (c_, (s, n))
