@@ -15,6 +15,7 @@
 // the dual-cotangent backward of the SISS step.
 // Output / cotangent rows may be "compact" ([N][H*W][C], no halo) for the attention block.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -441,15 +442,44 @@ bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16) {
     return true;
 }
 
+// The workspace starts with the two-phase kernels' region (groupnorm2p.hip: counters + fixed-point accumulators for up
+// to k2pSamples samples, ZERO-filled by the caller once and left zero by every launch); the two-pass kernels' partial
+// slab follows it.
+constexpr int k2pSamples = 64;
+int g_use_2p = -1;
+int use_2p() {
+    if (g_use_2p < 0) { const char* e = getenv("SISS_GN_2P"); g_use_2p = e ? atoi(e) : 0; }
+    return g_use_2p;
+}
+
 }  // namespace
+
+long siss_gn2p_words(int n);      // groupnorm2p.hip
+int siss_gn2p_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* ws,
+                  int N, int H, int W, int C, int G, float eps, int silu, int out_compact, int ldx, void* stream);
+int siss_gn2p_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                  const float* rstd, void* dx, const void* accum, const void* accum2, void* dx2, int split_c,
+                  int accumulate2, float* dgamma, float* dbeta, float* colsum, long colsum_ld, float* ws, int n2, int nx,
+                  int set_images, long set_stride, int H, int W, int C, int G, int silu, int dy_compact, int ldx,
+                  void* stream);
 
 extern "C" {
 
-// floats needed in `partial` for n samples
+// Selects the GroupNorm kernels: bit 0 = two-phase forward, bit 1 = two-phase backward (groupnorm2p.hip: one launch, every
+// byte once); 0 = the two-pass kernels everywhere; -1 = back to the default ($SISS_GN_2P, else 0: measured on MI355X the
+// per-sample barrier chain of the two-phase form costs more than the second read it saves).
+// Returns the value in effect.
+int siss_groupnorm_set_two_phase(int mask) {
+    g_use_2p = mask < 0 ? -1 : (mask & 3);
+    return use_2p();
+}
+
+// floats needed in `partial` for n samples.  The buffer must be ZERO-filled once before its first use (every launch
+// leaves the part that needs it zero again) and 16-B aligned.
 long siss_gn_partial_words(int n, int H, int W, int C, int G) {
     GNShape s;
     if (!make_shape(H, W, C, G, s, 1)) return -1;   // N = 1 gives the largest chunk count -> upper bound
-    return (long)n * s.nslices * s.nchunks * 2 * s.G;
+    return siss_gn2p_words(k2pSamples) + (long)n * s.nslices * s.nchunks * 2 * s.G;
 }
 
 // y = act(GroupNorm(x)); x padded NHWC; y padded or compact ([N][H*W][C]).  Writes mean/rstd [N][G].
@@ -462,7 +492,13 @@ int siss_groupnorm_fwd_ld(const void* x, const float* gamma, const float* beta, 
     SISS_CHECK_ARG(make_shape(H, W, C, G, s, N));
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
     if (ldx) s.ldx = ldx;
-    SISS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    SISS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y | (uintptr_t)partial) % 16 == 0);
+    if ((use_2p() & 1) && s.nslices == 1 && N <= k2pSamples) {
+        // one launch, every byte once (groupnorm2p.hip); -1: shape not covered -> the two-pass kernels below
+        const int rc = siss_gn2p_fwd(x, gamma, beta, y, mean, rstd, partial, N, H, W, C, G, eps, silu, out_compact, ldx, stream);
+        if (rc >= 0) return rc;
+    }
+    partial += siss_gn2p_words(k2pSamples);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, N, s.nslices);
     gn_stats_kernel<<<grid, kThreads, 0, st>>>((const bf16_t*)x, s, partial);
@@ -499,7 +535,14 @@ int siss_groupnorm_bwd_ld(const void* dy, const void* x, const float* gamma, con
     SISS_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)accum | (uintptr_t)accum2 | (uintptr_t)dx2) % 16 == 0);
     SISS_CHECK_ARG(!dx2 || (split_c > 0 && split_c < C && split_c % 8 == 0));
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
+    SISS_CHECK_ARG((uintptr_t)partial % 16 == 0);
     if (ldx) s.ldx = ldx;
+    if ((use_2p() & 2) && s.nslices == 1 && nx <= k2pSamples) {
+        const int rc = siss_gn2p_bwd(dy, x, gamma, beta, mean, rstd, dx, accum, accum2, dx2, split_c, accumulate2, dgamma, dbeta,
+                                     colsum, colsum_ld, partial, n2, nx, set_images, set_stride, H, W, C, G, silu, dy_compact, ldx, stream);
+        if (rc >= 0) return rc;
+    }
+    partial += siss_gn2p_words(k2pSamples);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, nx, s.nslices);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;

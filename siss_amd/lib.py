@@ -38,6 +38,7 @@ SIGNATURES = {
     "siss_rowdot": [P, P, P, L, L, I, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gn_partial_words": [I, I, I, I, I],
+    "siss_groupnorm_set_two_phase": [I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
     "siss_groupnorm_fwd_ld": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, I, P],
     "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],
