@@ -230,8 +230,49 @@ def step_cases():
     return cases
 
 
+def _ref_module(rel):
+    """Import ONE reference file by path (torch + numpy only; nothing else of the reference package is touched)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_" + os.path.basename(rel)[:-3], os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+SAMPLER_CASES = [  # (dataset length, rank, num_replicas, shuffle, seed, window_size, indices to record)
+    (1000, 0, 1, True, 0, 0.5, 10000), (1000, 0, 8, True, 0, 0.5, 10000), (1000, 3, 8, True, 0, 0.5, 10000),
+    (37, 0, 1, True, 0, 0.5, 2000), (37, 1, 2, True, 7, 0.5, 2000), (64, 0, 1, True, 0, 0.0, 500),
+    (64, 2, 4, False, 0, 0.5, 500), (3, 0, 1, True, 0, 0.5, 100), (1, 0, 1, True, 0, 0.5, 10),
+]
+
+
+def sampler_cases():
+    """The data-input step in front of the path: index sequences of the reference's
+    data/utils/infinite_sampler.py:4-35 (rank / num_replicas as the data-parallel shards use them) and
+    data/utils/repeat_sampler.py:4-21 (the celeb forget set), recorded from the reference's own classes."""
+    import itertools
+    inf = _ref_module("data/utils/infinite_sampler.py").InfiniteSampler
+    rep = _ref_module("data/utils/repeat_sampler.py").RepeatedSampler
+    rec = {}
+    for (n, rank, world, shuffle, seed, win, count) in SAMPLER_CASES:
+        ds = list(range(n))
+        # torch >= 2.4 removed Sampler.__init__(data_source), which the reference's __init__ (written for torch 2.2.1,
+        # environment.yml:283) still calls: build the object without it and store the six attributes __init__ stores
+        # (infinite_sampler.py:11-16); the index ALGORITHM under test is the reference's own __iter__ (:18-35).
+        smp = inf.__new__(inf)
+        smp.dataset, smp.rank, smp.num_replicas, smp.shuffle, smp.seed, smp.window_size = ds, rank, world, shuffle, seed, win
+        idx = np.fromiter((int(i) for i in itertools.islice(iter(smp), count)), dtype=np.int32, count=count)
+        rec[f"inf_n{n}_r{rank}of{world}_sh{int(shuffle)}_s{seed}_w{win}"] = idx
+    for (n, repeats) in ((1, 16), (3, 4), (5, 1)):
+        smp = rep(list(range(n)), repeats)
+        rec[f"rep_n{n}_x{repeats}"] = np.array(list(iter(smp)), dtype=np.int32)
+        assert len(smp) == n * repeats
+    return rec
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "samplers.npz"), **sampler_cases())
     for name, rec in loss_cases().items():
         np.savez_compressed(os.path.join(OUT, f"siss_loss_{name}.npz"), **rec)
     for name, rec in step_cases().items():

@@ -28,6 +28,35 @@ class StepStats:
     pre_clip_norm: float
     weighted_loss_x: float
     weighted_loss_a: float
+    batch_stats: list = None      # one dict per micro-batch: the block the reference hands to wandb.log (:626-663)
+
+
+def batch_stats(items, loss_params=None, superfactor_decay=None):
+    """The per-micro-step statistics block, delete_celeb.py:626-663 (identical in delete_tshirt.py:568-605), line by
+    line: mean over ALL elements, max / min / (unbiased) std over the per-sample means; importance weights over the
+    batch; `superfactor` logged and then decayed IN the config (:658-662) -- loss_params is mutated like cfg is."""
+    loss, loss_x, loss_a, iw_x, iw_a, _, _ = items
+    out = {}
+    for name, v in (("loss", loss), ("loss_x", loss_x), ("loss_a", loss_a)):                 # :627-645
+        if v is not None:
+            v = v.detach()
+            per = v.mean(dim=[1, 2, 3])
+            out[name + "/mean"] = v.mean().item()
+            out[name + "/max"] = per.max().item()
+            out[name + "/min"] = per.min().item()
+            out[name + "/std"] = per.std().item()
+    for name, v in (("importance_weight_x", iw_x), ("importance_weight_a", iw_a)):          # :647-656
+        if v is not None:
+            v = v.detach()
+            out[name + "/mean"] = v.mean().item()
+            out[name + "/max"] = v.max().item()
+            out[name + "/min"] = v.min().item()
+            out[name + "/std"] = v.std().item()
+    if loss_params is not None and "superfactor" in loss_params:                              # :658-662
+        out["superfactor"] = loss_params["superfactor"]
+        if superfactor_decay is not None:
+            loss_params["superfactor"] *= superfactor_decay
+    return out
 
 
 def prep_inputs(ac, x0, a0, noise, t):
@@ -39,7 +68,7 @@ def prep_inputs(ac, x0, a0, noise, t):
 
 def unlearning_step(unet, optimizer, loss_obj, loss_fn, ac, micro_batches, *,
                     train_batch_size, scaling_norm, loss_params=None, max_grad_norm=1.0,
-                    eta=None, inf_guard=False, conditioning=None, pass_u=True):
+                    eta=None, inf_guard=False, conditioning=None, pass_u=True, superfactor_decay=None):
     """Run ONE optimizer step over ``micro_batches`` (len = gradient accumulation).
 
     Each micro-batch is a dict with x0, a0, noise, t and optionally u (mask uniforms).
@@ -47,6 +76,7 @@ def unlearning_step(unet, optimizer, loss_obj, loss_fn, ac, micro_batches, *,
     """
     loss_params = dict(loss_params or {})
     ga = len(micro_batches)
+    blocks = []
     fn = getattr(loss_obj, loss_fn)
     names = [n for n, _ in unet.named_parameters()]
     params = [p for _, p in unet.named_parameters()]
@@ -60,6 +90,10 @@ def unlearning_step(unet, optimizer, loss_obj, loss_fn, ac, micro_batches, *,
                 "importance_sampling_with_mixture", "subscore_bernoulli"):
             kw["u"] = mb["u"]
         items = fn(unet, mb["t"], mb["noise"], conditioning or {}, keep, forget, **kw)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")               # std of a single per-sample mean is nan, as in the reference
+            blocks.append(batch_stats(items, loss_params, superfactor_decay))                  # :626-663
         loss, _, _, _, _, wlx, wla = items
         if loss is not None:                                   # :682-684
             (loss.sum() / train_batch_size / ga).backward()
@@ -96,9 +130,9 @@ def unlearning_step(unet, optimizer, loss_obj, loss_fn, ac, micro_batches, *,
     optimizer.step()                                                            # :769
     optimizer.zero_grad()
     if gx is not None:
-        stats = StepStats(nx, na, s, pre, wlx_tot, wla_tot)
+        stats = StepStats(nx, na, s, pre, wlx_tot, wla_tot, blocks)
         gx = dict(zip(names, gx))
         ga_ = dict(zip(names, ga_))
     else:
-        stats = StepStats(float("nan"), float("nan"), float("nan"), pre, wlx_tot, wla_tot)
+        stats = StepStats(float("nan"), float("nan"), float("nan"), pre, wlx_tot, wla_tot, blocks)
     return stats, gx, ga_, g

@@ -207,7 +207,14 @@ class Prefetcher:
             raise RuntimeError("data prefetch thread failed") from self._err
         dev, ev, _ = item
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            # The batch was allocated on the COPY stream's pool but is consumed on the compute stream -- by kernels that
+            # take raw pointers (ctypes), which the caching allocator cannot see.  Without this the block returns to the
+            # copy-stream pool the moment the caller drops the tensor and the producer thread's next host.to() may
+            # overwrite it while the step's kernels (the loss seed re-reads x0 after the whole UNet forward) are still
+            # queued.  record_stream defers the reuse until the compute stream has passed the point of the free.
+            dev.record_stream(cur)
         return dev
 
     def close(self):

@@ -43,7 +43,11 @@ class FlatAdamW:
 
     def stats(self):
         """One small D2H copy: the logged gradient scalars (delete_celeb.py:748)."""
-        s = self.scalars.cpu()
+        return self.stats_from(self.scalars.cpu())
+
+    @staticmethod
+    def stats_from(s):
+        """The same from a host copy of the scalar block (SISSStepper.stats fetches it together with the loss rows)."""
         return {"norm_loss_x": float(s[0]), "norm_loss_a": float(s[1]), "dot": float(s[2]),
                 "scaling_factor": float(s[3]), "pre_clip_norm": float(s[4]), "clip_coef": float(s[5]),
                 "step": int(s[6])}

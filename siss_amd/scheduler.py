@@ -39,3 +39,26 @@ class DDPMScheduler:
         while a.dim() < original_samples.dim():
             a, b = a.unsqueeze(-1), b.unsqueeze(-1)
         return a * original_samples + b * noise
+
+
+def lr_multiplier(name, step, num_warmup_steps=0, num_training_steps=0):
+    """LR multiplier at scheduler step `step` of diffusers.optimization.get_scheduler(name, ...) (0.27.2, as published):
+    what delete_celeb.py:296-301 builds from cfg.lr_scheduler / cfg.warmup_steps / cfg.training_steps and steps after
+    every optimizer update (:770).  Schedules outside this table raise instead of silently training at a constant rate."""
+    import math
+    w, total = int(num_warmup_steps), int(num_training_steps)
+    if name == "constant":
+        return 1.0
+    if name == "constant_with_warmup":
+        return step / max(1.0, w) if step < w else 1.0
+    if name == "linear":
+        if step < w:
+            return step / max(1, w)
+        return max(0.0, (total - step) / max(1, total - w))
+    if name == "cosine":
+        if step < w:
+            return step / max(1, w)
+        progress = (step - w) / max(1, total - w)
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
+    raise NotImplementedError(f"lr_scheduler={name!r}: implemented: constant, constant_with_warmup, linear, cosine "
+                              "(diffusers.optimization.get_scheduler)")

@@ -37,7 +37,7 @@ class SISSStepper:
     def __init__(self, engine: UNetEngine, alphas_cumprod, *, lr, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=1e-2, scaling_norm=None, eta=None, lambd=0.5, train_batch_size,
                  grad_accum=1, max_grad_norm=1.0, loss_fn=SISS, inf_guard=False, process_group=None,
-                 mixed_precision="bf16", superfactor=1.0):
+                 mixed_precision="bf16", superfactor=1.0, superfactor_decay=None):
         self.e = engine
         dev = engine.device
         ac = alphas_cumprod.to(device=dev, dtype=torch.float32).contiguous()
@@ -48,6 +48,7 @@ class SISSStepper:
         self.train_batch_size, self.ga = int(train_batch_size), int(grad_accum)
         self.loss_fn = loss_fn
         self.superfactor = float(superfactor)
+        self.superfactor_decay = None if superfactor_decay is None else float(superfactor_decay)   # delete_celeb.py:658-662
         if loss_fn == ERASEDIFF:
             assert eta is not None, "erasediff needs eta (delete_celeb.py:740-742)"
         self.pg = process_group
@@ -138,8 +139,8 @@ class SISSStepper:
             # c_x / c_a go straight into the stacked cotangent buffer that seeds the dual backward
             seed = loss_bwd_seed(pred, m, x0, a0, scale, c_out=cot, partials=self._partials(B, pred[0].numel()))
             e.backward(cot, nsets=2)
-            self.last = dict(iw_x=m.iw_x, iw_a=m.iw_a, sum_loss_x=seed.sum_loss_x, sum_loss_a=seed.sum_loss_a,
-                             chw=pred[0].numel())
+            chw = pred[0].numel()
+            self.last = dict(loss_x=seed.sum_loss_x / chw, loss_a=seed.sum_loss_a / chw, iw_x=m.iw_x, iw_a=m.iw_a)
         elif self.loss_fn == NO_IS:
             # two forwards as ONE batch-2B forward (ddpm_deletion_loss.py:60-67), plain noise target
             m = mixture_fwd(x0, a0, noise, t, torch.ones(B, device=e.device), self.ac, self.gamma_tab,
@@ -152,7 +153,8 @@ class SISSStepper:
             tgt = torch.cat([noise, noise], 0)
             cot, _, sums = mse_bwd_seed(pred, tgt, scale)
             e.backward(cot, nsets=2)
-            self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums[:B], sum_loss_a=sums[B:], chw=pred[0].numel())
+            chw = pred[0].numel()
+            self.last = dict(loss_x=sums[:B] / chw, loss_a=sums[B:] / chw)
         elif self.loss_fn == ERASEDIFF:
             # ddpm_deletion_loss.py:70-78: keep half against the noise, forget half against U[0,1) "noise"; the
             # recombination is s = -max(eta - <g_x, g_a> / |g_a|^2, 0) (delete_celeb.py:740-742, optimizer mode)
@@ -168,7 +170,8 @@ class SISSStepper:
             tgt = torch.cat([noise.float(), erase_target.to(device=e.device, dtype=torch.float32)], 0)
             cot, _, sums = mse_bwd_seed(pred, tgt, scale)
             e.backward(cot, nsets=2)
-            self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums[:B], sum_loss_a=sums[B:], chw=pred[0].numel())
+            chw = pred[0].numel()
+            self.last = dict(loss_x=sums[:B] / chw, loss_a=sums[B:] / chw)
         elif self.loss_fn in (NEG_GRAD, NAIVE):
             # a `loss` is returned (ddpm_deletion_loss.py:82-96): ONE backward, no gradient split
             # (delete_celeb.py:682-684); NegGrad ascends on the forget batch with -superfactor
@@ -179,9 +182,12 @@ class SISSStepper:
             cot, _, sums = mse_bwd_seed(pred, noise, scale if keep else -self.superfactor * scale)
             # the second gradient set stays zero (zero_grad above): g = g_x through the inf-guarded s = 0
             e.backward(cot, nsets=1)
-            z = torch.zeros_like(sums)
-            self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums if keep else z, sum_loss_a=z if keep else sums,
-                             chw=pred[0].numel())
+            per = sums / pred[0].numel()
+            # the returned 7-tuple (ddpm_deletion_loss.py:88,:96): naive = (loss_x, loss_x, None, ...), NegGrad = (-sf loss_a, None, loss_a, ...)
+            self.last = dict(loss=per, loss_x=per) if keep else dict(loss=-self.superfactor * per, loss_a=per,
+                                                                   superfactor=self.superfactor)
+            if not keep and self.superfactor_decay is not None:
+                self.superfactor *= self.superfactor_decay         # applied after the loss call (delete_celeb.py:658-662)
         elif self.loss_fn == SUBSCORE:
             # ddpm_deletion_loss.py:99-122: Bernoulli keep/forget rows against the plain noise target; the row
             # selection loss[mask] / (1 - lambd), loss[~mask] is a per-sample weight on the shared forward
@@ -197,8 +203,10 @@ class SISSStepper:
             torch.mul(c, wx, out=cot[:B])
             torch.mul(c, wa, out=cot[B:])
             e.backward(cot, nsets=2)
-            self.last = dict(iw_x=None, iw_a=None, sum_loss_x=sums * wx.view(B), sum_loss_a=sums * wa.view(B),
-                             chw=pred[0].numel())
+            # loss[mask] / (1 - lambd) and loss[~mask] are ROW SELECTIONS (ddpm_deletion_loss.py:109-110): the logged
+            # statistics run over the selected rows only; the zero-size guards (:113-120) log one zero
+            self.last = dict(loss_x=sums / pred[0].numel() / (1.0 - self.lambd), loss_a=sums / pred[0].numel(),
+                             rows_x=keep, rows_a=(1.0 - keep) * any_keep, subscore=True)
         else:
             raise ValueError(f"loss_fn {self.loss_fn!r} is not on the HIP fast path")
         self._micro += 1
@@ -212,6 +220,9 @@ class SISSStepper:
     def _early_allreduce(self):
         if self._micro + 1 != self.ga:          # only the sync micro-step communicates
             return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the overlapped gradient exchange issues async collectives from inside the backward pass "
+                               "and cannot be captured into a hipGraph: run N > 1 eagerly or set_overlap(False)")
         ps = self.e.ps
         for s in range(ps.grads.shape[0]):
             self._pending.append(torch.distributed.all_reduce(ps.grads[s, ps.split:], group=self.pg, async_op=True))
@@ -243,20 +254,38 @@ class SISSStepper:
 
     # ------------------------------------------------------------------ logging (one small D2H)
     def stats(self):
-        st = self.opt.stats()
-        if self.last is not None:
-            chw = self.last["chw"]
-            lx, la = self.last["sum_loss_x"].float().cpu() / chw, self.last["sum_loss_a"].float().cpu() / chw
-            st.update({"loss_x/mean": float(lx.mean()), "loss_x/max": float(lx.max()), "loss_x/min": float(lx.min()),
-                       "loss_a/mean": float(la.mean()), "loss_a/max": float(la.max()), "loss_a/min": float(la.min())})
-            if lx.numel() > 1:
-                st["loss_x/std"], st["loss_a/std"] = float(lx.std()), float(la.std())
-            if self.last["iw_x"] is not None:
-                for k in ("iw_x", "iw_a"):
-                    v = self.last[k].cpu()
-                    name = "importance_weight_" + k[-1]
-                    st.update({f"{name}/mean": float(v.mean()), f"{name}/max": float(v.max()),
-                               f"{name}/min": float(v.min())})
-                    if v.numel() > 1:
-                        st[f"{name}/std"] = float(v.std())
+        """The scalars the reference logs for the LAST micro-batch (delete_celeb.py:626-663: loss / loss_x / loss_a mean
+        over all elements and max / min / unbiased std over the per-sample means; importance-weight mean / max / min /
+        std; superfactor) plus the optimizer step's gradient scalars (:748) -- fetched with ONE device-to-host copy."""
+        import math
+        last = self.last or {}
+        keys = [k for k in ("loss", "loss_x", "loss_a", "iw_x", "iw_a", "rows_x", "rows_a") if last.get(k) is not None]
+        parts = [self.opt.scalars.float().flatten()] + [last[k].float().flatten() for k in keys]
+        host = torch.cat(parts).cpu()                           # the one D2H of the step
+        st = self.opt.stats_from(host[:self.opt.scalars.numel()])
+        off = self.opt.scalars.numel()
+        vals = {}
+        for k in keys:
+            n = last[k].numel()
+            vals[k] = host[off:off + n].double()
+            off += n
+
+        def block(name, v):
+            st[name + "/mean"] = float(v.mean())
+            st[name + "/max"], st[name + "/min"] = float(v.max()), float(v.min())
+            st[name + "/std"] = float(v.std()) if v.numel() > 1 else math.nan      # torch.std of one value: nan, as logged
+
+        for k in ("loss", "loss_x", "loss_a"):
+            if k in vals:
+                v = vals[k]
+                if last.get("subscore") and k != "loss":
+                    v = v[vals["rows_" + k[-1]] > 0]
+                    if v.numel() == 0:
+                        v = torch.zeros(1, dtype=torch.float64)                 # ddpm_deletion_loss.py:113-120
+                block(k, v)
+        for k in ("iw_x", "iw_a"):
+            if k in vals:
+                block("importance_weight_" + k[-1], vals[k])
+        if "superfactor" in last:
+            st["superfactor"] = last["superfactor"]
         return st

@@ -56,10 +56,16 @@ class _DeleteBase(Task):
         if path and os.path.isdir(str(path)):
             sub = (cfg.get("subfolders") or {}).get("unet")
             return UNet2DModel.from_pretrained(path, subfolder=sub, device=device)
+        # The reference hard-fails here (DDPMPipeline.from_pretrained, delete_celeb.py:181).  Random-init weights of the
+        # same architecture are for benchmarks / smoke runs only and must be asked for: allow_random_init=true.
+        if not cfg.get("allow_random_init"):
+            raise FileNotFoundError(
+                f"checkpoint_path {path!r} is not a directory on disk (no network: hub ids cannot be fetched); "
+                "pass allow_random_init=true to train random-init weights of the configured architecture instead")
         ucfg = {k: v for k, v in (cfg.get("unet") or {}).items() if not k.startswith("_")}
         m = UNet2DModel(UNet2DConfig.from_dict(ucfg) if ucfg else self.default_unet(), device=device)
         m.engine.init_random(seed=int(cfg.random_seed))
-        print(f"[siss_amd] checkpoint {path!r} not found on disk: random-init weights of the same architecture")
+        print(f"[siss_amd] allow_random_init: checkpoint {path!r} not on disk, RANDOM-INIT weights of the same architecture")
         return m
 
     def load_scheduler(self):
@@ -72,14 +78,35 @@ class _DeleteBase(Task):
         cfg = self.cfg
         try:
             if cfg.get("dataset_all") is None or cfg.get("dataset_deletion") is None:
-                raise FileNotFoundError("no dataset configured")
+                raise FileNotFoundError("no dataset_all / dataset_deletion configured")
             transform = hydra_lite.instantiate(cfg.transform)
             ds_all = hydra_lite.instantiate(cfg.dataset_all, transform=transform)
             ds_del = hydra_lite.instantiate(cfg.dataset_deletion, transform=transform)
             return ds_all, ds_del
-        except Exception as e:      # datasets are not in the repo (reference .gitignore:7): synthetic stand-in
-            print(f"[siss_amd] dataset unavailable ({type(e).__name__}: {e}); using synthetic images")
+        except FileNotFoundError as e:
+            # Only a MISSING dataset can be replaced, and only when asked for (allow_synthetic=true: benchmarks / smoke
+            # runs; the datasets are not in the repo, reference .gitignore:7).  Every other error -- a typo in a target,
+            # a bad transform, a decode failure -- surfaces, as it does in the reference.
+            if not cfg.get("allow_synthetic"):
+                raise
+            print(f"[siss_amd] allow_synthetic: dataset unavailable ({e}); using SYNTHETIC images")
             return SyntheticImages(4096, shape, seed=1), SyntheticImages(1, shape, seed=2)
+
+    def check_supported(self):
+        """Refuse, loudly, the configured features of the reference loop this loop does not implement -- rather than
+        run something else than what the config says."""
+        cfg = self.cfg
+        ema = cfg.get("ema") or {}
+        if ema.get("use_ema") or cfg.get("use_ema"):
+            raise NotImplementedError("ema.use_ema=true: EMA of the unlearned weights is not implemented "
+                                      "(delete_celeb.py:235-251; every shipped delete config has it off)")
+        for key in ("checkpointing_steps", "resume_from_checkpoint"):
+            if cfg.get(key) not in (None, "null", False, 0):
+                raise NotImplementedError(f"{key}={cfg.get(key)!r}: accelerate-state checkpoints are not implemented "
+                                          "(delete_celeb.py:786-825; null in every shipped delete config); the final model "
+                                          "is written in the diffusers layout")
+        if cfg.get("mixed_precision") not in (None, "null", "no", "bf16"):
+            raise NotImplementedError(f"mixed_precision={cfg.get('mixed_precision')!r}: only null / bf16 (no loss scaler)")
 
     def optimizer_args(self):
         """(lr, betas, eps, weight_decay) of the AdamW the reference instantiates from cfg.optimizer
@@ -136,10 +163,17 @@ class _DeleteBase(Task):
         torch.cuda.set_device(device)
         seed = self.seed()
         torch.manual_seed(seed + rank)
+        self.check_supported()
         unet = self.load_unet(device)
         eng = unet.engine
         sched = self.load_scheduler()
         lr, betas, eps, wd = self.optimizer_args()
+        from .scheduler import lr_multiplier
+        lr_name = str(cfg.get("lr_scheduler") or "constant")
+        # get_scheduler(cfg.lr_scheduler, num_warmup_steps=cfg.warmup_steps, num_training_steps=cfg.training_steps)
+        # (delete_celeb.py:296-301; delete_sd.py passes lr_warmup_steps * GA / max_train_steps * GA)
+        warm, total = int(cfg.get("warmup_steps") or 0), int(cfg.get("training_steps") or 0)
+        lr_multiplier(lr_name, 0, warm, total)                  # raises now for a schedule that is not implemented
         d = cfg.deletion
         B, ga = int(cfg.train_batch_size), int(cfg.gradient_accumulation_steps)
         stepper = SISSStepper(
@@ -149,7 +183,8 @@ class _DeleteBase(Task):
             lambd=float((d.loss_params or {}).get("lambd", 0.5)), train_batch_size=B, grad_accum=ga,
             loss_fn=d.loss_fn, inf_guard=self.inf_guard, process_group=pg,
             mixed_precision=cfg.get("mixed_precision"),
-            superfactor=float((d.loss_params or {}).get("superfactor", 1.0)))
+            superfactor=float((d.loss_params or {}).get("superfactor", 1.0)),
+            superfactor_decay=d.get("superfactor_decay"))
         shape = (unet.config.in_channels, unet.config.sample_size, unet.config.sample_size)
         ds_all, ds_del = self.datasets(shape)
         # keep shard: decoded / pinned / copied in the background, `depth` batches ahead (the forget set is one or a
@@ -166,6 +201,9 @@ class _DeleteBase(Task):
         t0 = time.perf_counter()
         eval_every = int(cfg.get("eval_every") or 0)
         for step in range(n_steps):
+            # lr_scheduler.step() after every optimizer step (delete_celeb.py:770); accelerate's wrapper advances the
+            # schedule once per PROCESS per optimizer step (AcceleratedScheduler, split_batches=False)
+            stepper.opt.lr = lr * lr_multiplier(lr_name, step * world, warm, total)
             for _ in range(ga):
                 x0 = self.prepare_batch(next(it_all).to(device, non_blocking=True), g)
                 a0 = self.prepare_batch(next(it_del).to(device, non_blocking=True), g)
@@ -175,6 +213,7 @@ class _DeleteBase(Task):
                 stepper.micro_step(x0, a0, noise, t, u, cond)
             st = stepper.stats()
             st["global_step"] = step + 1
+            st["lr"] = stepper.opt.lr
             st["elapsed_s"] = time.perf_counter() - t0
             log.write(json.dumps(st) + "\n")
             log.flush()
@@ -242,10 +281,14 @@ class DeleteSD(_DeleteBase):
         path = cfg.get("pretrained_model_name_or_path")
         if path and os.path.isdir(os.path.join(str(path), "unet")):
             return UNet2DConditionModel.from_pretrained(path, subfolder="unet", device=device)   # delete_sd.py:458-462
+        if not cfg.get("allow_random_init"):                     # the reference hard-fails (from_pretrained, delete_sd.py:458-462)
+            raise FileNotFoundError(
+                f"pretrained_model_name_or_path {path!r} has no unet/ directory on disk (no network: hub ids cannot be "
+                "fetched); pass allow_random_init=true to train random-init weights of the configured architecture instead")
         ucfg = {k: v for k, v in (cfg.get("unet") or {}).items() if not k.startswith("_")}
         m = UNet2DConditionModel(UNet2DConditionConfig.from_dict(ucfg) if ucfg else self.default_unet(), device=device)
         m.engine.init_random(seed=self.seed())
-        print(f"[siss_amd] {path!r}/unet not found on disk: random-init weights of the same architecture")
+        print(f"[siss_amd] allow_random_init: {path!r}/unet not on disk, RANDOM-INIT weights of the same architecture")
         return m
 
     def load_scheduler(self):
@@ -266,7 +309,10 @@ class DeleteSD(_DeleteBase):
             return TensorImages(torch.load(ia)), TensorImages(torch.load(idl))     # [N,3,H,W] in [-1,1]: encoded per batch
         if la and ld and os.path.exists(str(la)) and os.path.exists(str(ld)):
             return TensorImages(torch.load(la)), TensorImages(torch.load(ld))
-        print("[siss_amd] no latent files configured (the VAE front end is outside the path): synthetic latents")
+        if not cfg.get("allow_synthetic"):
+            raise FileNotFoundError("no images_all / images_deletion (with a vae/ on disk) or latents_all / latents_deletion "
+                                    "tensor files configured; pass allow_synthetic=true for synthetic latents")
+        print("[siss_amd] allow_synthetic: no image / latent files configured, SYNTHETIC latents")
         return (SyntheticImages(4096, shape, seed=1, scale=self.VAE_SCALE, normal=True),
                 SyntheticImages(1, shape, seed=2, scale=self.VAE_SCALE, normal=True))
 
@@ -286,6 +332,9 @@ class DeleteSD(_DeleteBase):
             ids = tok([str(vp[0])], max_length=tok.model_max_length, padding="max_length", truncation=True,
                       return_tensors="pt").input_ids
             e = self.text_encoder(ids)[0].float()
-        else:
+        elif cfg.get("allow_synthetic"):
             e = torch.randn(1, 77, X, generator=torch.Generator().manual_seed(self.seed())).to(device)
+        else:
+            raise FileNotFoundError("validation_prompts[0] is neither a .pt embedding / token file on disk nor a prompt with a "
+                                    "text_encoder/ + tokenizer/ on disk; pass allow_synthetic=true for a synthetic embedding")
         return {"encoder_hidden_states": e.repeat(B, 1, 1)}     # one prompt for the whole batch (delete_sd.py:941-944)

@@ -976,6 +976,11 @@ class UNetEngine:
         for idx in range(len(self.tape) - 1, -1, -1):
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
+                if self.side is not None:
+                    # wgrads of the early-final parameters may still be running on the side stream: the collective
+                    # the hook starts must see complete gradients (and later side-stream work must not race with it)
+                    torch.cuda.current_stream().wait_stream(self.side)
+                    _BUSY.clear()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)     # join: every wgrad has landed in ps.grads

@@ -153,6 +153,7 @@ def test_mixture_and_loss_seed_vs_golden(dev, path):
     (wx * (pred - ex) ** 2).sum().div(B).backward()
     torch.testing.assert_close(s.c_x.cpu(), pred.grad, rtol=3e-4, atol=1e-7)
     torch.testing.assert_close(s.sum_loss_x.cpu(), torch.from_numpy(z["loss_x"]).sum(dim=[1, 2, 3]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s.sum_loss_a.cpu(), torch.from_numpy(z["loss_a"]).sum(dim=[1, 2, 3]), rtol=1e-5, atol=1e-6)
 
 
 def test_mixture_bf16_mode_matches_torch_bf16(dev):

@@ -395,3 +395,78 @@ def test_direct_concat_writes_equal_the_copying_concat(monkeypatch):
     assert float((ga - gb).norm() / gb.norm()) < 1e-5
     v = ActView(eng._act("probe", 2, 4, 4, 24), 0, 16)
     assert v.ld == 24 and tuple(v.data.shape) == (v.rows, 16) and v.data.data_ptr() == v.base.data.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a-6: the statistics block the reference logs every micro-step (delete_celeb.py:626-663) -- every key the reference
+# emits for the objective, against the oracle's literal restatement (oracle/step.py::batch_stats) on the same step.
+# Tolerances: loss statistics rel 5e-2 (bf16 compute vs fp32), importance weights rel 2e-3, std unbiased (nan for one row).
+# ---------------------------------------------------------------------------------------------------------------------
+def _check_block(ref_block, got, what):
+    import math
+    assert ref_block, what
+    for k, r in ref_block.items():
+        assert k in got, (what, "missing", k, sorted(got))
+        v = got[k]
+        if isinstance(r, float) and math.isnan(r):
+            assert math.isnan(v), (what, k, v, r)
+            continue
+        tol = 2e-3 if k.startswith("importance_weight") else (0.0 if k == "superfactor" else 5e-2)
+        scale = abs(r) if not k.endswith("/std") else max(abs(r), 1e-3 * abs(ref_block[k[:-4] + "/mean"]))
+        assert abs(v - r) <= tol * scale + 1e-12, (what, k, v, r)
+    extra = {k for k in got if "/" in k} - set(ref_block)
+    assert not extra, (what, "keys the reference does not log", extra)
+
+
+@pytest.mark.parametrize("loss_fn", ["importance_sampling_with_mixture", "double_forward_with_neg_del", "erasediff",
+                                     "simple_neg_del", "naive_del", "subscore_bernoulli"])
+def test_stats_block_matches_the_reference_block(setup, loss_fn):
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    eng, net, sd = _fresh(setup)
+    ac = S.alphas_cumprod()
+    okw = dict(lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6)
+    opt = torch.optim.AdamW(net.parameters(), **okw)
+    B = 5
+    mb = _batch(torch.Generator().manual_seed(77), B=B)
+    mb["t"] = torch.tensor([999, 940, 999, 870, 999])          # unequal per-sample losses / weights
+    mb["u"] = torch.tensor([0.9, 0.1, 0.7, 0.2, 0.6])
+    lp = {"lambd": 0.5} if loss_fn in ("importance_sampling_with_mixture", "subscore_bernoulli") else (
+        {"superfactor": 3.0} if loss_fn == "simple_neg_del" else {})
+    kw = dict(scaling_norm=5.0) if loss_fn != "erasediff" else dict(eta=1e-2)
+    st = SISSStepper(eng, ac, lambd=0.5, train_batch_size=B, loss_fn=loss_fn, mixed_precision=None, superfactor=3.0,
+                     superfactor_decay=0.5, inf_guard=True, **okw, **kw)
+    torch.manual_seed(99)
+    ref, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), loss_fn, ac, [mb], train_batch_size=B,
+                              scaling_norm=5.0, eta=1e-2, loss_params=lp, inf_guard=True, superfactor_decay=0.5)
+    torch.manual_seed(99)
+    target = torch.rand(mb["noise"].shape) if loss_fn == "erasediff" else None
+    st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"], erase_target=target)
+    _check_block(ref.batch_stats[0], st.stats(), loss_fn)
+    if loss_fn == "simple_neg_del":                              # superfactor *= superfactor_decay (:658-662)
+        assert st.superfactor == 1.5
+
+
+@pytest.mark.parametrize("u", [[0.9, 0.8, 0.7], [0.1, 0.2, 0.3], [0.9, 0.1, 0.2]])
+def test_subscore_stats_row_selection_and_zero_size_guards(setup, u):
+    """subscore_bernoulli logs statistics over the SELECTED rows (loss[mask] / (1 - lambd), loss[~mask]); with no keep
+    rows both entries are one zero, with no forget rows loss_a is (ddpm_deletion_loss.py:113-120); one selected row
+    has std nan."""
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    eng, net, sd = _fresh(setup)
+    ac = S.alphas_cumprod()
+    okw = dict(lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6)
+    opt = torch.optim.AdamW(net.parameters(), **okw)
+    mb = _batch(torch.Generator().manual_seed(78), B=3)
+    mb["u"] = torch.tensor(u)
+    st = SISSStepper(eng, ac, lambd=0.5, train_batch_size=3, loss_fn="subscore_bernoulli", mixed_precision=None,
+                     scaling_norm=5.0, inf_guard=True, **okw)
+    ref, *_ = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), "subscore_bernoulli", ac, [mb],
+                              train_batch_size=3, scaling_norm=5.0, loss_params={"lambd": 0.5}, inf_guard=True)
+    st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+    _check_block(ref.batch_stats[0], st.stats(), f"subscore u={u}")

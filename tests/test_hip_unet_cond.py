@@ -323,7 +323,8 @@ def test_delete_sd_task_runs_from_config(dev, tmp_path):
     torch.save(torch.randn(1, 77, 64), emb)
     cfg = H.compose("delete_sd", os.path.join(root, "config"),
                     ["training_steps=2", "train_batch_size=2", "gradient_accumulation_steps=2",
-                     f"output_dir={tmp_path}/out", "pretrained_model_name_or_path=/nonexistent"])
+                     f"output_dir={tmp_path}/out", "pretrained_model_name_or_path=/nonexistent",
+                     "allow_random_init=true", "allow_synthetic=true"])
     cfg.validation_prompts = [str(emb)]
     cfg.unet = dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=[64, 128],
                     down_block_types=["CrossAttnDownBlock2D", "DownBlock2D"],

@@ -220,3 +220,100 @@ def test_dp_two_ranks_equals_global_batch(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("dp ok") == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f-3: the data-input samplers, pinned by index sequences recorded from the REFERENCE's own classes
+# (tests/golden/samplers.npz, made by oracle/make_golden.py::sampler_cases from data/utils/infinite_sampler.py:4-35 and
+# data/utils/repeat_sampler.py:4-21).  Bit-exact (integer work).
+# ---------------------------------------------------------------------------------------------------------------------
+def test_samplers_reproduce_the_reference_index_sequences(golden_dir):
+    import itertools
+    import re as _re
+    from siss_amd.data import InfiniteSampler, RepeatedSampler
+    z = np.load(os.path.join(golden_dir, "samplers.npz"))
+    seen = 0
+    for key in z.files:
+        want = z[key]
+        m = _re.fullmatch(r"inf_n(\d+)_r(\d+)of(\d+)_sh(\d)_s(\d+)_w([\d.]+)", key)
+        if m:
+            n, rank, world, sh, seed = (int(m.group(i)) for i in range(1, 6))
+            smp = InfiniteSampler(list(range(n)), rank=rank, num_replicas=world, shuffle=bool(sh), seed=seed,
+                                  window_size=float(m.group(6)))
+            got = np.fromiter(itertools.islice(iter(smp), want.size), dtype=np.int64, count=want.size)
+        else:
+            m = _re.fullmatch(r"rep_n(\d+)_x(\d+)", key)
+            assert m, key
+            smp = RepeatedSampler(list(range(int(m.group(1)))), int(m.group(2)))
+            got = np.array(list(iter(smp)), dtype=np.int64)
+            assert len(smp) == want.size
+        assert got.shape == want.shape and np.array_equal(got, want), key
+        seen += 1
+    assert seen >= 12
+    # the shards of one global sequence: ranks r of R interleave back to the single-process order
+    one = z["inf_n1000_r0of1_sh1_s0_w0.5"]
+    assert np.array_equal(z["inf_n1000_r0of8_sh1_s0_w0.5"][:1250], one[0::8])
+    assert np.array_equal(z["inf_n1000_r3of8_sh1_s0_w0.5"][:1250], one[3::8])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f-2: unet/config.json as diffusers 0.27.2 writes it (every key, defaults included) loads; a config that describes a
+# network the HIP engine does not implement is REFUSED instead of silently computing the default architecture.
+# ---------------------------------------------------------------------------------------------------------------------
+DIFFUSERS_UNET2D_JSON = {
+    "_class_name": "UNet2DModel", "_diffusers_version": "0.27.2", "_name_or_path": "google/ddpm-celebahq-256",
+    "act_fn": "silu", "add_attention": True, "attention_head_dim": None, "attn_norm_num_groups": None,
+    "block_out_channels": [128, 128, 256, 256, 512, 512], "center_input_sample": False, "class_embed_type": None,
+    "down_block_types": ["DownBlock2D"] * 4 + ["AttnDownBlock2D", "DownBlock2D"], "downsample_padding": 0,
+    "downsample_type": "conv", "dropout": 0.0, "flip_sin_to_cos": False, "freq_shift": 1, "in_channels": 3,
+    "layers_per_block": 2, "mid_block_scale_factor": 1, "norm_eps": 1e-06, "norm_num_groups": 32, "num_class_embeds": None,
+    "num_train_timesteps": None, "out_channels": 3, "resnet_time_scale_shift": "default", "sample_size": 256,
+    "time_embedding_type": "positional", "up_block_types": ["UpBlock2D", "AttnUpBlock2D"] + ["UpBlock2D"] * 4,
+    "upsample_type": "conv",
+}
+
+
+def test_diffusers_config_json_loads_and_unsupported_architectures_are_refused():
+    from siss_amd.config import UNet2DConditionConfig, UNet2DConfig
+    c = UNet2DConfig.from_dict(DIFFUSERS_UNET2D_JSON)
+    assert c == UNet2DConfig.celebahq256()
+    for key, val in (("resnet_time_scale_shift", "scale_shift"), ("add_attention", False), ("time_embedding_type", "fourier"),
+                     ("center_input_sample", True), ("mid_block_scale_factor", 2.0), ("dropout", 0.1),
+                     ("downsample_type", "resnet"), ("class_embed_type", "timestep"), ("act_fn", "gelu"),
+                     ("attn_norm_num_groups", 8), ("some_future_key", 1)):
+        with pytest.raises(ValueError, match=key):
+            UNet2DConfig.from_dict({**DIFFUSERS_UNET2D_JSON, key: val})
+    with pytest.raises(ValueError, match="down_block_types"):
+        UNet2DConfig.from_dict({**DIFFUSERS_UNET2D_JSON, "down_block_types": ["SkipDownBlock2D"] * 6})
+    sd = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=[320, 640, 1280, 1280],
+              down_block_types=["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], up_block_types=["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3,
+              layers_per_block=2, attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32, norm_eps=1e-5,
+              downsample_padding=1, flip_sin_to_cos=True, freq_shift=0, act_fn="silu", center_input_sample=False,
+              mid_block_type="UNetMidBlock2DCrossAttn", only_cross_attention=False, use_linear_projection=False,
+              upcast_attention=False, dual_cross_attention=False, class_embed_type=None, num_class_embeds=None,
+              resnet_time_scale_shift="default", mid_block_scale_factor=1, _class_name="UNet2DConditionModel")
+    assert UNet2DConditionConfig.from_dict(sd) == UNet2DConditionConfig.sd15()
+    for key, val in (("use_linear_projection", True), ("only_cross_attention", True), ("transformer_layers_per_block", 2),
+                     ("addition_embed_type", "text_time")):       # SD 2.x / SDXL UNets are different networks
+        with pytest.raises(ValueError, match=key):
+            UNet2DConditionConfig.from_dict({**sd, key: val})
+
+
+def test_lr_multiplier_matches_the_published_schedules():
+    """diffusers.optimization.get_scheduler as delete_celeb.py:296-301 builds it (cfg.lr_scheduler, warmup_steps,
+    training_steps), checked against torch's LambdaLR driving the published lambdas."""
+    import math
+    from siss_amd.scheduler import lr_multiplier
+    W, T = 3, 10
+    lam = {"constant": lambda s: 1.0, "constant_with_warmup": lambda s: s / max(1.0, W) if s < W else 1.0,
+           "linear": lambda s: s / max(1, W) if s < W else max(0.0, (T - s) / max(1, T - W)),
+           "cosine": lambda s: s / max(1, W) if s < W else max(0.0, 0.5 * (1 + math.cos(math.pi * (s - W) / max(1, T - W))))}
+    for name, f in lam.items():
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=1.0)
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, f)
+        for s in range(T + 2):
+            assert abs(opt.param_groups[0]["lr"] - lr_multiplier(name, s, W, T)) < 1e-12, (name, s)
+            opt.step(); sch.step()
+    with pytest.raises(NotImplementedError):
+        lr_multiplier("polynomial", 0, W, T)
