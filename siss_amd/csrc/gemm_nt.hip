@@ -323,7 +323,7 @@ int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
 
 // Diagnostics: number of launches dispatched to device kernel `kernel_id` since the last reset (process-wide):
 // 0 gemm_nt_kernel, 1 gemm_nt_c3p_kernel, 2 gemm_nt_c3_kernel, 3 gemm_nt_conv3_kernel, 4 gemm_nt_kernel split-K (+ reduce),
-// 5 gemm_tn_kernel<1>, 6 gemm_tn_kernel<3>, 7 gemm_nt_c3p_kernel launches that also emitted GroupNorm statistics.
+// 5 gemm_tn_kernel<1>, 6 gemm_tn_kernel<3>, 7 GroupNorm slab kernels (forward or backward, small sites).
 // -1 for an unknown id.  siss_dispatch_reset() zeroes them all.  (Tests use these to prove which kernel a case ran on.)
 long siss_dispatch_count(int kernel_id) {
     return kernel_id >= 0 && kernel_id < SISS_K_COUNT ? __atomic_load_n(&g_dispatch[kernel_id], __ATOMIC_RELAXED) : -1;

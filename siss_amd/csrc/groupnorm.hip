@@ -448,13 +448,20 @@ bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16) {
 constexpr int k2pSamples = 64;
 int g_use_2p = -1;
 int use_2p() {
-    if (g_use_2p < 0) { const char* e = getenv("SISS_GN_2P"); g_use_2p = e ? atoi(e) : 0; }
+    if (g_use_2p < 0) { const char* e = getenv("SISS_GN_2P"); g_use_2p = e ? atoi(e) : 4; }
     return g_use_2p;
 }
 
 }  // namespace
 
 long siss_gn2p_words(int n);      // groupnorm2p.hip
+int siss_gn_slab_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int N, int H,
+                     int W, int C, int G, float eps, int silu, int out_compact, int ldx, void* stream);
+int siss_gn_slab_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                     const float* rstd, void* dx, const void* accum, const void* accum2, void* dx2, int split_c,
+                     int accumulate2, float* dgamma, float* dbeta, float* colsum, long colsum_ld, int n2, int nx,
+                     int set_images, long set_stride, int H, int W, int C, int G, int silu, int dy_compact, int ldx,
+                     void* stream);
 int siss_gn2p_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* ws,
                   int N, int H, int W, int C, int G, float eps, int silu, int out_compact, int ldx, void* stream);
 int siss_gn2p_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
@@ -465,12 +472,13 @@ int siss_gn2p_bwd(const void* dy, const void* x, const float* gamma, const float
 
 extern "C" {
 
-// Selects the GroupNorm kernels: bit 0 = two-phase forward, bit 1 = two-phase backward (groupnorm2p.hip: one launch, every
-// byte once); 0 = the two-pass kernels everywhere; -1 = back to the default ($SISS_GN_2P, else 0: measured on MI355X the
-// per-sample barrier chain of the two-phase form costs more than the second read it saves).
-// Returns the value in effect.
+// Selects the GroupNorm kernels: bit 2 (4) = slab kernels for the small sites (<= 32 x 32 pixels: one launch, a block holds its
+// (sample, channel slice) on chip); bit 0 / bit 1 = two-phase forward / backward with a per-sample barrier (groupnorm2p.hip);
+// 0 = the two-pass kernels everywhere; -1 = back to the default ($SISS_GN_2P, else 4: measured on MI355X the slab kernels
+// win at the small sites, while the barrier chain of the two-phase form costs more than the second read it saves --
+// DESIGN.md section 3.2).  Returns the value in effect.
 int siss_groupnorm_set_two_phase(int mask) {
-    g_use_2p = mask < 0 ? -1 : (mask & 3);
+    g_use_2p = mask < 0 ? -1 : (mask & 7);
     return use_2p();
 }
 
@@ -493,6 +501,11 @@ int siss_groupnorm_fwd_ld(const void* x, const float* gamma, const float* beta, 
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
     if (ldx) s.ldx = ldx;
     SISS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y | (uintptr_t)partial) % 16 == 0);
+    if ((use_2p() & 4) && s.nslices == 1) {
+        // small sites: one launch, the block holds its (sample, channel slice) on chip (groupnorm2p.hip, slab kernels)
+        const int rc = siss_gn_slab_fwd(x, gamma, beta, y, mean, rstd, N, H, W, C, G, eps, silu, out_compact, ldx, stream);
+        if (rc >= 0) return rc;
+    }
     if ((use_2p() & 1) && s.nslices == 1 && N <= k2pSamples) {
         // one launch, every byte once (groupnorm2p.hip); -1: shape not covered -> the two-pass kernels below
         const int rc = siss_gn2p_fwd(x, gamma, beta, y, mean, rstd, partial, N, H, W, C, G, eps, silu, out_compact, ldx, stream);
@@ -537,6 +550,11 @@ int siss_groupnorm_bwd_ld(const void* dy, const void* x, const float* gamma, con
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
     SISS_CHECK_ARG((uintptr_t)partial % 16 == 0);
     if (ldx) s.ldx = ldx;
+    if ((use_2p() & 4) && s.nslices == 1 && (n2 == nx || n2 == 2 * nx) && n2 / set_images <= 2) {
+        const int rc = siss_gn_slab_bwd(dy, x, gamma, beta, mean, rstd, dx, accum, accum2, dx2, split_c, accumulate2, dgamma, dbeta,
+                                        colsum, colsum_ld, n2, nx, set_images, set_stride, H, W, C, G, silu, dy_compact, ldx, stream);
+        if (rc >= 0) return rc;
+    }
     if ((use_2p() & 2) && s.nslices == 1 && nx <= k2pSamples) {
         const int rc = siss_gn2p_bwd(dy, x, gamma, beta, mean, rstd, dx, accum, accum2, dx2, split_c, accumulate2, dgamma, dbeta,
                                      colsum, colsum_ld, partial, n2, nx, set_images, set_stride, H, W, C, G, silu, dy_compact, ldx, stream);

@@ -11,7 +11,8 @@ row-strided inputs (column views of a concat buffer), compact outputs / cotangen
 inputs (accum, accum2), the channel-split output with accumulation (concat backward), per-sample column sums
 (time-embedding gradient), one and two cotangent sets, the No-IS layout (2B saved samples, sets by sample index).
 Tolerances: y, dx rel 1.5e-2 of scale (bf16 outputs); dgamma / dbeta / colsum rel 5e-3; mean / rstd rel 1e-5.
-The two-phase kernels must be bitwise deterministic and leave their workspace zero.
+The two-phase and slab kernels must be bitwise deterministic; the two-phase kernels leave their workspace zero.
+"slab" = the default configuration: slab kernels at the small sites (<= 32 x 32), two-pass kernels elsewhere.
 """
 import pytest
 import torch
@@ -77,7 +78,7 @@ FWD_CASES = [  # B, C, H, W, silu, compact, ld_extra
 ]
 
 
-@pytest.mark.parametrize("mode", [0, 3], ids=["two_pass", "two_phase"])
+@pytest.mark.parametrize("mode", [0, 3, 4], ids=["two_pass", "two_phase", "slab"])
 @pytest.mark.parametrize("B,C,H,W,silu,compact,ldx", FWD_CASES)
 def test_groupnorm_forward(dev, mode, B, C, H, W, silu, compact, ldx):
     from siss_amd import lib
@@ -91,12 +92,15 @@ def test_groupnorm_forward(dev, mode, B, C, H, W, silu, compact, ldx):
     m_ref, v_ref = xg.mean(-1), xg.var(-1, unbiased=False)
     part = torch.zeros(lib.query("siss_gn_partial_words", B, H, W, C, G), device=dev)
     assert lib.query("siss_groupnorm_set_two_phase", mode) == mode
+    lib.dispatch_counts(reset=True)
     try:
         _, _, out, mean, rstd, _ = _run_fwd(lib, dev, x, gamma, beta, eps, silu, compact, ldx, part)
         _close(out, ref, 1.5e-2, "y")
         torch.testing.assert_close(mean, m_ref, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(rstd, (v_ref + eps).rsqrt(), rtol=1e-4, atol=1e-6)
         if mode:
+            if mode == 4 and H * W <= 1024 and C // G >= 4:
+                assert lib.dispatch_counts()["gn_slab"] > 0, "a small site must run on the slab kernel"
             words2p = lib.query("siss_gn_partial_words", 1, 8, 8, 128, G) - 1 * 1 * 2 * G   # prefix of the workspace
             assert float(part[:words2p].abs().max()) == 0.0, "the two-phase kernels must leave their workspace zero"
             _, _, out2, *_ = _run_fwd(lib, dev, x, gamma, beta, eps, silu, compact, ldx, part)
@@ -119,7 +123,7 @@ BWD_CASES = [  # B(saved), sets, C, H, W, silu, compact_dy, accum, accum2, split
 ]
 
 
-@pytest.mark.parametrize("mode", [0, 3], ids=["two_pass", "two_phase"])
+@pytest.mark.parametrize("mode", [0, 3, 4], ids=["two_pass", "two_phase", "slab"])
 @pytest.mark.parametrize("B,sets,C,H,W,silu,cdy,acc,acc2,split,colsum,ldx", BWD_CASES)
 def test_groupnorm_backward(dev, mode, B, sets, C, H, W, silu, cdy, acc, acc2, split, colsum, ldx):
     from siss_amd import lib
