@@ -34,6 +34,8 @@ SUBSCORE = "subscore_bernoulli"
 
 
 class SISSStepper:
+    _warned_fp32 = False
+
     def __init__(self, engine: UNetEngine, alphas_cumprod, *, lr, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=1e-2, scaling_norm=None, eta=None, lambd=0.5, train_batch_size,
                  grad_accum=1, max_grad_norm=1.0, loss_fn=SISS, inf_guard=False, process_group=None,
@@ -54,6 +56,16 @@ class SISSStepper:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.io_dtype = torch.bfloat16 if mixed_precision == "bf16" else torch.float32
+        if mixed_precision != "bf16" and not SISSStepper._warned_fp32:
+            # config/delete_*.yaml ship mixed_precision: null (fp32 everywhere in the reference).  Here that selects f32
+            # image / noise I/O, f32 master weights, gradients and optimizer state -- but every GEMM still takes bf16
+            # MFMA operands with f32 accumulation (there is no f32-operand GEMM path).
+            import warnings
+            warnings.warn("siss_amd: mixed_precision is not 'bf16': I/O, master weights, gradients and optimizer state are "
+                          "f32, but convolutions / linears still run on bf16 MFMA operands with f32 accumulation "
+                          "(no f32-operand GEMM path) -- results match an fp32 run to bf16 tolerance, not bitwise",
+                          RuntimeWarning, stacklevel=2)
+            SISSStepper._warned_fp32 = True
         self.opt = FlatAdamW(engine.ps.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                              max_grad_norm=max_grad_norm, shadow=engine.ps.shadow)
         self._micro = 0
