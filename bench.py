@@ -283,6 +283,8 @@ def main():
                             "allreduce = RCCL all-reduce, direct = all-to-all reduce-scatter + all-gather (siss_amd/dp.py)"}
         timings = getattr(st, "overlap_timings", None) or {}
         for name, fn in EXCHANGES.items():
+            if fn is None:
+                continue                                  # "sharded" is a whole update, not an exchange of the flat pair
             if name == "direct" and "serial_direct_ms" not in timings and timings:
                 continue                                  # the autotune's probe found no all-to-all on this backend
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

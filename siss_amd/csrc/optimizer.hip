@@ -222,6 +222,27 @@ int siss_grad_norms_scale(const float* gx, const float* ga, long n, int mode, fl
     SISS_LAUNCH_RET();
 }
 
+// The two halves of siss_grad_norms_scale on their own, for the SHARDED data-parallel update (reduce-scatter
+// -> shard-local recombine / clip / AdamW -> all-gather): every rank sums its parameter shard, the three sums
+// (|g_x|^2, |g_a|^2, <g_x, g_a>) are all-reduced by the host, and the step scalars are formed from the global sums.
+// siss_grad_norm_partials writes 3 doubles per block to `partials` and returns the block count in *nblk_out (host int).
+int siss_grad_norm_partials(const float* gx, const float* ga, long n, double* partials, int* nblk_out, void* stream) {
+    SISS_CHECK_ARG(gx && ga && partials && nblk_out && n > 0);
+    SISS_CHECK_ARG(((uintptr_t)gx | (uintptr_t)ga) % 16 == 0);
+    const int nblk = grid_for(n);
+    norms_kernel<<<nblk, kThreads, 0, (hipStream_t)stream>>>(gx, ga, n, partials);
+    *nblk_out = nblk;
+    SISS_LAUNCH_RET();
+}
+// sums: `nrows` rows of 3 doubles (device) whose column sums are the GLOBAL |g_x|^2, |g_a|^2, <g_x, g_a>.
+int siss_grad_scalars(const double* sums, int nrows, int mode, float knob, float max_norm, float beta1, float beta2,
+                      float* scalars, void* stream) {
+    SISS_CHECK_ARG(sums && scalars && nrows > 0 && mode >= 0 && mode <= 2);
+    scalars_kernel<<<1, kThreads, 0, (hipStream_t)stream>>>(sums, nrows, mode, knob, max_norm, beta1, beta2,
+                                                            reinterpret_cast<StepScalars*>(scalars));
+    SISS_LAUNCH_RET();
+}
+
 // pass 2.  shadow (bf16 copy of the updated parameters) and g_out (final clipped gradient) are optional.
 int siss_recombine_clip_adamw(const float* gx, const float* ga, float* p, float* m, float* v, void* shadow,
                               float* g_out, long n, float lr, float beta1, float beta2, float eps, float wd,

@@ -51,7 +51,42 @@ def direct_exchange_flat_grads(flat_pair, group=None):
     return flat_pair
 
 
-EXCHANGES = {"allreduce": allreduce_flat_grads, "direct": direct_exchange_flat_grads}
+def reduce_scatter_param_shards(flat_pair, group=None):
+    """First half of the SHARDED update: rank j receives, and sums in rank order, every rank's slice
+    [j P/N, (j+1) P/N) of g_x and of g_a (two all-to-alls, one per gradient set, so that a rank owns the SAME parameter
+    range of both sets).  Returns (g_x shard, g_a shard, lo, hi); P must divide by the world size."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nsets, P = flat_pair.shape
+    assert nsets == 2 and P % world == 0 and flat_pair.is_contiguous()
+    shard = P // world
+    key = ("rs", flat_pair.device, flat_pair.dtype, P, world)
+    scratch = _SCRATCH.get(key)
+    if scratch is None:
+        scratch = _SCRATCH[key] = torch.empty(2 * P + 2 * shard, dtype=flat_pair.dtype, device=flat_pair.device)
+    out = []
+    for s in range(2):
+        recv, mine = scratch[s * P:(s + 1) * P], scratch[2 * P + s * shard:2 * P + (s + 1) * shard]
+        dist.all_to_all_single(recv, flat_pair[s], group=group)
+        torch.sum(recv.view(world, shard), dim=0, out=mine)         # fixed rank order: the same bits whoever asks
+        out.append(mine)
+    return out[0], out[1], rank * shard, (rank + 1) * shard
+
+
+def all_gather_params(flat_params, lo, hi, group=None):
+    """Second half: every rank contributes its updated shard [lo, hi); afterwards all replicas hold the same parameters
+    (each element was written by exactly one rank)."""
+    key = ("ag", flat_params.device, flat_params.dtype, hi - lo)
+    mine = _SCRATCH.get(key)
+    if mine is None:
+        mine = _SCRATCH[key] = torch.empty(hi - lo, dtype=flat_params.dtype, device=flat_params.device)
+    mine.copy_(flat_params[lo:hi])
+    dist.all_gather_into_tensor(flat_params, mine, group=group)
+    return flat_params
+
+
+# "sharded" is not a gradient exchange with the replicated update behind it: SISSStepper handles it (reduce-scatter ->
+# shard-local norm-fix / clip / AdamW -> all-gather of the parameters); listed here so that the name validates.
+EXCHANGES = {"allreduce": allreduce_flat_grads, "direct": direct_exchange_flat_grads, "sharded": None}
 
 
 def recombine_reference(gx, ga, scaling_norm, max_norm=1.0):

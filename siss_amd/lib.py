@@ -25,6 +25,8 @@ SIGNATURES = {
     "siss_opt_partials_words": [],
     "siss_opt_scalars_words": [],
     "siss_grad_norms_scale": [P, P, L, I, F, F, F, F, P, P, P],
+    "siss_grad_norm_partials": [P, P, L, P, IP],
+    "siss_grad_scalars": [P, I, I, F, F, F, F, P],
     "siss_recombine_clip_adamw": [P, P, P, P, P, P, P, L, F, F, F, F, F, P, P],
     "siss_cast_f32_bf16": [P, P, L, P],
     "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],

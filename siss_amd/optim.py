@@ -41,6 +41,28 @@ class FlatAdamW:
                  self.last_grad if want_grad else None, n, self.lr, self.betas[0], self.betas[1],
                  self.eps, self.wd, self.scalars)
 
+    def launch_sharded(self, gx_shard, ga_shard, lo, hi, group, *, scaling_norm=None, eta=None, inf_guard=False):
+        """The same update on THIS rank's parameter shard [lo, hi) (sharded data-parallel exchange):
+        gx_shard / ga_shard are the rank-summed gradients of the shard.  The three norm sums are all-reduced (24 bytes),
+        so every rank forms the same scaling factor and clip coefficient as the replicated update; p / m / v / shadow are
+        touched on [lo, hi) only -- the caller all-gathers the parameters afterwards."""
+        import ctypes
+        import torch.distributed as dist
+        n = hi - lo
+        assert gx_shard.numel() == n and ga_shard.numel() == n and gx_shard.dtype == torch.float32
+        if eta is not None:
+            mode, knob = MODE_ERASEDIFF, float(eta)
+        else:
+            mode, knob = (MODE_NORM_FIX_INF_GUARD if inf_guard else MODE_NORM_FIX), float(scaling_norm)
+        nblk = ctypes.c_int(0)
+        lib.call("siss_grad_norm_partials", gx_shard, ga_shard, n, self.partials, ctypes.byref(nblk))
+        sums = self.partials.view(-1, 3)[:nblk.value].sum(dim=0, keepdim=True)      # [1, 3] f64 on the device
+        dist.all_reduce(sums, group=group)
+        lib.call("siss_grad_scalars", sums, 1, mode, knob, self.max_grad_norm, self.betas[0], self.betas[1], self.scalars)
+        lib.call("siss_recombine_clip_adamw", gx_shard, ga_shard, self.p[lo:hi], self.m[lo:hi], self.v[lo:hi],
+                 self.shadow[lo:hi] if self.shadow is not None else None, None, n, self.lr, self.betas[0],
+                 self.betas[1], self.eps, self.wd, self.scalars)
+
     def stats(self):
         """One small D2H copy: the logged gradient scalars (delete_celeb.py:748)."""
         return self.stats_from(self.scalars.cpu())

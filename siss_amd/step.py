@@ -75,7 +75,7 @@ class SISSStepper:
         # ~85 % of the bytes) is final long before the high-resolution down blocks finish their backward;
         # its all-reduce is started from a hook inside the backward pass and runs beside the rest of it.
         import os
-        self.exchange = os.environ.get("SISS_DP_EXCHANGE", "allreduce")      # serial mode: "allreduce" | "direct"
+        self.exchange = os.environ.get("SISS_DP_EXCHANGE", "allreduce")      # serial mode: "allreduce" | "direct" | "sharded"
         assert self.exchange in EXCHANGES
         self.set_overlap(self.pg is not None and self.world > 1 and engine.ps.split < engine.ps.total
                          and os.environ.get("SISS_DP_OVERLAP", "1") != "0")
@@ -102,7 +102,8 @@ class SISSStepper:
         # overlap_cu248: the overlapped exchange with the persistent 3x3 kernel on 248 of the 256 CUs -- it holds all
         # the LDS of every CU it runs on for its whole duration, so RCCL's workgroups otherwise wait for kernel gaps
         candidates = {"overlap": (True, "allreduce", 256), "overlap_cu248": (True, "allreduce", 248),
-                      "serial": (False, "allreduce", 256), "serial_direct": (False, "direct", 256)}
+                      "serial": (False, "allreduce", 256), "serial_direct": (False, "direct", 256),
+                      "serial_sharded": (False, "sharded", 256)}
         try:                                                     # a backend without all-to-all keeps the all-reduce
             probe = torch.ones(2, 8 * self.world, device=self.e.device)
             direct_exchange_flat_grads(probe, self.pg)
@@ -111,6 +112,7 @@ class SISSStepper:
         except (RuntimeError, AssertionError, NotImplementedError) as exc:
             errors["serial_direct"] = (str(exc) or type(exc).__name__)[:200]
             del candidates["serial_direct"]
+            del candidates["serial_sharded"]                     # its reduce-scatter is the same all-to-all
         for name, (mode, exch, cus) in candidates.items():
             self.set_overlap(mode, exch)
             lib.query("siss_gemm_nt_set_c3p_blocks", cus)
@@ -124,7 +126,7 @@ class SISSStepper:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
             results[name] = float(tt.item()) / iters
         best = min(results, key=results.get)
-        self.set_overlap(best.startswith("overlap"), "direct" if best == "serial_direct" else "allreduce")
+        self.set_overlap(best.startswith("overlap"), candidates[best][1])
         self.c3p_blocks = lib.query("siss_gemm_nt_set_c3p_blocks", candidates[best][2])
         self.overlap_timings = {k + "_ms": v * 1e3 for k, v in results.items()}
         if errors:
@@ -241,7 +243,9 @@ class SISSStepper:
 
     def _sync_and_update(self):
         g = self.e.ps.grads
-        if self.pg is not None and self.world > 1:
+        sharded = (self.pg is not None and self.world > 1 and self.exchange == "sharded" and not self.overlap
+                   and g.shape[1] % self.world == 0)
+        if self.pg is not None and self.world > 1 and not sharded:
             # the exchange of the step: sum of [g_x ; g_a] over ranks (RCCL over xGMI) -- one flat buffer; with
             # the overlap hook the early-final tail is already in flight and only the head remains
             if self.overlap and self._pending:
@@ -252,11 +256,21 @@ class SISSStepper:
                     w.wait()
                 self._pending = []
             else:
-                EXCHANGES[self.exchange](g, self.pg)
+                (EXCHANGES.get(self.exchange) or allreduce_flat_grads)(g, self.pg)     # 'sharded' that cannot shard: all-reduce
         single = self.loss_fn in (NEG_GRAD, NAIVE)
-        self.opt.launch(g, scaling_norm=self.scaling_norm if not single else 1.0,
-                        eta=self.eta if self.loss_fn == ERASEDIFF else None,
-                        inf_guard=self.inf_guard or single)
+        okw = dict(scaling_norm=self.scaling_norm if not single else 1.0,
+                   eta=self.eta if self.loss_fn == ERASEDIFF else None, inf_guard=self.inf_guard or single)
+        if sharded:
+            # reduce-scatter -> this rank's 1/N of the norm sums (3 doubles all-reduced) and of the recombine / clip / AdamW
+            # pass -> all-gather of the updated f32 parameters (3 P (N-1)/N floats on the wire instead of 4 P (N-1)/N,
+            # optimizer traffic / N); the bf16 operand shadow is recast from the gathered master
+            from .dp import all_gather_params, reduce_scatter_param_shards
+            gx_s, ga_s, lo, hi = reduce_scatter_param_shards(g, self.pg)
+            self.opt.launch_sharded(gx_s, ga_s, lo, hi, self.pg, **okw)
+            all_gather_params(self.e.ps.flat, lo, hi, self.pg)
+            self.e.refresh_weights(cast_shadow=True)
+            return
+        self.opt.launch(g, **okw)
         self.e.refresh_weights()
 
     def step(self, x0, a0, noise, t, u, conditioning=None, erase_target=None):

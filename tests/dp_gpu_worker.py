@@ -85,7 +85,7 @@ def main():
     # the direct exchange (all-to-all reduce-scatter + all-gather) is timed too when the backend has an all-to-all for
     # device tensors; otherwise the probe's error is recorded and the all-reduce kept
     assert len(set(flags)) == 1 and {"overlap_ms", "overlap_cu248_ms", "serial_ms"} <= keys <= {
-        "overlap_ms", "overlap_cu248_ms", "serial_ms", "serial_direct_ms", "errors"}
+        "overlap_ms", "overlap_cu248_ms", "serial_ms", "serial_direct_ms", "serial_sharded_ms", "errors"}
     assert st3.c3p_blocks in (248, 256)
     assert ("serial_direct_ms" in keys) != ("errors" in keys), st3.overlap_timings
     if "serial_direct_ms" in keys:
@@ -96,6 +96,23 @@ def main():
         st4.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
         d3 = eng.ps.flat - base
         cos = float((d3 * d2).sum() / (d3.norm() * d2.norm()))
+        assert cos > 0.999, cos
+        # the SHARDED update (reduce-scatter -> this rank's half of norm-fix / clip / AdamW -> all-gather of the parameters,
+        # SURVEY.md section 5) is the same step: same scalars, same update, replicas bit-identical
+        eng.load_state_dict(sd)
+        st5 = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, **kw)
+        st5.set_overlap(False, "sharded")
+        st5.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
+        s5 = st5.stats()
+        for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm"):
+            assert abs(s5[k] - dp_stats[k]) <= 1e-3 * abs(dp_stats[k]), (k, s5[k], dp_stats[k])
+        p5 = eng.ps.flat.clone()
+        both = [torch.zeros_like(p5) for _ in range(world)]
+        dist.all_gather(both, p5)
+        assert all(torch.equal(both[0], o) for o in both), "sharded update: replicas diverged"
+        assert torch.equal(eng.ps.shadow, eng.ps.flat.to(torch.bfloat16)), "bf16 operand shadow must follow the gathered master"
+        d5 = p5 - base
+        cos = float((d5 * d2).sum() / (d5.norm() * d2.norm()))
         assert cos > 0.999, cos
     print("dp exchange timings", rank, st3.overlap_timings)
     dist.barrier()
