@@ -86,8 +86,22 @@ class SISSStepper:
         self.overlap = bool(on)
         if exchange is not None:
             assert exchange in EXCHANGES
+            if exchange != "sharded" or on:
+                self._gather_optimizer_state()      # leaving the sharded update: every rank needs the whole m / v again
             self.exchange = exchange
         self.e.on_early_grads_final = self._early_allreduce if self.overlap else None
+
+    def _gather_optimizer_state(self):
+        """The sharded update advances AdamW's moments on this rank's parameter shard only.  Before a REPLICATED update
+        follows (another exchange mode, a checkpoint of the optimizer) the shards are all-gathered once, so that every
+        rank holds identical full moments again."""
+        if getattr(self, "_state_shard", None) is None:
+            return
+        from .dp import all_gather_params
+        lo, hi = self._state_shard
+        all_gather_params(self.opt.m, lo, hi, self.pg)
+        all_gather_params(self.opt.v, lo, hi, self.pg)
+        self._state_shard = None
 
     def autotune_overlap(self, step_fn, iters=3):
         """Measure, don't guess: the overlapped exchange shares the chip with the persistent one-block-per-CU GEMMs of
@@ -267,6 +281,7 @@ class SISSStepper:
             from .dp import all_gather_params, reduce_scatter_param_shards
             gx_s, ga_s, lo, hi = reduce_scatter_param_shards(g, self.pg)
             self.opt.launch_sharded(gx_s, ga_s, lo, hi, self.pg, **okw)
+            self._state_shard = (lo, hi)                        # m / v are current on [lo, hi) only
             all_gather_params(self.e.ps.flat, lo, hi, self.pg)
             self.e.refresh_weights(cast_shadow=True)
             return

@@ -114,6 +114,14 @@ def main():
         d5 = p5 - base
         cos = float((d5 * d2).sum() / (d5.norm() * d2.norm()))
         assert cos > 0.999, cos
+        # leaving the sharded mode gathers AdamW's moments (each rank advanced only its shard): a replicated step that
+        # follows must keep the replicas bit-identical
+        st5.set_overlap(False, "allreduce")
+        st5.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
+        for buf in (eng.ps.flat, st5.opt.m, st5.opt.v):
+            both = [torch.zeros_like(buf) for _ in range(world)]
+            dist.all_gather(both, buf.clone())
+            assert all(torch.equal(both[0], o) for o in both), "replicas diverged after switching from the sharded update"
     print("dp exchange timings", rank, st3.overlap_timings)
     dist.barrier()
     dist.destroy_process_group()
