@@ -73,6 +73,8 @@ SIGNATURES = {
     "siss_geglu_bwd": [P, P, P, L, L, I, P],
     "siss_head_split": [P, P, I, I, I, I, I, I, P],
     "siss_head_merge": [P, P, I, I, I, I, I, I, P],
+    "siss_flash_attn_fwd": [P, P, P, P, P, I, I, I, I, I, F],
+    "siss_flash_attn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F],
     "siss_softmax_rows_fwd": [P, P, L, I, I, I, P],
     "siss_quick_gelu": [P, P, L, P],
     "siss_softmax_rows_bwd": [P, P, P, L, L, I, I, F, P],

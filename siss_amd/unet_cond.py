@@ -33,6 +33,10 @@ class UNetCondEngine(UNetEngine):
     def __init__(self, cfg: UNet2DConditionConfig, device="cuda"):
         super().__init__(cfg, device)
         self.ctx = None
+        import os
+        # fused attention (csrc/flash_attn.hip) for the transformer blocks; SISS_FLASH_ATTN=0: batched GEMMs + row softmax
+        # with the S x S matrices in HBM (the round-1 form, kept as the A/B baseline)
+        self.flash = os.environ.get("SISS_FLASH_ATTN", "1") == "1"
 
     # ------------------------------------------------------------------ parameters
     def _declare_transformer(self, pre, ch):
@@ -169,15 +173,22 @@ class UNetCondEngine(UNetEngine):
         lib.call("siss_head_split", q, qh, B, Sq, Hh, D, Sqp, Dp)
         lib.call("siss_head_split", k, kh, B, Sk, Hh, D, Skp, Dp)
         lib.call("siss_head_split", v, vh, B, Sk, Hh, D, Skp, Dp)
-        vT = tb(".vT", (BH, Dp, Skp))
-        lib.call("siss_transpose_bf16", vh, vT, BH, Skp, Dp)
-        sc, p = tb(".sc", (BH, Sqp, Skp)), bb(".p", (BH, Sqp, Skp))
-        ops.gemm_nt(lib.ptr(qh), Dp, kh, lib.ptr(sc), Skp, Sqp, Skp, Dp, [0], [0], alpha=scale, batch=BH,
-                    stride_a=Sqp * Dp, stride_w=Skp * Dp, stride_c=Sqp * Skp)
-        lib.call("siss_softmax_rows_fwd", sc, p, BH * Sqp, Sk, Skp, 0)
         oh = bb(".oh", (BH, Sqp, Dp))                # kept: delta = rowsum(dO o O) in the backward
-        ops.gemm_nt(lib.ptr(p), Skp, vT, lib.ptr(oh), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
-                    stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
+        flash = self.flash and Dp in (64, 128, 192)
+        if flash:
+            # QK^T -> softmax -> .V in ONE kernel (csrc/flash_attn.hip): the S x S matrices never reach HBM; the base-2
+            # log-sum-exp is all the backward needs besides q, k, v, o
+            lse = bb(".lse", (BH, Sqp), torch.float32)
+            lib.call("siss_flash_attn_fwd", qh, kh, vh, oh, lse, BH, Sqp, Skp, Dp, Sk, float(scale))
+        else:
+            vT = tb(".vT", (BH, Dp, Skp))
+            lib.call("siss_transpose_bf16", vh, vT, BH, Skp, Dp)
+            sc, p = tb(".sc", (BH, Sqp, Skp)), bb(".p", (BH, Sqp, Skp))
+            ops.gemm_nt(lib.ptr(qh), Dp, kh, lib.ptr(sc), Skp, Sqp, Skp, Dp, [0], [0], alpha=scale, batch=BH,
+                        stride_a=Sqp * Dp, stride_w=Skp * Dp, stride_c=Sqp * Skp)
+            lib.call("siss_softmax_rows_fwd", sc, p, BH * Sqp, Sk, Skp, 0)
+            ops.gemm_nt(lib.ptr(p), Skp, vT, lib.ptr(oh), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
+                        stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
         o = bb(".o", (rq, C))
         lib.call("siss_head_merge", oh, o, B, Sq, Hh, D, Sqp, Dp)
         out = bb(".out", (rq, C))
@@ -194,34 +205,40 @@ class UNetCondEngine(UNetEngine):
             self._linear_bwd(dout, o, pre + ".to_out.0", rows2, rq, C, C, dx_out=do)
             doh = tb(".doh", (nBH, Sqp, Dp))
             lib.call("siss_head_split", do, doh, nb, Sq, Hh, D, Sqp, Dp)
-            ds = tb(".ds", (nBH, Sqp, Skp))
             delta = tb(".delta", (nBH * Sqp,), torch.float32)
             dqh = tb(".dqh", (nBH, Sqp, Dp))
-            dkf, dvf = tb(".dkf", (nBH, Skp, Dp), torch.float32), tb(".dvf", (nBH, Skp, Dp), torch.float32)
-            khT = tb(".khT", (BH, Dp, Skp))
-            lib.call("siss_transpose_bf16", kh, khT, BH, Skp, Dp)
-            i0, i1 = lib.int_array([0]), lib.int_array([0])
+            dkh, dvh = tb(".dkh", (nBH, Skp, Dp)), tb(".dvh", (nBH, Skp, Dp))
             # delta[q] = sum_k P[q][k] dP[q][k] = <dO[q], O[q]> : no pass over the S x S matrices needed for it
             lib.call("siss_rowdot", doh, oh, delta, nBH * Sqp, BH * Sqp, Dp)
-            for g in range(nb // B):             # cotangent groups that share the B forward samples
-                sl = slice(g * BH, (g + 1) * BH)
-                # dS = scale * P o (dO V^T - delta) straight from the product's epilogue: dP is never materialised
-                lib.call("siss_gemm_nt_mulsub", doh[sl], Dp, vh, ds[sl], Skp, p, Skp, delta[g * BH * Sqp:], Sqp, Skp, Dp,
-                         float(scale), BH, Sqp * Dp, Skp * Dp, Sqp * Skp)
-                # dV[key][d] = sum_q P[q][key] dO[q][d]
-                lib.call("siss_gemm_tn", p, Skp, doh[sl], Dp, dvf[sl], Skp * Dp, Skp, Dp, 1, i0, i1, BH, Sqp, Sqp,
-                         0, Sqp, -1, zp, None, None)     # -1: one split, dW overwritten (no zero fill)
-            for g in range(nb // B):
-                sl = slice(g * BH, (g + 1) * BH)
-                # dQ = dS K
-                ops.gemm_nt(lib.ptr(ds[sl]), Skp, khT, lib.ptr(dqh[sl]), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
-                            stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
-                # dK[key][d] = sum_q dS[q][key] Q[q][d]
-                lib.call("siss_gemm_tn", ds[sl], Skp, qh, Dp, dkf[sl], Skp * Dp, Skp, Dp, 1, i0, i1, BH, Sqp, Sqp,
-                         0, Sqp, -1, zp, None, None)     # -1: one split, dW overwritten (no zero fill)
-            dkh, dvh = tb(".dkh", (nBH, Skp, Dp)), tb(".dvh", (nBH, Skp, Dp))
-            lib.call("siss_cast_f32_bf16", dkf, dkh, dkf.numel())
-            lib.call("siss_cast_f32_bf16", dvf, dvh, dvf.numel())
+            if flash:
+                # FlashAttention-2 style: P is recomputed per tile from q, k and the saved log-sum-exp; all cotangent
+                # (batch, head) entries in one launch pair, entry z against forward entry z % BH
+                lib.call("siss_flash_attn_bwd", qh, kh, vh, doh, lse, delta, dqh, dkh, dvh, nBH, BH, Sqp, Skp, Dp, Sk,
+                         float(scale))
+            else:
+                ds = tb(".ds", (nBH, Sqp, Skp))
+                dkf, dvf = tb(".dkf", (nBH, Skp, Dp), torch.float32), tb(".dvf", (nBH, Skp, Dp), torch.float32)
+                khT = tb(".khT", (BH, Dp, Skp))
+                lib.call("siss_transpose_bf16", kh, khT, BH, Skp, Dp)
+                i0, i1 = lib.int_array([0]), lib.int_array([0])
+                for g in range(nb // B):             # cotangent groups that share the B forward samples
+                    sl = slice(g * BH, (g + 1) * BH)
+                    # dS = scale * P o (dO V^T - delta) straight from the product's epilogue: dP is never materialised
+                    lib.call("siss_gemm_nt_mulsub", doh[sl], Dp, vh, ds[sl], Skp, p, Skp, delta[g * BH * Sqp:], Sqp, Skp, Dp,
+                             float(scale), BH, Sqp * Dp, Skp * Dp, Sqp * Skp)
+                    # dV[key][d] = sum_q P[q][key] dO[q][d]
+                    lib.call("siss_gemm_tn", p, Skp, doh[sl], Dp, dvf[sl], Skp * Dp, Skp, Dp, 1, i0, i1, BH, Sqp, Sqp,
+                             0, Sqp, -1, zp, None, None)     # -1: one split, dW overwritten (no zero fill)
+                for g in range(nb // B):
+                    sl = slice(g * BH, (g + 1) * BH)
+                    # dQ = dS K
+                    ops.gemm_nt(lib.ptr(ds[sl]), Skp, khT, lib.ptr(dqh[sl]), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
+                                stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
+                    # dK[key][d] = sum_q dS[q][key] Q[q][d]
+                    lib.call("siss_gemm_tn", ds[sl], Skp, qh, Dp, dkf[sl], Skp * Dp, Skp, Dp, 1, i0, i1, BH, Sqp, Sqp,
+                             0, Sqp, -1, zp, None, None)     # -1: one split, dW overwritten (no zero fill)
+                lib.call("siss_cast_f32_bf16", dkf, dkh, dkf.numel())
+                lib.call("siss_cast_f32_bf16", dvf, dvh, dvf.numel())
             dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (nb * Sk, C)), tb(".dv", (nb * Sk, C))
             lib.call("siss_head_merge", dqh, dq, nb, Sq, Hh, D, Sqp, Dp)
             lib.call("siss_head_merge", dkh, dk, nb, Sk, Hh, D, Skp, Dp)

@@ -1,0 +1,107 @@
+"""Fused attention kernels (csrc/flash_attn.hip) against torch fp32 softmax(scale Q K^T) V and its autograd gradients on the
+same bf16-rounded operands -- the computation diffusers' BasicTransformerBlock attn1 / attn2 hands to
+scaled_dot_product_attention (reached from delete_sd.py:977-985 through losses/ddpm_deletion_loss.py:24, differentiated
+twice at delete_sd.py:1040-1060: here one dual-cotangent backward, 2 x BH cotangent entries against BH forward entries).
+
+Shapes: the SD-v1.5 head dims 40 / 80 / 160 (padded to 64 / 128 / 192), self-attention with ragged sequence lengths
+(padded queries AND padded keys), cross-attention onto 77 text tokens (masked keys in the second 64-key tile), several
+key / query tiles (online-softmax rescaling across tiles), large score ranges (max subtraction).
+Tolerances: O rel 1e-2 of scale (bf16 output, bf16 P operand), lse abs 2e-3, dQ / dK / dV rel 2e-2 of scale.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    from siss_amd import lib
+    lib.load()
+    return torch.device("cuda:0")
+
+
+def _up(n, m):
+    return -(-n // m) * m
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _close(got, ref, rel, what=""):
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g} (rel {err / scale:.3g} > {rel})"
+
+
+def _pad(x, Sp, Dp, dev):
+    BH, S, D = x.shape
+    out = torch.zeros(BH, Sp, Dp, dtype=torch.bfloat16, device=dev)
+    out[:, :S, :D] = x.to(torch.bfloat16).to(dev)
+    return out
+
+
+CASES = [  # BH, Sq, Sk, D, logit spread
+    (4, 256, 256, 40, 1.0), (2, 1024, 77, 40, 1.0), (4, 200, 200, 80, 1.0), (2, 64, 64, 160, 1.0),
+    (3, 320, 77, 160, 1.0), (2, 192, 448, 64, 6.0), (1, 4096, 4096, 40, 1.0),
+]
+
+
+@pytest.mark.parametrize("BH,Sq,Sk,D,spread", CASES)
+def test_flash_attention_forward_and_dual_backward(dev, BH, Sq, Sk, D, spread):
+    from siss_amd import lib
+    g = torch.Generator().manual_seed(BH * 1000 + Sq + Sk + D)
+    q = _bf(torch.randn(BH, Sq, D, generator=g) * spread)
+    k = _bf(torch.randn(BH, Sk, D, generator=g))
+    v = _bf(torch.randn(BH, Sk, D, generator=g))
+    sets = 2
+    do = _bf(torch.randn(sets * BH, Sq, D, generator=g))
+    scale = D ** -0.5
+    big = Sq * Sk > 4_000_000
+    rdev = dev if big else torch.device("cpu")                  # the 4096^2 case: fp32 reference on the GPU through torch
+    qr, kr, vr = (t.to(rdev).clone().requires_grad_(True) for t in (q, k, v))
+    s = (qr @ kr.transpose(1, 2)) * scale
+    p = torch.softmax(s, dim=-1)
+    o_ref = p @ vr
+    lse_ref = torch.logsumexp(s, dim=-1) / math.log(2.0)
+    grads = [torch.autograd.grad(o_ref, (qr, kr, vr), do[i * BH:(i + 1) * BH].to(rdev), retain_graph=True) for i in range(sets)]
+
+    Dp, Sqp, Skp = _up(D, 64), _up(Sq, 64), _up(Sk, 64)
+    qh, kh, vh = _pad(q, Sqp, Dp, dev), _pad(k, Skp, Dp, dev), _pad(v, Skp, Dp, dev)
+    oh = torch.full((BH, Sqp, Dp), 7.0, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(BH, Sqp, device=dev)
+    lib.call("siss_flash_attn_fwd", qh, kh, vh, oh, lse, BH, Sqp, Skp, Dp, Sk, float(scale))
+    torch.cuda.synchronize()
+    _close(oh[:, :Sq, :D].float().cpu(), o_ref.detach().cpu(), 1e-2, "O")
+    assert float(oh[:, :, D:].float().abs().max()) == 0.0, "padded head columns must stay zero"
+    assert (lse[:, :Sq].cpu() - lse_ref.detach().cpu()).abs().max() < 2e-3
+
+    doh = _pad(do, Sqp, Dp, dev)
+    delta = torch.zeros(sets * BH * Sqp, device=dev)
+    lib.call("siss_rowdot", doh, oh, delta, sets * BH * Sqp, BH * Sqp, Dp)
+    dq, dk, dv = (torch.full((sets * BH, n, Dp), 3.0, dtype=torch.bfloat16, device=dev) for n in (Sqp, Skp, Skp))
+    lib.call("siss_flash_attn_bwd", qh, kh, vh, doh, lse, delta, dq, dk, dv, sets * BH, BH, Sqp, Skp, Dp, Sk, float(scale))
+    torch.cuda.synchronize()
+    for i in range(sets):
+        sl = slice(i * BH, (i + 1) * BH)
+        _close(dq[sl, :Sq, :D].float().cpu(), grads[i][0].cpu(), 2e-2, f"dQ set {i}")
+        _close(dk[sl, :Sk, :D].float().cpu(), grads[i][1].cpu(), 2e-2, f"dK set {i}")
+        _close(dv[sl, :Sk, :D].float().cpu(), grads[i][2].cpu(), 2e-2, f"dV set {i}")
+    # padded keys take no gradient, padded head columns stay zero
+    if Skp > Sk:
+        assert float(dk[:, Sk:].float().abs().max()) == 0.0 and float(dv[:, Sk:].float().abs().max()) == 0.0
+    assert float(dq[:, :, D:].float().abs().max()) == 0.0 if Dp > D else True
+
+
+def test_flash_attention_rejects_unsupported_shapes(dev):
+    from siss_amd import lib
+    t = torch.zeros(1, 64, 256, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(64, device=dev)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("siss_flash_attn_fwd", t, t, t, t, lse, 1, 64, 64, 256, 64, 1.0)      # D_pad 256: not covered
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("siss_flash_attn_fwd", t, t, t, t, lse, 1, 60, 64, 64, 64, 1.0)       # Sq_pad not a multiple of 64
