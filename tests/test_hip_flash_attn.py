@@ -77,7 +77,8 @@ def test_flash_attention_forward_and_dual_backward(dev, BH, Sq, Sk, D, spread):
     lib.call("siss_flash_attn_fwd", qh, kh, vh, oh, lse, BH, Sqp, Skp, Dp, Sk, float(scale))
     torch.cuda.synchronize()
     _close(oh[:, :Sq, :D].float().cpu(), o_ref.detach().cpu(), 1e-2, "O")
-    assert float(oh[:, :, D:].float().abs().max()) == 0.0, "padded head columns must stay zero"
+    if Dp > D:
+        assert float(oh[:, :, D:].float().abs().max()) == 0.0, "padded head columns must stay zero"
     assert (lse[:, :Sq].cpu() - lse_ref.detach().cpu()).abs().max() < 2e-3
 
     doh = _pad(do, Sqp, Dp, dev)
@@ -94,7 +95,8 @@ def test_flash_attention_forward_and_dual_backward(dev, BH, Sq, Sk, D, spread):
     # padded keys take no gradient, padded head columns stay zero
     if Skp > Sk:
         assert float(dk[:, Sk:].float().abs().max()) == 0.0 and float(dv[:, Sk:].float().abs().max()) == 0.0
-    assert float(dq[:, :, D:].float().abs().max()) == 0.0 if Dp > D else True
+    if Dp > D:
+        assert float(dq[:, :, D:].float().abs().max()) == 0.0
 
 
 def test_flash_attention_rejects_unsupported_shapes(dev):
