@@ -46,15 +46,27 @@ template <int DP> struct FA {
     __device__ static __forceinline__ int off(int row, int chunk) { return row * RS + ((chunk ^ swz(row)) << 4); }
 };
 
-// Stage a [64][DP] tile (global row stride DP) into LDS; rows >= rows_valid... (all 64 rows exist: tensors are padded).
+// A [64][DP] tile (global row stride DP; the tensors are padded, all 64 rows exist) travels global -> registers -> LDS in two
+// halves, so that the loads of tile t+1 are in flight while tile t is being multiplied (one LDS buffer, register prefetch).
+template <int DP> struct TileRegs { u32x4_t v[FA<DP>::CH * kTQ / kThreadsFA]; };
 template <int DP>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, char* lds, int tid) {
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ g, TileRegs<DP>& r, int tid) {
     using F = FA<DP>;
 #pragma unroll
     for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i) {
         const int idx = i * kThreadsFA + tid;
         const int row = idx / F::CH, c = idx - row * F::CH;
-        *reinterpret_cast<u32x4_t*>(lds + F::off(row, c)) = *reinterpret_cast<const u32x4_t*>(g + (long)row * DP + c * 8);
+        r.v[i] = *reinterpret_cast<const u32x4_t*>(g + (long)row * DP + c * 8);
+    }
+}
+template <int DP>
+__device__ __forceinline__ void tile_store(const TileRegs<DP>& r, char* lds, int tid) {
+    using F = FA<DP>;
+#pragma unroll
+    for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i) {
+        const int idx = i * kThreadsFA + tid;
+        const int row = idx / F::CH, c = idx - row * F::CH;
+        *reinterpret_cast<u32x4_t*>(lds + F::off(row, c)) = r.v[i];
     }
 }
 
@@ -80,6 +92,7 @@ __device__ __forceinline__ bf16x8_t pack_pair(const f32x4_t& a, const f32x4_t& b
     const uint32_t w0 = pack_bf2(a[0], a[1]), w1 = pack_bf2(a[2], a[3]), w2 = pack_bf2(b[0], b[1]), w3 = pack_bf2(b[2], b[3]);
     return __builtin_bit_cast(bf16x8_t, u32x4_t{w0, w1, w2, w3});
 }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32: exp2(-inf) = 0, no denormal fix-up
 __device__ __forceinline__ float group_max(float v) {      // over the four 16-lane groups (same lane & 15)
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -115,11 +128,18 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
     float m = -INFINITY, l = 0.f;
     const bf16_t* kg = K + bh * Skp * DP;
     const bf16_t* vg = V + bh * Skp * DP;
+    TileRegs<DP> kr, vr;
+    tile_load<DP>(kg, kr, tid);
+    tile_load<DP>(vg, vr, tid);
     for (int k0 = 0; k0 < Skp; k0 += kTQ) {
         __syncthreads();                                        // the previous tile's readers are done
-        stage_tile<DP>(kg + (long)k0 * DP, ks_, tid);
-        stage_tile<DP>(vg + (long)k0 * DP, vs_, tid);
+        tile_store<DP>(kr, ks_, tid);
+        tile_store<DP>(vr, vs_, tid);
         __syncthreads();
+        if (k0 + kTQ < Skp) {                                   // next tile: in flight under this tile's products
+            tile_load<DP>(kg + (long)(k0 + kTQ) * DP, kr, tid);
+            tile_load<DP>(vg + (long)(k0 + kTQ) * DP, vr, tid);
+        }
         f32x4_t st[4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -139,12 +159,12 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
                 mx = fmaxf(mx, s);
             }
         const float m_new = fmaxf(m, group_max(mx));            // finite: every 64-key tile up to valid_k has a valid key... see launcher
-        const float alpha = exp2f(m - m_new);                   // m = -inf on the first tile: alpha = 0
+        const float alpha = fast_exp2(m - m_new);                   // m = -inf on the first tile: alpha = 0
         float ps = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float p = exp2f(st[sub][r] - m_new); st[sub][r] = p; ps += p; }
+            for (int r = 0; r < 4; ++r) { const float p = fast_exp2(st[sub][r] - m_new); st[sub][r] = p; ps += p; }
         l = l * alpha + group_sum(ps);
         m = m_new;
 #pragma unroll
@@ -197,11 +217,18 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
     for (int dt = 0; dt < F::DT; ++dt) dqt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bf16_t* kg = K + zf * Skp * DP;
     const bf16_t* vg = V + zf * Skp * DP;
+    TileRegs<DP> kr, vr;
+    tile_load<DP>(kg, kr, tid);
+    tile_load<DP>(vg, vr, tid);
     for (int k0 = 0; k0 < Skp; k0 += kTQ) {
         __syncthreads();
-        stage_tile<DP>(kg + (long)k0 * DP, ks_, tid);
-        stage_tile<DP>(vg + (long)k0 * DP, vs_, tid);
+        tile_store<DP>(kr, ks_, tid);
+        tile_store<DP>(vr, vs_, tid);
         __syncthreads();
+        if (k0 + kTQ < Skp) {
+            tile_load<DP>(kg + (long)(k0 + kTQ) * DP, kr, tid);
+            tile_load<DP>(vg + (long)(k0 + kTQ) * DP, vr, tid);
+        }
         f32x4_t st[4], dp[4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + sub * 16 + (lane >> 4) * 4 + r;
-                const float p = key < valid_k ? exp2f(st[sub][r] * scale_log2 - lse) : 0.f;
+                const float p = key < valid_k ? fast_exp2(st[sub][r] * scale_log2 - lse) : 0.f;
                 st[sub][r] = p * (dp[sub][r] - dl) * scale;
             }
 #pragma unroll
@@ -266,11 +293,18 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     const bf16_t* dog = dO + z * Sqp * DP;
     const float* lseg = LSE2 + zf * Sqp;
     const float* dlg = delta + z * Sqp;
+    TileRegs<DP> qr, dor;
+    tile_load<DP>(qg, qr, tid);
+    tile_load<DP>(dog, dor, tid);
     for (int q0 = 0; q0 < Sqp; q0 += kTQ) {
         __syncthreads();
-        stage_tile<DP>(qg + (long)q0 * DP, qs_, tid);
-        stage_tile<DP>(dog + (long)q0 * DP, dos_, tid);
+        tile_store<DP>(qr, qs_, tid);
+        tile_store<DP>(dor, dos_, tid);
         __syncthreads();
+        if (q0 + kTQ < Sqp) {
+            tile_load<DP>(qg + (long)(q0 + kTQ) * DP, qr, tid);
+            tile_load<DP>(dog + (long)(q0 + kTQ) * DP, dor, tid);
+        }
         f32x4_t s[4], dp[4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -289,7 +323,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
             const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(dlg + qb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = key_ok ? exp2f(s[sub][r] * scale_log2 - lse[r]) : 0.f;
+                const float p = key_ok ? fast_exp2(s[sub][r] * scale_log2 - lse[r]) : 0.f;
                 s[sub][r] = p;
                 ds[sub][r] = p * (dp[sub][r] - dl[r]) * scale;
             }
