@@ -868,7 +868,7 @@ int slab_slice(int H, int W, int C, int G, int N, SlabShape& s) {
         bool two = true;                                            // a lane's 8 channels: at most two adjacent groups
         for (int cc = 0; cc < lpp; ++cc) two = two && ((cc * 8 + 7) / cpg <= (cc * 8) / cpg + 1);
         if (!two) continue;
-        if (Cs < 32 && best) break;
+        if (Cs < 32) continue;                                      // 64-B row segments at least (measured: 48-B slices of a 768-channel site run 1.6x slower than the two-pass kernels)
         best = Cs;
         if ((long)(C / Cs) * N >= 128) break;                       // enough blocks: keep the widest such slice
     }
@@ -957,7 +957,9 @@ int siss_gn_slab_bwd(const void* dy, const void* x, const float* gamma, const fl
                      int set_images, long set_stride, int H, int W, int C, int G, int silu, int dy_compact, int ldx,
                      void* stream) {
     SlabShape s;
-    if (!slab_slice(H, W, C, G, nx, s)) return -1;
+    // backward: only up to 16 x 16 pixels (measured per site, B = 16: 8x8 38.8 -> 24.0 us, 16x16 40.9 -> 26.9 us, but 32x32
+    // 40.7 -> 45.7 us: three tensors of 1024 pixels per block leave one block per CU and a serial walk of 8 vectors per lane)
+    if (H * W > 256 || !slab_slice(H, W, C, G, nx, s)) return -1;
     if (ldx) s.ldx = ldx;
     BwdArgs a;
     a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
