@@ -65,11 +65,12 @@ struct TCfg {
     static constexpr int kSmemBytes = kStages * kStageBytes;
 };
 
+// The whole product of one block.  bid / nwg: the block's index and the block count of ITS launch -- or, in a grouped launch
+// (gemm_tn_grouped_kernel), of its job.
 template <int TAPS>
-__global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const TNParams p) {
+__device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nwg, char* smem) {
     using C_ = TCfg<TAPS>;
     constexpr int NP = C_::kPieces, CT = C_::kCT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = TAPS == 3 ? w >> 2 : w >> 1, wc = TAPS == 3 ? w & 3 : w & 1;   // wave tile 64(n) x (CT*16)(c)
@@ -79,8 +80,6 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
     // (measured before this remap: 5 % L2 hit rate, 9x the operand bytes from HBM).
     const int tiles_c = (p.C + BC - 1) / BC, tiles_n = (p.N + BN - 1) / BN;
     const int ngroups = p.npanels / TAPS;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
@@ -336,6 +335,34 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const 
 }
 
 template <int TAPS>
+__global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const TNParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn_body<TAPS>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Several independent products in ONE launch (the low-resolution weight gradients: each of them alone leaves most CUs idle
+// and pays a launch's fixed latency; together they fill the chip).  Job j owns blocks [first[j], first[j+1]); first[] are
+// multiples of 8 so that a job's blocks keep their XCD (block index mod 8) -- the surplus blocks of a job exit at once.
+constexpr int kMaxJobs = 14;
+struct TNGroup {
+    int njobs;
+    int first[kMaxJobs + 1];
+    int nwg[kMaxJobs];
+    TNParams job[kMaxJobs];
+};
+static_assert(sizeof(TNGroup) <= 4096, "kernel arguments are limited to 4 KiB");
+
+template <int TAPS>
+__global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_grouped_kernel(const TNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int j = 0;
+    while (j + 1 < g.njobs && (int)blockIdx.x >= g.first[j + 1]) ++j;
+    const int bid = blockIdx.x - g.first[j];
+    if (bid >= g.nwg[j]) return;
+    tn_body<TAPS>(g.job[j], bid, g.nwg[j], smem);
+}
+
+template <int TAPS>
 int launch_tn(const TNParams& p, hipStream_t st) {
     using C_ = TCfg<TAPS>;
     static unsigned char attr_set[kMaxDevices];
@@ -348,25 +375,24 @@ int launch_tn(const TNParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" {
+// argument list of siss_gemm_tn as a struct (include/siss_hip.h declares the same layout)
+struct siss_tn_job {
+    const void* Y; long ldy; const void* X; long ldx; float* dW; long set_stride;
+    int N, C, npanels, nsets, rows_per_set, row_begin, row_end, nsplits;
+    long x_set_rows;
+    const void* zero_page; float* dbias; float* dbias2;
+    int shifts[9]; int coffs[9];
+};
 
-// dW must be zeroed (or hold the running sum for gradient accumulation) before the call.
-// dbias / dbias2 (optional): dbias[set*set_stride + n] += sum over the set's rows of Y[r][n].
-// Rows [row_begin, row_end) of every set are reduced; shifts/coffs are HOST arrays.
-// nsplits == 0: choose the kernel variant and the split count here (cost model below); when that lands on one split
-// the block that owns a tile read-add-writes it with plain accesses instead of atomics.
-// nsplits == -1: one split per tile and dW is OVERWRITTEN with the product (no accumulation: the caller needs no zero
-// fill; attention dK / dV).
-int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
-                 int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
-                 long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
-                 float* dbias, float* dbias2, void* stream) {
+static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
+                    int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
+                    long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
+                    float* dbias, float* dbias2, bool grouped, TNParams& p, bool& fused3_out) {
     SISS_CHECK_ARG(Y && X && dW && shifts && coffs && zero_page);
     SISS_CHECK_ARG(N > 0 && C > 0 && npanels >= 1 && npanels <= kMaxPanels && nsets >= 1);
     SISS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && C % 8 == 0);   // N may be ragged (masked at the store)
     SISS_CHECK_ARG(((uintptr_t)Y | (uintptr_t)X | (uintptr_t)zero_page) % 16 == 0 && (uintptr_t)dW % 4 == 0);
     SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set);
-    TNParams p;
     p.Y = (const bf16_t*)Y; p.X = (const bf16_t*)X; p.dW = dW; p.zero_page = (const bf16_t*)zero_page;
     p.dbias = dbias; p.dbias2 = dbias ? dbias2 : nullptr;
     p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.x_set_rows = x_set_rows;
@@ -386,6 +412,12 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
     const bool overwrite = nsplits == -1;                  // one split per tile, dW = product (no read, no zero fill needed)
     if (overwrite) nsplits = 1;
     const bool automatic = nsplits <= 0;
+    if (grouped && nsplits <= 0) {
+        // a grouped launch fills the chip with OTHER jobs' blocks: no split for occupancy's sake; splits only bound a
+        // block's K loop (32 steps of 64 rows), and the fused 3-tap variant is always the better one (X read once)
+        nsplits = cdiv(rows, 32 * BR);
+        if (nsplits < 1) nsplits = 1;
+    }
     if (nsplits <= 0) {
         // Auto: pick (kernel variant, split count) by a small cost model (us), measured constants:
         //   a block's K-step (64 rows): 1.5 us for the 3-tap kernel (one 8-wave block per CU), 0.6 us for the
@@ -426,8 +458,78 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
     int rps = cdiv(rows, nsplits);
     rps = cdiv(rps, BR) * BR;
     p.rows_per_split = rps;
+    fused3_out = fused3;
+    return SISS_OK;
+}
+
+template <int TAPS>
+static int launch_tn_group(const TNParams* ps, int n, hipStream_t st) {
+    using C_ = TCfg<TAPS>;
+    static unsigned char attr_set[kMaxDevices];
+    if (siss_ensure_smem((const void*)gemm_tn_grouped_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    for (int i0 = 0; i0 < n; i0 += kMaxJobs) {
+        TNGroup g;
+        g.njobs = n - i0 < kMaxJobs ? n - i0 : kMaxJobs;
+        int total = 0;
+        for (int j = 0; j < g.njobs; ++j) {
+            const TNParams& p = ps[i0 + j];
+            g.job[j] = p;
+            g.first[j] = total;
+            g.nwg[j] = cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits;
+            total += (g.nwg[j] + 7) & ~7;
+            siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
+        }
+        g.first[g.njobs] = total;
+        gemm_tn_grouped_kernel<TAPS><<<dim3(total), C_::kThreads, C_::kSmemBytes, st>>>(g);
+    }
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+}
+
+extern "C" {
+
+// dW must be zeroed (or hold the running sum for gradient accumulation) before the call.
+// dbias / dbias2 (optional): dbias[set*set_stride + n] += sum over the set's rows of Y[r][n].
+// Rows [row_begin, row_end) of every set are reduced; shifts/coffs are HOST arrays.
+// nsplits == 0: choose the kernel variant and the split count here (cost model below); when that lands on one split
+// the block that owns a tile read-add-writes it with plain accesses instead of atomics.
+// nsplits == -1: one split per tile and dW is OVERWRITTEN with the product (no accumulation: the caller needs no zero
+// fill; attention dK / dV).
+int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
+                 int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
+                 long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
+                 float* dbias, float* dbias2, void* stream) {
+    TNParams p;
+    bool fused3 = false;
+    const int rc = tn_setup(Y, ldy, X, ldx, dW, set_stride, N, C, npanels, shifts, coffs, nsets, rows_per_set, x_set_rows,
+                            row_begin, row_end, nsplits, zero_page, dbias, dbias2, false, p, fused3);
+    if (rc != SISS_OK) return rc;
     if (fused3) return launch_tn<3>(p, (hipStream_t)stream);
     return launch_tn<1>(p, (hipStream_t)stream);
 }
+
+// The same product for `njobs` independent problems in ONE launch per kernel variant (job table passed by value as kernel
+// arguments: nothing is copied to the device, hipGraph-safe).  jobs: HOST array of siss_tn_job (the argument list of
+// siss_gemm_tn as a struct, shifts / coffs inline).  Meant for the low-resolution weight gradients: each of them alone leaves
+// most CUs idle and pays a launch's fixed latency.  All operands must stay valid until the launch has run.
+int siss_gemm_tn_grouped(const void* jobs, int njobs, void* stream) {
+    SISS_CHECK_ARG(jobs && njobs > 0 && njobs <= 256);
+    const siss_tn_job* js = (const siss_tn_job*)jobs;
+    TNParams p3[256], p1[256];
+    int n3 = 0, n1 = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const siss_tn_job& j = js[i];
+        TNParams p;
+        bool fused3 = false;
+        const int rc = tn_setup(j.Y, j.ldy, j.X, j.ldx, j.dW, j.set_stride, j.N, j.C, j.npanels, j.shifts, j.coffs, j.nsets,
+                                j.rows_per_set, j.x_set_rows, j.row_begin, j.row_end, j.nsplits, j.zero_page, j.dbias, j.dbias2,
+                                true, p, fused3);
+        if (rc != SISS_OK) return rc;
+        if (fused3) p3[n3++] = p; else p1[n1++] = p;
+    }
+    if (n3) { const int rc = launch_tn_group<3>(p3, n3, (hipStream_t)stream); if (rc != SISS_OK) return rc; }
+    if (n1) { const int rc = launch_tn_group<1>(p1, n1, (hipStream_t)stream); if (rc != SISS_OK) return rc; }
+    return SISS_OK;
+}
+
 
 }  // extern "C"

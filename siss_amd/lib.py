@@ -39,6 +39,7 @@ SIGNATURES = {
     "siss_gemm_nt_mulsub": [P, L, P, P, L, P, L, P, I, I, I, F, I, L, L, L, P],
     "siss_rowdot": [P, P, P, L, L, I, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
+    "siss_gemm_tn_grouped": [P, I],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_set_two_phase": [I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
@@ -100,6 +101,16 @@ def dispatch_counts(reset=False):
         lib.siss_dispatch_reset()
     return out
 
+
+
+class TNJob(C.Structure):
+    """siss_tn_job of include/siss_hip.h: one problem of siss_gemm_tn_grouped."""
+    _fields_ = [("Y", P), ("ldy", L), ("X", P), ("ldx", L), ("dW", P), ("set_stride", L),
+                ("N", I), ("C", I), ("npanels", I), ("nsets", I), ("rows_per_set", I), ("row_begin", I), ("row_end", I),
+                ("nsplits", I), ("x_set_rows", L), ("zero_page", P), ("dbias", P), ("dbias2", P),
+                ("shifts", I * 9), ("coffs", I * 9)]
+
+
 _lib = None
 
 
@@ -155,6 +166,7 @@ def int_array(xs):
     return (C.c_int * len(xs))(*xs)
 
 
+
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -179,6 +191,9 @@ def _work(name, a):
         if wp > 2 and rps % (wp * wp) == 0 and rows == rps - 2 * rb:
             rows = (rps // (wp * wp)) * (wp - 2) * (wp - 2)
         return 2.0 * a[6] * a[7] * a[8] * a[11] * rows
+    if name == "siss_gemm_tn_grouped":
+        return sum(_work("siss_gemm_tn", [None] * 6 + [j.N, j.C, j.npanels, None, None, j.nsets, j.rows_per_set, None,
+                                                       j.row_begin, j.row_end]) for j in a[0])
     if name == "siss_gemm_nt_mulsub":   # 2 * M * N * Kp * batch
         return 2.0 * a[8] * a[9] * a[10] * a[12]
     return 0.0
@@ -232,6 +247,8 @@ def kernel_symbol(name, a):
         return "gemm_nt_kernel"
     if name == "siss_gemm_nt_mulsub":
         return "gemm_nt_kernel"
+    if name == "siss_gemm_tn_grouped":
+        return "gemm_tn_grouped_kernel"
     if name == "siss_gemm_tn":
         rows = a[15] - a[14]
         return "gemm_tn_kernel<3>" if triples(a[9], a[10], a[8]) and (a[16] > 0 or rows >= 8192) else "gemm_tn_kernel<1>"
@@ -242,7 +259,8 @@ def call(name, *args):
     """Call a launcher on torch's current stream; tensors are passed as raw pointers."""
     lib = load()
     fn = getattr(lib, name)
-    conv = [ptr(a) if (torch.is_tensor(a) or a is None) else a for a in args]
+    conv = [ptr(a) if (torch.is_tensor(a) or a is None) else
+            (C.cast(a, C.c_void_p) if isinstance(a, C.Array) and a._type_ is not C.c_int else a) for a in args]   # job tables
     if PROF is not None:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

@@ -184,6 +184,14 @@ class UNetEngine:
         self.side_max_rows = int(os.environ.get("SISS_SIDE_MAX_ROWS", "0"))
         # convs that feed a concat write into the concat buffer directly (SISS_DIRECT_CAT=0: copy both parts)
         self.direct_cat = os.environ.get("SISS_DIRECT_CAT", "1") == "1"
+        # Weight gradients of the LOW-RESOLUTION layers (at most this many reduction rows per set: the 8x8 .. 32x32 levels) are
+        # not launched one by one -- each alone leaves most CUs idle and pays a launch's fixed ~10-40 us -- but queued and run
+        # as grouped launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).  They only feed the flat
+        # gradient buffer, so nothing waits for them; their cotangent operand is held back from the buffer pool until the
+        # group has run.  0 = off.
+        self.group_rows = int(os.environ.get("SISS_WGRAD_GROUP_ROWS", "20000"))
+        self.group_max = int(os.environ.get("SISS_WGRAD_GROUP_MAX", "42"))
+        self._wq, self._held, self._held_release = [], {}, []
 
     # ------------------------------------------------------------------ parameters
     def _early_blocks(self):
@@ -386,9 +394,22 @@ class UNetEngine:
     # -- side-stream bookkeeping: a buffer still being READ by a wgrad on the side stream carries the event
     #    that marks the end of that read; anyone about to overwrite it waits for the event first.
     def _wsync(self, a):
+        if a is not None and self._held and id(getattr(a, "base", a).buf) in self._held:
+            self._flush_wgrads()                          # about to be overwritten while a queued wgrad still reads it
         ev = _BUSY.pop(id(a.buf), None) if a is not None else None
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+
+    def _flush_wgrads(self):
+        """Run the queued weight-gradient products as grouped launches and give their operands back to the pool."""
+        if self._wq:
+            jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
+            lib.call("siss_gemm_tn_grouped", jobs, len(self._wq))
+            self._wq = []
+        self._held = {}
+        rel, self._held_release = self._held_release, []
+        for a in rel:
+            self._put(a)
 
     def _on_side(self, fn, reads, rows=0):
         if self.side is None or (self.side_max_rows and rows > self.side_max_rows):
@@ -406,6 +427,9 @@ class UNetEngine:
 
     def _put(self, a):
         if a is not None:
+            if self._held and id(a.buf) in self._held:   # still the operand of a queued wgrad: back to the pool after the flush
+                self._held_release.append(a)
+                return
             self._pool.setdefault((a.n, a.h, a.w, a.c), []).append(a)
 
     def _name(self, base):
@@ -454,14 +478,16 @@ class UNetEngine:
             accum / accum2: cotangents already known for x (added; accum is overwritten in place).
             split = (da, db, accumulate_b): x was concat(a, b) -- write the two halves straight into da / db."""
             nb = self.nb
-            if accum is not None:
+            # accum is normally overwritten in place; not while a queued (grouped) wgrad still reads it: fresh output then
+            held = accum is not None and self._held and id(accum.buf) in self._held
+            if accum is not None and not held:
                 self._wsync(accum)                      # written in place
             if split is not None:
                 da, db, accb = split
                 dx, dx2p, split_c = da, db.data, da.c
                 self._wsync(db)
             else:
-                dx = accum if accum is not None else self._get(nb, x.h, x.w, x.c)
+                dx = accum if (accum is not None and not held) else self._get(nb, x.h, x.w, x.c)
                 dx2p, split_c, accb = None, 0, False
             dyp = dy.data if isinstance(dy, Act) else dy
             lib.call("siss_groupnorm_bwd_ld", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
@@ -470,6 +496,8 @@ class UNetEngine:
                      ps.g(pre + ".weight", self.gbase), ps.g(pre + ".bias", self.gbase), colsum, colsum_ld,
                      self._gn_partial(nb, x.h, x.w, x.c), nb, x.n, self.set_images, ps.total,
                      x.h, x.w, x.c, G, int(silu), int(not isinstance(dy, Act)), 0 if ldx == x.c else ldx)
+            if held and split is None:
+                self._put(accum)                        # read only here: released once the queued wgrad has run
             return dx
         return y, bwd
 
@@ -531,6 +559,18 @@ class UNetEngine:
         ns = ops._nsplits(tiles, t, self.nsets, re - rb, ops.is_conv3_panels(shifts, coffs))
         sh, cf, zp = lib.int_array(shifts), lib.int_array(coffs), ops.zero_page(self.device)
         nsets = self.nsets
+        if self.group_rows and re - rb <= self.group_rows and self.side is None and isinstance(dy, Act):
+            job = lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
+                            dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
+                            rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=0, x_set_rows=x_set_rows,
+                            zero_page=zp.data_ptr(), dbias=dbias.data_ptr() if dbias is not None else None,
+                            dbias2=dbias2.data_ptr() if dbias2 is not None else None,
+                            shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t))))
+            self._wq.append((job, (dy, x)))
+            self._held[id(dy.buf)] = dy
+            if len(self._wq) >= self.group_max:
+                self._flush_wgrads()
+            return
         self._on_side(lambda: lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or getattr(x, "ld", x.c), dW_view, ps.total, co, ci, t,
                                        sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2),
                       reads=[dy, x], rows=re - rb)
@@ -841,6 +881,7 @@ class UNetEngine:
         N, cin, H, W = x.shape
         assert cin == cfg.in_channels
         self.tape, self.gmap, self._uid = [], {}, 0
+        self._wq, self._held, self._held_release = [], {}, []
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
@@ -976,12 +1017,14 @@ class UNetEngine:
         for idx in range(len(self.tape) - 1, -1, -1):
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
+                self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail
                 if self.side is not None:
                     # wgrads of the early-final parameters may still be running on the side stream: the collective
                     # the hook starts must see complete gradients (and later side-stream work must not race with it)
                     torch.cuda.current_stream().wait_stream(self.side)
                     _BUSY.clear()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
+        self._flush_wgrads()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)     # join: every wgrad has landed in ps.grads
             _BUSY.clear()
