@@ -226,14 +226,41 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     __builtin_amdgcn_s_barrier();
 
     if (p.ksplit > 1) {
-        // accumulator order, 16 B per lane: fully coalesced, read back the same way by the reduce kernel
-        float* dst = p.slab + ((long)(tm * tiles_n + tn) * p.ksplit + blockIdx.y) * (BM * BN);
+        // accumulator order, 16 B per lane: fully coalesced, read back the same way below
+        const int tile = tm * tiles_n + tn;
+        float* base = p.slab + (long)tile * p.ksplit * (BM * BN);
+        float* dst = base + (long)blockIdx.y * (BM * BN);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 *reinterpret_cast<f32x4_t*>(dst + ((i * MT + j) * C_::kThreads + tid) * 4) = acc[i][j];
-        return;
+        // The LAST block of the tile to arrive sums the ksplit partial tiles and runs the epilogue (no second launch: the
+        // separate reduce kernel cost ~10 us per small product, 48 launches per CelebA-HQ step).  The sum walks the
+        // splits in index order whoever is last, so the result is bitwise independent of the arrival order.
+        __shared__ int s_last;
+        __threadfence();                                       // this block's partial tile is visible device-wide
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(p.tile_ctr + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == p.ksplit - 1;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();                                       // the other blocks' partial tiles, too
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = *reinterpret_cast<const f32x4_t*>(base + ((i * MT + j) * C_::kThreads + tid) * 4);
+        for (int k = 1; k < p.ksplit; ++k) {
+            const float* src = base + (long)k * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + ((i * MT + j) * C_::kThreads + tid) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += v[r];
+                }
+        }
+        if (tid == 0) p.tile_ctr[tile] = 0;                    // as found: zero for the next launch
     }
     nt_epilogue<BM, C_::kThreads, MT>(p, acc, smem, m0, n0, bz, tid, wm, wn, frow, fq);
 }
@@ -278,7 +305,7 @@ int launch_nt(const NTParams& p, int batch, hipStream_t st) {
     siss_count_dispatch(p.ksplit > 1 ? SISS_K_NT_SPLITK : SISS_K_NT);
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.ksplit > 1 ? p.ksplit : 1, batch);
     gemm_nt_kernel<BM, NW, STAGES><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
-    if (p.ksplit > 1) {
+    if (p.ksplit > 1 && !p.tile_ctr) {                      // (kept for A/B: SISS_NT_FUSED_REDUCE=0)
         static unsigned char attr2[kMaxDevices];
         if (siss_ensure_smem((const void*)gemm_nt_reduce_kernel<BM, NW>, BM * kCRow, attr2) != SISS_OK) return SISS_ERR_LAUNCH;
         gemm_nt_reduce_kernel<BM, NW><<<grid.x, C_::kThreads, BM * kCRow, st>>>(p);
@@ -312,6 +339,7 @@ extern "C" {
 // Optional device workspace for the split-K path of siss_gemm_nt (small grids).  The library never allocates:
 // without a workspace (or with one that is too small for a launch) that path is simply not taken.  The buffer
 // is used by launches on ONE stream at a time (the partial tiles live from the product kernel to its reduce kernel).
+// It must be ZERO-filled by its owner once (its last 4 KiB hold the tiles' arrival counters, which every launch leaves zero).
 // The workspace belongs to the CURRENT device (hipGetDevice) -- a second device in the process gets its own.
 int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
     SISS_CHECK_ARG((ptr && bytes > 0 && (uintptr_t)ptr % 16 == 0) || (!ptr && bytes == 0));
@@ -369,12 +397,16 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
-    p.ksplit = 1; p.slab = nullptr;
+    p.ksplit = 1; p.slab = nullptr; p.tile_ctr = nullptr;
     p.rowsub = rowsub; p.mul_r = mul_r;
     SISS_CHECK_ARG(!mul_r || (R && Hp == 0));              // the multiplicative epilogue has no halo form
     const int dev_ = siss_current_device();
     float* const g_slab = dev_ >= 0 ? g_slab_dev[dev_] : nullptr;
-    const long g_slab_bytes = dev_ >= 0 ? g_slab_bytes_dev[dev_] : 0;
+    constexpr long kCtrBytes = 4096;                           // arrival counters of the split-K tiles live at the workspace's end
+    const long g_slab_bytes = dev_ >= 0 && g_slab_bytes_dev[dev_] > kCtrBytes ? g_slab_bytes_dev[dev_] - kCtrBytes : 0;
+    static int fused_reduce = -1;
+    if (fused_reduce < 0) { const char* e = getenv("SISS_NT_FUSED_REDUCE"); fused_reduce = e ? atoi(e) : 1; }
+    int* const g_ctr = (fused_reduce && g_slab_bytes > 0) ? reinterpret_cast<int*>(reinterpret_cast<char*>(g_slab) + g_slab_bytes) : nullptr;
     { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     SISS_CHECK_ARG((!rowbias && Hp == 0) || rows_per_image >= 64);   // <= 3 images per 128/256-row tile
     SISS_CHECK_ARG(N % 8 == 0 && (!rowbias || ldrb % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0));
@@ -431,7 +463,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
             if (S > 8) S = 8;
             if (S > steps / 6) S = steps / 6;
             if (S >= 2 && (long)tiles128 * S * 128 * BN * (long)sizeof(float) <= g_slab_bytes) {
-                p.ksplit = S; p.slab = g_slab;
+                p.ksplit = S; p.slab = g_slab; p.tile_ctr = g_ctr;
             }
         }
         // 129..256 tiles (the 16x16 layers): two double-buffered blocks per CU, each with half the K loop
@@ -439,7 +471,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
         if (split2 < 0) { const char* e = getenv("SISS_NT_SPLIT2"); split2 = e ? atoi(e) : 1; }
         if (splitk && split2 && batch == 1 && tiles128 > 128 && steps >= 24 && g_slab &&
             (long)tiles128 * 2 * 128 * BN * (long)sizeof(float) <= g_slab_bytes) {
-            p.ksplit = 2; p.slab = g_slab;
+            p.ksplit = 2; p.slab = g_slab; p.tile_ctr = g_ctr;
             return launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
         }
         return launch_nt<128, 4, 4>(p, batch, (hipStream_t)stream);

@@ -20,7 +20,8 @@ struct NTParams {
     const float* rowsub;              // optional f32 [batch][M]: subtracted from the accumulator row before alpha
     int mul_r;                        // 1: the epilogue MULTIPLIES by R instead of adding it  (C = R o (alpha (acc - rowsub)))
     int ksplit;                       // > 1: split-K -- gridDim.y blocks per tile write f32 partial tiles to `slab`
-    float* slab;                      //      ([tile][split][BM*BN] in accumulator order), gemm_nt_reduce_kernel finishes
+    float* slab;                      //      ([tile][split][BM*BN] in accumulator order); the LAST block of a tile to arrive
+    int* tile_ctr;                    //      (arrival counters, one per tile, zero between launches) sums them and runs the epilogue
     long long* dbg;                   // timing probe buffer (SISS_NT_DEBUG_PTR), normally null
     int shift[kMaxPanels];
     int coff[kMaxPanels];

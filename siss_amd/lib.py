@@ -145,7 +145,7 @@ def ensure_workspace(device):
     key = (device.type, index)
     if key not in _WORKSPACE:
         with torch.cuda.device(index):           # the library files the pointer under hipGetDevice()
-            buf = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=torch.device("cuda", index))
+            buf = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=torch.device("cuda", index))    # zero-filled once: arrival counters
             rc = load().siss_gemm_nt_set_workspace(C.c_void_p(buf.data_ptr()), WORKSPACE_BYTES)
         if rc != 0:
             raise RuntimeError(f"siss_gemm_nt_set_workspace failed with status {rc}")
