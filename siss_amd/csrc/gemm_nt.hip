@@ -235,9 +235,10 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 *reinterpret_cast<f32x4_t*>(dst + ((i * MT + j) * C_::kThreads + tid) * 4) = acc[i][j];
-        // The LAST block of the tile to arrive sums the ksplit partial tiles and runs the epilogue (no second launch: the
-        // separate reduce kernel cost ~10 us per small product, 48 launches per CelebA-HQ step).  The sum walks the
-        // splits in index order whoever is last, so the result is bitwise independent of the arrival order.
+        // Opt-in variant (SISS_NT_FUSED_REDUCE=1): the LAST block of the tile to arrive sums the ksplit partial tiles and runs
+        // the epilogue instead of a second launch.  The sum walks the splits in index order whoever is last, so the result
+        // is bitwise independent of the arrival order.  Measured slower than the reduce kernel (see gemm_nt_dispatch).
+        if (!p.tile_ctr) return;                               // SISS_NT_FUSED_REDUCE=0: gemm_nt_reduce_kernel finishes the tile
         __shared__ int s_last;
         __threadfence();                                       // this block's partial tile is visible device-wide
         __syncthreads();
@@ -405,7 +406,9 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     constexpr long kCtrBytes = 4096;                           // arrival counters of the split-K tiles live at the workspace's end
     const long g_slab_bytes = dev_ >= 0 && g_slab_bytes_dev[dev_] > kCtrBytes ? g_slab_bytes_dev[dev_] - kCtrBytes : 0;
     static int fused_reduce = -1;
-    if (fused_reduce < 0) { const char* e = getenv("SISS_NT_FUSED_REDUCE"); fused_reduce = e ? atoi(e) : 1; }
+    // opt-in: measured 2.3 ms per step SLOWER than the separate reduce launch (64.8 vs 62.5 ms, same box): the two device-scope
+    // fences around the arrival counter (L2 write-back + invalidate on every split block) cost more than 48 tiny launches
+    if (fused_reduce < 0) { const char* e = getenv("SISS_NT_FUSED_REDUCE"); fused_reduce = e ? atoi(e) : 0; }
     int* const g_ctr = (fused_reduce && g_slab_bytes > 0) ? reinterpret_cast<int*>(reinterpret_cast<char*>(g_slab) + g_slab_bytes) : nullptr;
     { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
     SISS_CHECK_ARG((!rowbias && Hp == 0) || rows_per_image >= 64);   // <= 3 images per 128/256-row tile
