@@ -191,6 +191,7 @@ class UNetEngine:
         # group has run.  0 = off.
         self.group_rows = int(os.environ.get("SISS_WGRAD_GROUP_ROWS", "20000"))
         self.group_max = int(os.environ.get("SISS_WGRAD_GROUP_MAX", "42"))
+        self.group_attn = self.group_rows and os.environ.get("SISS_WGRAD_GROUP_ATTN", "1") == "1"   # ... the attention blocks' linears too
         self._wq, self._held, self._held_release = [], {}, []
 
     # ------------------------------------------------------------------ parameters
@@ -710,7 +711,10 @@ class UNetEngine:
             rows2 = nb * S
             dout = self._take(out)
             tb = lambda s, shape, dt=torch.bfloat16: self._buf("attn" + s, shape, dt)
-            dy = tb(".dy", (rows2, C))
+            # the operands of this site's four weight-gradient products get buffers of their OWN (8 MB each at B = 16): the
+            # products are queued and run later in a grouped launch, when the shared scratch has long been reused
+            own = (lambda s, shape: self._buf(nm + ".bwd" + s, shape, torch.bfloat16)) if self.group_attn else tb
+            dy = own(".dy", (rows2, C))
             lib.call("siss_pad_to_compact", dout.data, dy, nb, x.h, x.w, C)
             zp = ops.zero_page(self.device)
 
@@ -718,15 +722,24 @@ class UNetEngine:
                 """dyt [rows2,C] cotangent of y = xin W^T + b (xin has B*S rows shared by the sets)."""
                 dW = ps.grads[gb:, ps.specs[wname + ".weight"].off:]
                 tiles = (-(-C // 128)) ** 2
-                lib.call("siss_gemm_tn", dyt, C, xin, C, dW, ps.total, C, C, 1, lib.int_array([0]),
-                         lib.int_array([0]), ns, si * S, si * S if B == nb else 0,
-                         0, si * S, ops._nsplits(tiles, 1, ns, si * S, False), zp, ps.g(wname + ".bias", gb), None)
+                if self.group_attn and self.side is None:
+                    z9 = (lib.I * 9)(*([0] * 9))
+                    self._wq.append((lib.TNJob(Y=dyt.data_ptr(), ldy=C, X=xin.data_ptr(), ldx=C, dW=dW.data_ptr(),
+                                               set_stride=ps.total, N=C, C=C, npanels=1, nsets=ns, rows_per_set=si * S,
+                                               row_begin=0, row_end=si * S, nsplits=0,
+                                               x_set_rows=si * S if B == nb else 0, zero_page=zp.data_ptr(),
+                                               dbias=ps.g(wname + ".bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
+                                     (dyt, xin)))
+                else:
+                    lib.call("siss_gemm_tn", dyt, C, xin, C, dW, ps.total, C, C, 1, lib.int_array([0]),
+                             lib.int_array([0]), ns, si * S, si * S if B == nb else 0,
+                             0, si * S, ops._nsplits(tiles, 1, ns, si * S, False), zp, ps.g(wname + ".bias", gb), None)
                 if dx_out is not None:
                     ops.gemm_nt(lib.ptr(dyt), C, self.wT[wname + ".weight"], lib.ptr(dx_out), C, rows2, C, C,
                                 [0], [0], res_ptr=lib.ptr(dx_out) if accumulate else None, ldr=C)
             do = tb(".do", (rows2, C))
             lin_bwd(dy, o, pre + ".to_out.0", do, False)
-            dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (rows2, C)), tb(".dv", (rows2, C))
+            dq, dk, dv = own(".dq", (rows2, C)), own(".dk", (rows2, C)), own(".dv", (rows2, C))
             if small:
                 lib.call("siss_mha_small_bwd", q, k, v, o, lse, do, dq, dk, dv, nb, B, S, C, D, float(scale))
             else:
