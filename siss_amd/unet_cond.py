@@ -133,10 +133,22 @@ class UNetCondEngine(UNetEngine):
         rps = rows2 // ns
         dW = ps.grads[gb:, ps.specs[wname + ".weight"].off:]
         tiles = (-(-n_out // 128)) * (-(-k_in // 128))
-        lib.call("siss_gemm_tn", dy, n_out, xin, k_in, dW, ps.total, n_out, k_in, 1, lib.int_array([0]),
-                 lib.int_array([0]), ns, rps, rps if rows_x == rows2 else 0, 0, rps,
-                 ops._nsplits(tiles, 1, ns, rps, False), ops.zero_page(self.device),
-                 ps.g(wname + ".bias", gb) if bias else None, None)
+        zp = ops.zero_page(self.device)
+        if self.group_attn and self.side is None:
+            # queued for a grouped launch (UNetEngine._flush_wgrads): dy lives in a per-site buffer (see transformer())
+            z9 = (lib.I * 9)(*([0] * 9))
+            self._wq.append((lib.TNJob(Y=dy.data_ptr(), ldy=n_out, X=xin.data_ptr(), ldx=k_in, dW=dW.data_ptr(),
+                                       set_stride=ps.total, N=n_out, C=k_in, npanels=1, nsets=ns, rows_per_set=rps,
+                                       row_begin=0, row_end=rps, nsplits=0, x_set_rows=rps if rows_x == rows2 else 0,
+                                       zero_page=zp.data_ptr(),
+                                       dbias=ps.g(wname + ".bias", gb).data_ptr() if bias else None, dbias2=None,
+                                       shifts=z9, coffs=z9), (dy, xin)))
+            if len(self._wq) >= self.group_max:
+                self._flush_wgrads()
+        else:
+            lib.call("siss_gemm_tn", dy, n_out, xin, k_in, dW, ps.total, n_out, k_in, 1, lib.int_array([0]),
+                     lib.int_array([0]), ns, rps, rps if rows_x == rows2 else 0, 0, rps,
+                     ops._nsplits(tiles, 1, ns, rps, False), zp, ps.g(wname + ".bias", gb) if bias else None, None)
         if dx_out is not None:
             ops.gemm_nt(lib.ptr(dy), n_out, self.wT[wname + ".weight"], lib.ptr(dx_out), k_in, rows2, k_in, n_out,
                         [0], [0], res_ptr=lib.ptr(dx_out) if accumulate else None, ldr=k_in)
@@ -163,7 +175,10 @@ class UNetCondEngine(UNetEngine):
         BH = B * Hh
         scale = D ** -0.5
         bb = lambda s, shape, dt=torch.bfloat16: self._buf(nm + s, shape, dt)      # saved for the backward
-        tb = lambda s, shape, dt=torch.bfloat16: self._buf("tfm" + s, shape, dt)   # scratch shared by all sites
+        # scratch shared by all sites -- or, when the weight-gradient products are queued for grouped launches, per site
+        # (a queued product reads its cotangent operand long after the next site would have reused the buffer)
+        tb = lambda s, shape, dt=torch.bfloat16: self._buf((nm if self.group_attn else "tfm") + ".scr" + s, shape, dt)
+        sb = lambda s, shape, dt=torch.bfloat16: self._buf("tfm" + s, shape, dt)   # always shared: the S x S matrices of the materialised path
         rq, rk = B * Sq, B * Sk
         q, k, v = tb(".q", (rq, C)), tb(".k", (rk, C)), tb(".v", (rk, C))
         self._linear(xq, pre + ".to_q", q, rq, C, C, bias=False)
@@ -181,9 +196,9 @@ class UNetCondEngine(UNetEngine):
             lse = bb(".lse", (BH, Sqp), torch.float32)
             lib.call("siss_flash_attn_fwd", qh, kh, vh, oh, lse, BH, Sqp, Skp, Dp, Sk, float(scale))
         else:
-            vT = tb(".vT", (BH, Dp, Skp))
+            vT = sb(".vT", (BH, Dp, Skp))
             lib.call("siss_transpose_bf16", vh, vT, BH, Skp, Dp)
-            sc, p = tb(".sc", (BH, Sqp, Skp)), bb(".p", (BH, Sqp, Skp))
+            sc, p = sb(".sc", (BH, Sqp, Skp)), bb(".p", (BH, Sqp, Skp))
             ops.gemm_nt(lib.ptr(qh), Dp, kh, lib.ptr(sc), Skp, Sqp, Skp, Dp, [0], [0], alpha=scale, batch=BH,
                         stride_a=Sqp * Dp, stride_w=Skp * Dp, stride_c=Sqp * Skp)
             lib.call("siss_softmax_rows_fwd", sc, p, BH * Sqp, Sk, Skp, 0)
@@ -216,9 +231,9 @@ class UNetCondEngine(UNetEngine):
                 lib.call("siss_flash_attn_bwd", qh, kh, vh, doh, lse, delta, dqh, dkh, dvh, nBH, BH, Sqp, Skp, Dp, Sk,
                          float(scale))
             else:
-                ds = tb(".ds", (nBH, Sqp, Skp))
-                dkf, dvf = tb(".dkf", (nBH, Skp, Dp), torch.float32), tb(".dvf", (nBH, Skp, Dp), torch.float32)
-                khT = tb(".khT", (BH, Dp, Skp))
+                ds = sb(".ds", (nBH, Sqp, Skp))
+                dkf, dvf = sb(".dkf", (nBH, Skp, Dp), torch.float32), sb(".dvf", (nBH, Skp, Dp), torch.float32)
+                khT = sb(".khT", (BH, Dp, Skp))
                 lib.call("siss_transpose_bf16", kh, khT, BH, Skp, Dp)
                 i0, i1 = lib.int_array([0]), lib.int_array([0])
                 for g in range(nb // B):             # cotangent groups that share the B forward samples
@@ -281,7 +296,7 @@ class UNetCondEngine(UNetEngine):
             nb = self.nb
             rows2 = nb * S
             dout = self._take(out)
-            tb = lambda s, shape, dt=torch.bfloat16: self._buf("tfm" + s, shape, dt)
+            tb = lambda s, shape, dt=torch.bfloat16: self._buf((nm if self.group_attn else "tfm") + ".scr" + s, shape, dt)
             dy = tb(".dy", (rows2, C))
             lib.call("siss_pad_to_compact", dout.data, dy, nb, x.h, x.w, C)
             dx3 = tb(".dx3", (rows2, C))
