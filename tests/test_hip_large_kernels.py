@@ -217,3 +217,47 @@ def test_full_size_forward_and_dual_backward_match_the_fp32_oracle(dev, B):
         del grads
     print(f"\nfull-size parity: pred rel err {err / scale:.3g}; worst per-tensor gradient cosine {worst[0]:.5f} at {worst[1]}")
     assert not bad, (len(bad), bad[:12])
+
+
+def test_grouped_weight_gradient_launch_equals_single_launches(dev):
+    """siss_gemm_tn_grouped: a mixed job table (3x3 filters on two resolutions -> the fused 3-tap variant, a linear and a
+    1x1 conv -> the one-tap variant; one and two cotangent sets; bias gradients) in ONE call against the same products
+    launched one by one with siss_gemm_tn.  Both accumulate through f32 atomics / plain adds: equal to f32 rounding."""
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act, conv3x3_panels
+    g = torch.Generator().manual_seed(17)
+    zp = ops.zero_page(dev)
+    jobs, singles, outs = [], [], []
+    for (n, hw, ci, co, nsets, ksize) in ((2, 16, 128, 256, 2, 3), (4, 8, 512, 512, 2, 3), (2, 32, 256, 128, 1, 3), (2, 16, 384, 128, 2, 1)):
+        x = Act.from_nchw(_bf(torch.randn(n, ci, hw, hw, generator=g)), dev)
+        dy = Act.from_nchw(_bf(torch.randn(nsets * n, co, hw, hw, generator=g)), dev)
+        shifts, coffs = conv3x3_panels(dy.wp, ci) if ksize == 3 else ([0], [0])
+        t = len(shifts)
+        rps = n * dy.rows_per_image
+        rb, re = dy.wp + 1, rps - (dy.wp + 1)
+        pair = []
+        for which in range(2):
+            dW = torch.zeros(nsets, t * co * ci + co, device=dev)          # [dW | dbias] per set, set stride = row length
+            pair.append(dW)
+            args = dict(Y=dy.data.data_ptr(), ldy=co, X=x.data.data_ptr(), ldx=ci, dW=dW.data_ptr(), set_stride=dW.shape[1],
+                        N=co, C=ci, npanels=t, nsets=nsets, rows_per_set=rps, row_begin=rb, row_end=re, nsplits=0, x_set_rows=0,
+                        zero_page=zp.data_ptr(), dbias=dW[0, t * co * ci:].data_ptr(), dbias2=None,
+                        shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t))))
+            if which == 0:
+                jobs.append((lib.TNJob(**args), (x, dy, dW)))
+            else:
+                singles.append((dy, x, dW, co, ci, t, shifts, coffs, nsets, rps, rb, re))
+        outs.append(pair)
+    lib.dispatch_counts(reset=True)
+    arr = (lib.TNJob * len(jobs))(*[j for j, _ in jobs])
+    lib.call("siss_gemm_tn_grouped", arr, len(jobs))
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    assert cnt["gemm_tn_kernel<3>"] == 3 and cnt["gemm_tn_kernel<1>"] == 1, cnt
+    for (dy, x, dW, co, ci, t, shifts, coffs, nsets, rps, rb, re) in singles:
+        lib.call("siss_gemm_tn", dy.data, co, x.data, ci, dW, dW.shape[1], co, ci, t, lib.int_array(shifts), lib.int_array(coffs),
+                 nsets, rps, 0, rb, re, 0, zp, dW[0, t * co * ci:], None)
+    torch.cuda.synchronize()
+    for grouped, single in outs:
+        assert float(single.abs().max()) > 0
+        _close(grouped.cpu(), single.cpu(), 1e-5, "grouped vs single")
