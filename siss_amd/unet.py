@@ -739,7 +739,8 @@ class UNetEngine:
                                 [0], [0], res_ptr=lib.ptr(dx_out) if accumulate else None, ldr=C)
             do = tb(".do", (rows2, C))
             lin_bwd(dy, o, pre + ".to_out.0", do, False)
-            dq, dk, dv = own(".dq", (rows2, C)), own(".dk", (rows2, C)), own(".dv", (rows2, C))
+            dqkv = own(".dqkv", (3, rows2, C))        # one buffer: the three projections' dgrads run as ONE three-panel product
+            dq, dk, dv = dqkv[0], dqkv[1], dqkv[2]
             if small:
                 lib.call("siss_mha_small_bwd", q, k, v, o, lse, do, dq, dk, dv, nb, B, S, C, D, float(scale))
             else:
@@ -770,9 +771,14 @@ class UNetEngine:
                 lib.call("siss_cast_f32_bf16", dkf, dk, dkf.numel())
                 lib.call("siss_cast_f32_bf16", dvf, dv, dvf.numel())
             dhn = tb(".dhn", (rows2, C))
-            lin_bwd(dq, hn, pre + ".to_q", dhn, False)
-            lin_bwd(dk, hn, pre + ".to_k", dhn, True)
-            lin_bwd(dv, hn, pre + ".to_v", dhn, True)
+            lin_bwd(dq, hn, pre + ".to_q", None, False)
+            lin_bwd(dk, hn, pre + ".to_k", None, False)
+            lin_bwd(dv, hn, pre + ".to_v", None, False)
+            # dhn = dq Wq + dk Wk + dv Wv: three panels of one product -- panel p reads rows [p * rows2, (p + 1) * rows2) of the
+            # stacked cotangents (row shift) against the p-th of the three consecutive transposed weight copies
+            wq, wk, wv = (self.wT[pre + n + ".weight"] for n in (".to_q", ".to_k", ".to_v"))
+            assert wk.data_ptr() == wq.data_ptr() + 2 * C * C and wv.data_ptr() == wk.data_ptr() + 2 * C * C
+            ops.gemm_nt(lib.ptr(dqkv), C, wq, lib.ptr(dhn), C, rows2, C, C, [0, rows2, 2 * rows2], [0, 0, 0])
             dx = gn_b(dhn, accum=dout)        # residual path: d_out passes straight through
             self._give(x, dx)
         self.tape.append(bwd)
