@@ -53,7 +53,7 @@ __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >>
 //           by one, so the X tile is staged once with two extra rows and read at row offsets 0/1/2, and
 //           the Y tile is staged once for three products -- a third of the DMA instructions, HBM/L2 bytes
 //           and barriers per MFMA, and two thirds of the LDS reads.
-template <int TAPS>
+template <int TAPS, bool ILV = false>
 struct TCfg {
     static constexpr int kWaves = TAPS == 3 ? 8 : 4;              // 3 taps: 8 waves of 64(n) x 32(c) keep 96 acc VGPRs
     static constexpr int kThreads = kWaves * 64;
@@ -61,15 +61,15 @@ struct TCfg {
     static constexpr int kPieces = 16 / kWaves;                   // 4-row DMA pieces per wave and operand
     static constexpr int kXRows = BR + (TAPS == 3 ? 4 : 0);       // 64 (+ one extra 4-row DMA piece)
     static constexpr int kStageBytes = kYTile + kXRows * 256;
-    static constexpr int kStages = TAPS == 3 ? 3 : 2;            // 3 taps: one block per CU -> room for a 3-deep ring
+    static constexpr int kStages = TAPS == 3 ? (ILV ? 4 : 3) : 2; // 3 taps: one block per CU -> room for a 3-deep ring (4 in the interleaved variant)
     static constexpr int kSmemBytes = kStages * kStageBytes;
 };
 
 // The whole product of one block.  bid / nwg: the block's index and the block count of ITS launch -- or, in a grouped launch
 // (gemm_tn_grouped_kernel), of its job.
-template <int TAPS>
+template <int TAPS, bool ILV = false>
 __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nwg, char* smem) {
-    using C_ = TCfg<TAPS>;
+    using C_ = TCfg<TAPS, ILV>;
     constexpr int NP = C_::kPieces, CT = C_::kCT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,10 +212,74 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
         bf16x8_t yf[2][4], xf[2][TAPS][CT];
         stage(0, 0);
         if (steps > 1) stage(1, 1);
+        if (ILV && steps > 2) stage(2, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         load_frags(yf[0], xf[0], smem, 0);
         int buf = 0;
+        if constexpr (ILV) {
+            // Interleaved variant: the 20 transposed reads of the NEXT half-step are issued one per MFMA under the 24
+            // MFMAs of this half-step (sched_group_barrier pipeline), in the order the next half-step consumes them, instead
+            // of as one burst between two MFMA bursts -- the two waves of a SIMD are phase-locked by the step barrier, so a
+            // burst of reads leaves the matrix pipe idle in BOTH of them.
+            // One half-step: 24 MFMAs (taps 2, 1, 0) with ONE transposed read of the next half-step's fragments issued
+            // behind each of the first 20, pinned by a scheduling fence per pair.  Read order = consumption order (Y
+            // fragments, then taps 2, 1, 0), so the counted LDS wait in front of the next half-step's first MFMA leaves the
+            // younger reads in flight.  Past the last step the reads fetch a stale buffer: harmless, never used.
+            auto half = [&](bf16x8_t (&yc)[4], bf16x8_t (&xc)[TAPS][CT], bf16x8_t (&yn)[4], bf16x8_t (&xn)[TAPS][CT],
+                            const char* sbn, int kkn) {
+                s16x4_t r[20];
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yc[i], ones, bacc[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < 24; ++m) {
+                    const int t = 2 - m / 8, i = (m % 8) / CT, j = m % CT;
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yc[i], xc[t][j], acc[t][i][j], 0, 0, 0);
+                    if (m < 20) {
+                        if (m < 8) {
+                            r[m] = tr_read(sbn + ((y_off[m & 1] ^ ((m >> 1) << 5)) + kkn * 8192));
+                        } else {
+                            const int q = m - 8, tt = 2 - q / 4, ii = (q % 4) >> 1, h = q & 1;
+                            r[m] = tr_read(sbn + ((x_off[tt][h] ^ (ii << 5)) + kkn * 8192));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    yn[i] = bf16x8_t{r[2 * i][0], r[2 * i][1], r[2 * i][2], r[2 * i][3], r[2 * i + 1][0], r[2 * i + 1][1], r[2 * i + 1][2], r[2 * i + 1][3]};
+#pragma unroll
+                for (int q = 0; q < 12; q += 2) {
+                    const int tt = 2 - q / 4, ii = (q % 4) >> 1;
+                    xn[tt][ii] = bf16x8_t{r[8 + q][0], r[8 + q][1], r[8 + q][2], r[8 + q][3], r[9 + q][0], r[9 + q][1], r[9 + q][2], r[9 + q][3]};
+                }
+            };
+            // Ring of FOUR stages here: stage s+3 is issued during step s and only has to have landed at the bottom of step
+            // s+1, so the wait at the bottom of a step is COUNTED (this step's own DMA stays in flight).  The two waves of a
+            // SIMD (w and w + 4) issue their DMA half a step apart: a DMA piece costs 60-180 issue cycles during which the
+            // issuing wave feeds no MFMAs -- staggered, the SIMD's other wave keeps the matrix pipe busy meanwhile.
+            const bool early = w < 4;
+            for (int s = 0; s < steps; ++s) {
+                const int b1 = (buf + 1) & 3, b3 = (buf + 3) & 3;
+                const bool more = s + 3 < steps;
+                if (more && early) stage(b3, s + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                half(yf[0], xf[0], yf[1], xf[1], smem + buf * SB, 1);
+                if (more && !early) stage(b3, s + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                half(yf[1], xf[1], yf[0], xf[0], smem + b1 * SB, 0);
+                if (more) {
+                    if (w == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP + 1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                buf = b1;
+            }
+        } else
         for (int s = 0; s < steps; ++s) {
             const int b1 = buf + 1 == 3 ? 0 : buf + 1, b2 = b1 + 1 == 3 ? 0 : b1 + 1;
             if (s + 2 < steps) stage(b2, s + 2);
@@ -334,10 +398,10 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
     }
 }
 
-template <int TAPS>
+template <int TAPS, bool ILV = false>
 __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const TNParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tn_body<TAPS>(p, blockIdx.x, gridDim.x, smem);
+    tn_body<TAPS, ILV>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // Several independent products in ONE launch (the low-resolution weight gradients: each of them alone leaves most CUs idle
@@ -365,10 +429,18 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_grouped_kerne
 template <int TAPS>
 int launch_tn(const TNParams& p, hipStream_t st) {
     using C_ = TCfg<TAPS>;
-    static unsigned char attr_set[kMaxDevices];
-    if (siss_ensure_smem((const void*)gemm_tn_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    static unsigned char attr_set[kMaxDevices], attr_ilv[kMaxDevices];
     siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
     dim3 grid(cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits);
+    static int ilv = -1;
+    if (ilv < 0) { const char* e = getenv("SISS_TN_INTERLEAVE"); ilv = e ? atoi(e) : 0; }
+    if (TAPS == 3 && ilv) {
+        constexpr int smem_ilv = TCfg<3, true>::kSmemBytes;
+        if (siss_ensure_smem((const void*)gemm_tn_kernel<3, true>, smem_ilv, attr_ilv) != SISS_OK) return SISS_ERR_LAUNCH;
+        gemm_tn_kernel<3, true><<<grid, C_::kThreads, smem_ilv, st>>>(p);
+        return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+    }
+    if (siss_ensure_smem((const void*)gemm_tn_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
     gemm_tn_kernel<TAPS><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
