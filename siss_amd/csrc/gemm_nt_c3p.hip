@@ -44,6 +44,7 @@ struct TileMap {
     __device__ __forceinline__ int tile(int k) const { return k * nb + b_lo * per + b_hi; }   // XCD-contiguous
 };
 
+template <bool ILV>
 __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -228,6 +229,32 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             if (p.ablate & 4) continue;
             ldW(wf[0], 0, 0);
             ldA(af[0], 0, 0, 0);
+            if constexpr (ILV) {
+                // Interleaved variant: the (4 or 8) fragment reads of block b+1 are issued ONE behind each of the first MFMAs
+                // of block b instead of as a burst in front of them -- a consumer wave is alone on its SIMD as far as MFMAs
+                // go, so every cycle it spends issuing a burst of reads is a cycle the matrix pipe drains.
+#pragma unroll
+                for (int b = 0; b < 12; ++b) {
+                    const int h = b & 1;
+                    const int nb = b + 1, nt = nb >> 2, nkk = (nb >> 1) & 1, nh = nb & 1;
+                    const bool more = b + 1 < 12;
+                    const int nreads = more ? (nh == 0 ? 8 : 4) : 0;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const int i = m >> 2, jj = m & 3;
+                        acc[i][h * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(b >> 1) & 1][i], af[b & 1][jj],
+                                                                                     acc[i][h * 4 + jj], 0, 0, 0);
+                        if (m < nreads) {
+                            if (m < 4)
+                                af[nb & 1][m] = *reinterpret_cast<const bf16x8_t*>(sl + (a_base[nt] ^ (nkk << 6)) + (nh * 4 + m) * 2048);
+                            else
+                                wf[(nb >> 1) & 1][m - 4] = *reinterpret_cast<const bf16x8_t*>(sl + (w_base ^ (nkk << 6)) + nt * P_WBYTES + (m - 4) * 2048);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                continue;
+            }
             // 12 blocks of 16 MFMAs: block b = (tap t, k-half kk, m-half h); the fragments of block b+1 are read
             // before block b's MFMAs (counted lgkmcnt leaves them in flight).  Block 0 runs one MFMA row first:
             // the wait in front of it is lgkmcnt(0) and must not cover fresh reads.
@@ -317,8 +344,11 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
 // N % 128 == 0, batch == 1, rows_per_image >= 256.
 int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     const NTParams& p = *reinterpret_cast<const NTParams*>(params);
-    static unsigned char attr_set[kMaxDevices];
-    if (siss_ensure_smem((const void*)gemm_nt_c3p_kernel, P_SMEM, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    static unsigned char attr_set[kMaxDevices], attr_ilv[kMaxDevices];
+    static int ilv = -1;
+    if (ilv < 0) { const char* e = getenv("SISS_NT_C3P_ILV"); ilv = e ? atoi(e) : 1; }   // measured +2.6 % (1064 -> 1092 TF/s over the 98 launches of a step)
+    if (siss_ensure_smem(ilv ? (const void*)gemm_nt_c3p_kernel<true> : (const void*)gemm_nt_c3p_kernel<false>, P_SMEM,
+                         ilv ? attr_ilv : attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
     siss_count_dispatch(SISS_K_NT_C3P);
     // Grid = the FEWEST blocks (a multiple of 8: XCD runs) that finish in the same number of tile rounds as the full
     // chip: 550 tiles are 3 rounds on 256 CUs (38 CUs with three tiles, 218 with two) and exactly 3 on 184 -- the idle
@@ -330,6 +360,7 @@ int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     nb = (nb + 7) & ~7;
     if (nb > maxb) nb = maxb;
     if (nb < 8) nb = 8;
-    gemm_nt_c3p_kernel<<<dim3(nb), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
+    if (ilv) gemm_nt_c3p_kernel<true><<<dim3(nb), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
+    else gemm_nt_c3p_kernel<false><<<dim3(nb), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }

@@ -433,7 +433,7 @@ int launch_tn(const TNParams& p, hipStream_t st) {
     siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
     dim3 grid(cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits);
     static int ilv = -1;
-    if (ilv < 0) { const char* e = getenv("SISS_TN_INTERLEAVE"); ilv = e ? atoi(e) : 0; }
+    if (ilv < 0) { const char* e = getenv("SISS_TN_INTERLEAVE"); ilv = e ? atoi(e) : 1; }   // measured +5 % (996 -> 1044, 1057 -> 1112 TF/s)
     if (TAPS == 3 && ilv) {
         constexpr int smem_ilv = TCfg<3, true>::kSmemBytes;
         if (siss_ensure_smem((const void*)gemm_tn_kernel<3, true>, smem_ilv, attr_ilv) != SISS_OK) return SISS_ERR_LAUNCH;
