@@ -423,7 +423,7 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_grouped_kerne
     while (j + 1 < g.njobs && (int)blockIdx.x >= g.first[j + 1]) ++j;
     const int bid = blockIdx.x - g.first[j];
     if (bid >= g.nwg[j]) return;
-    tn_body<TAPS>(g.job[j], bid, g.nwg[j], smem);
+    tn_body<TAPS, TAPS == 3>(g.job[j], bid, g.nwg[j], smem);      // 3 taps: the interleaved variant (4-deep ring)
 }
 
 template <int TAPS>
@@ -536,7 +536,7 @@ static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW,
 
 template <int TAPS>
 static int launch_tn_group(const TNParams* ps, int n, hipStream_t st) {
-    using C_ = TCfg<TAPS>;
+    using C_ = TCfg<TAPS, TAPS == 3>;
     static unsigned char attr_set[kMaxDevices];
     if (siss_ensure_smem((const void*)gemm_tn_grouped_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
     for (int i0 = 0; i0 < n; i0 += kMaxJobs) {
