@@ -228,7 +228,7 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
             // younger reads in flight.  Past the last step the reads fetch a stale buffer: harmless, never used.
             auto half = [&](bf16x8_t (&yc)[4], bf16x8_t (&xc)[TAPS][CT], bf16x8_t (&yn)[4], bf16x8_t (&xn)[TAPS][CT],
                             const char* sbn, int kkn) {
-                s16x4_t r[20];
+                s16x4_t r0;                                              // the first read of the pair in flight
                 if (do_bias) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yc[i], ones, bacc[i], 0, 0, 0);
@@ -238,22 +238,24 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
                     const int t = 2 - m / 8, i = (m % 8) / CT, j = m % CT;
                     acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yc[i], xc[t][j], acc[t][i][j], 0, 0, 0);
                     if (m < 20) {
+                        // read m: pair (m >> 1) = fragment, m & 1 = its 4-row half; the fragment is assembled the moment its
+                        // second half is issued, so that both reads land in the fragment's own registers (no copies)
+                        s16x4_t rr;
                         if (m < 8) {
-                            r[m] = tr_read(sbn + ((y_off[m & 1] ^ ((m >> 1) << 5)) + kkn * 8192));
+                            rr = tr_read(sbn + ((y_off[m & 1] ^ ((m >> 1) << 5)) + kkn * 8192));
                         } else {
                             const int q = m - 8, tt = 2 - q / 4, ii = (q % 4) >> 1, h = q & 1;
-                            r[m] = tr_read(sbn + ((x_off[tt][h] ^ (ii << 5)) + kkn * 8192));
+                            rr = tr_read(sbn + ((x_off[tt][h] ^ (ii << 5)) + kkn * 8192));
+                        }
+                        if (!(m & 1)) {
+                            r0 = rr;
+                        } else {
+                            const bf16x8_t f = bf16x8_t{r0[0], r0[1], r0[2], r0[3], rr[0], rr[1], rr[2], rr[3]};
+                            if (m < 8) yn[m >> 1] = f;
+                            else { const int q = m - 9; xn[2 - q / 4][(q % 4) >> 1] = f; }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    yn[i] = bf16x8_t{r[2 * i][0], r[2 * i][1], r[2 * i][2], r[2 * i][3], r[2 * i + 1][0], r[2 * i + 1][1], r[2 * i + 1][2], r[2 * i + 1][3]};
-#pragma unroll
-                for (int q = 0; q < 12; q += 2) {
-                    const int tt = 2 - q / 4, ii = (q % 4) >> 1;
-                    xn[tt][ii] = bf16x8_t{r[8 + q][0], r[8 + q][1], r[8 + q][2], r[8 + q][3], r[9 + q][0], r[9 + q][1], r[9 + q][2], r[9 + q][3]};
                 }
             };
             // Ring of FOUR stages here: stage s+3 is issued during step s and only has to have landed at the bottom of step
