@@ -10,6 +10,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 MFMA accu
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;     // packed-f32 math (v_pk_add / v_pk_fma)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;   // operand of v_dot2c_f32_bf16
 
 #define SISS_OK 0
 #define SISS_ERR_ARG 1
@@ -49,6 +51,29 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Sum over the eight lanes that share (lane & 7), result in all of them, on the VALU only (no LDS round trips as
+// __shfl_xor's ds_bpermute): lane ^ 8 by a DPP row rotate, lane ^ 16 / lane ^ 32 by gfx950's permlane swaps
+// (v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second: swapping a value with itself and
+// adding the two results adds each lane's partner).
+__device__ __forceinline__ float sum_lanes_mod8(float t) {
+    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    // (operands and results go through empty asm statements: hipcc 7.2 otherwise folds `r[0] + r[1]` of a swap of a value
+    // with itself into `r[0] + r[0]` -- checked in the ISA and by tests/test_hip_gn_qstats.py)
+    unsigned u = __builtin_bit_cast(unsigned, t), u2 = u;
+    asm volatile("" : "+v"(u2));
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u2, false, false);
+    unsigned a0 = a[0], a1 = a[1];
+    asm volatile("" : "+v"(a0), "+v"(a1));
+    t = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+    unsigned v = __builtin_bit_cast(unsigned, t), v2 = v;
+    asm volatile("" : "+v"(v2));
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v2, false, false);
+    unsigned b0 = b[0], b1 = b[1];
+    asm volatile("" : "+v"(b0), "+v"(b1));
+    return __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1);
+}
+
 // sigmoid with the hardware reciprocal (v_rcp_f32, 1 ulp): an IEEE divide costs ~10 VALU ops and these
 // sit in HBM-bound kernels that are otherwise close to VALU-bound
 __device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
@@ -77,6 +102,10 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- host-side launcher state, PER DEVICE (a process may drive several GPUs; nothing here is shared between them) ----
 constexpr int kMaxDevices = 64;
+// Geometry of the GroupNorm statistics a 3x3 convolution can leave for its consumer (NTParams::qstats, siss_groupnorm_fwd_qs):
+// entry (2 * t + h, slot) covers rows [t * kQsTileRows + h * kQsHalfRows, ...) of the flat padded row space, h = 0 / 1, of the
+// image floor(t * kQsTileRows / rows_per_image) + slot.
+constexpr int kQsTileRows = 254, kQsHalfRows = 128;
 static inline int siss_current_device() {
     int dev = 0;
     return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices ? dev : -1;
@@ -96,5 +125,5 @@ static inline int siss_ensure_smem(const void* kernel, int bytes, unsigned char 
 // ---- dispatch counters (diagnostics): which DEVICE KERNEL a launcher call landed on.  Tests read them through
 //      siss_dispatch_count() to prove that a parity case really exercised e.g. gemm_nt_c3p_kernel. ----
 enum SissKernelId { SISS_K_NT = 0, SISS_K_NT_C3P, SISS_K_NT_C3, SISS_K_NT_CONV3, SISS_K_NT_SPLITK, SISS_K_TN1, SISS_K_TN3,
-                    SISS_K_GN_SLAB, SISS_K_COUNT };
+                    SISS_K_GN_SLAB, SISS_K_GN_QSTATS, SISS_K_COUNT };
 void siss_count_dispatch(int kernel_id);   // gemm_nt.hip

@@ -352,7 +352,8 @@ int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
 
 // Diagnostics: number of launches dispatched to device kernel `kernel_id` since the last reset (process-wide):
 // 0 gemm_nt_kernel, 1 gemm_nt_c3p_kernel, 2 gemm_nt_c3_kernel, 3 gemm_nt_conv3_kernel, 4 gemm_nt_kernel split-K (+ reduce),
-// 5 gemm_tn_kernel<1>, 6 gemm_tn_kernel<3>, 7 GroupNorm slab kernels (forward or backward, small sites).
+// 5 gemm_tn_kernel<1>, 6 gemm_tn_kernel<3>, 7 GroupNorm slab kernels (forward or backward, small sites),
+// 8 GroupNorm forward on the statistics its producing convolution left (no statistics pass).
 // -1 for an unknown id.  siss_dispatch_reset() zeroes them all.  (Tests use these to prove which kernel a case ran on.)
 long siss_dispatch_count(int kernel_id) {
     return kernel_id >= 0 && kernel_id < SISS_K_COUNT ? __atomic_load_n(&g_dispatch[kernel_id], __ATOMIC_RELAXED) : -1;
@@ -382,8 +383,10 @@ namespace {
 int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
                      const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
                      const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
-                     int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream) {
+                     int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream,
+                     float* qstats = nullptr, int* qstats_written = nullptr) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
+    if (qstats_written) *qstats_written = 0;
     SISS_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % BK == 0 && npanels >= 1 && npanels <= kMaxPanels);
     SISS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0) && batch >= 1);
     SISS_CHECK_ARG(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)R) % 16 == 0);
@@ -398,7 +401,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
-    p.ksplit = 1; p.slab = nullptr; p.tile_ctr = nullptr;
+    p.ksplit = 1; p.slab = nullptr; p.tile_ctr = nullptr; p.qstats = nullptr;
     p.rowsub = rowsub; p.mul_r = mul_r;
     SISS_CHECK_ARG(!mul_r || (R && Hp == 0));              // the multiplicative epilogue has no halo form
     const int dev_ = siss_current_device();
@@ -431,6 +434,10 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
         if (conv3 && Kp % 64 == 0 && N % BN == 0 && rows_per_image >= 256 && (c3 == 1 || (c3 == 2 && tiles >= c3_min))) {
             static int c3p = -1;
             if (c3p < 0) { const char* e = getenv("SISS_NT_C3P"); c3p = e ? atoi(e) : 1; }   // persistent producer/consumer variant
+            if (c3p && qstats && Hp > 0 && ((uintptr_t)qstats % 16) == 0) {
+                p.qstats = qstats;                          // only the persistent kernel forms them; the caller is told
+                if (qstats_written) *qstats_written = 1;
+            }
             return c3p ? siss_launch_gemm_nt_c3p(&p, stream) : siss_launch_gemm_nt_c3(&p, stream);
         }
         if (conv3 && (use3 == 1 || (use3 == 2 && tiles >= 1024))) return siss_launch_gemm_nt_conv3(&p, stream);
@@ -497,6 +504,26 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
                  int batch, long strideA, long strideW, long strideC, void* stream) {
     return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, Kp, npanels, shifts, coffs,
                             rows_per_image, Hp, Wp, alpha, batch, strideA, strideW, strideC, nullptr, 0, stream);
+}
+
+// siss_gemm_nt that may also hand the GroupNorm statistics of its OUTPUT to the consumer.  `qstats` (f32, siss_conv_qstats_words
+// floats, 16-B aligned) receives, per (128-row half of a 254-row tile, image slot, 4-channel quad), the sum and the sum of squares
+// of the stored bf16 values -- but only when the product is dispatched to the persistent 3x3 kernel (nine 3x3 panels, halo mask,
+// large grid); *written (a HOST int) says whether it was (1) or whether the buffer was left untouched (0: the consumer runs its
+// own statistics pass).  siss_groupnorm_fwd_qs folds the buffer.
+int siss_gemm_nt_qstats(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
+                        const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
+                        const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
+                        float* qstats, int* written, void* stream) {
+    SISS_CHECK_ARG(qstats && written);
+    return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, Kp, npanels, shifts, coffs,
+                            rows_per_image, Hp, Wp, alpha, 1, 0, 0, 0, nullptr, 0, stream, qstats, written);
+}
+
+// floats in the `qstats` buffer of a product with M rows and N output channels
+long siss_conv_qstats_words(long M, int N) {
+    if (M <= 0 || N <= 0 || N % 4) return -1;
+    return ((M + kQsTileRows - 1) / kQsTileRows) * 2 * 2 * (long)(N / 4) * 2;
 }
 
 // Same product with the attention-backward epilogue  C = R o (alpha * (acc - rowsub[row]))  (R: bf16 [batch][M][N]

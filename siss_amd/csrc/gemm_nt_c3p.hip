@@ -32,6 +32,7 @@ constexpr int P_ABYTES = P_BM * 128;                       // 32,768
 constexpr int P_WBYTES = BN * 128;                         // 16,384 per tap
 constexpr int P_SLOT = P_ABYTES + 3 * P_WBYTES;            // 81,920: one GROUP (A tile + three weight tiles)
 constexpr int P_SMEM = 2 * P_SLOT;                         // 163,840 = all of the CU's LDS
+static_assert(P_VALID == kQsTileRows && P_BM / 2 == kQsHalfRows, "qstats geometry is shared with groupnorm.hip");
 
 __device__ __forceinline__ int swz3p(int row) { return row & 6; }
 // s_barrier as inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin barrier, which would make every
@@ -44,7 +45,9 @@ struct TileMap {
     __device__ __forceinline__ int tile(int k) const { return k * nb + b_lo * per + b_hi; }   // XCD-contiguous
 };
 
-template <bool ILV>
+// QS: the producers also form the GroupNorm statistics of what they store (NTParams::qstats): the tensor's consumer is a
+// GroupNorm, whose statistics pass (one more read of the whole tensor) then disappears.
+template <bool ILV, bool QS>
 __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,14 +111,50 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         // The parked tile of the previous tile, in registers: lane -> (row = it*8 + lane>>3, 16-B chunk = lane&7).
         u32x4_t ov[16];
         int pend = -1, phalf = 0;                          // tile iteration whose rows `ov` holds (-1: none), next half
+        // QS: this lane's running statistics over the rows it stores, [set][sum lo quad, sumsq lo quad, sum hi quad, sumsq hi quad]:
+        // its 8 channels are two 4-channel quads; set 0 takes every row, set 1 only the rows of the tile's SECOND image
+        float qacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // fold the eight row groups of the wave (lane >> 3), then lanes 0..7 write the (half tile, slot) entries:
+        // [2 * row tile + wm][slot][N / 4 quads][sum, sumsq]; every entry is written by every launch
+        auto fold_tile = [&](int k) __attribute__((always_inline)) {
+            const int tl = tm.tile(k);
+            const int m0 = (tl / tm.tiles_n) * P_VALID, n0 = (tl % tm.tiles_n) * BN;
+            const bool straddle = m0 + P_BM > (m0 / rpi + 1) * rpi;
+            float qs[2][4];                                // [slot][sum lo quad, sumsq lo quad, sum hi quad, sumsq hi quad]
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qs[sl][e] = qacc[sl][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qs[0][e] -= qs[1][e];      // all rows - second image's rows (0 unless straddling)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                if (sl == 1 && !straddle) continue;        // (uniform) slot 1 of a one-image tile is all zero
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qs[sl][e] = sum_lanes_mod8(qs[sl][e]);
+            }
+            if (prow == 0) {
+                const long ht = (long)(tl / tm.tiles_n) * 2 + wm;
+                const int quad = ((n0 + wn * 64) >> 2) + pc * 2;
+                float* dst = p.qstats + ((ht * 2) * (p.N >> 2) + quad) * 2;
+                *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{qs[0][0], qs[0][1], qs[0][2], qs[0][3]};
+                *reinterpret_cast<f32x4_t*>(dst + (p.N >> 2) * 2) = f32x4_t{qs[1][0], qs[1][1], qs[1][2], qs[1][3]};
+            }
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qacc[sl][e] = 0.f;
+        };
         // Stores rows it = 8*half .. 8*half+7 of the parked tile (one half per group, so that the producers are
-        // back at the next group barrier in time).  Returns true when exactly 8 store instructions were issued.
-        auto store_tile = [&](auto has_r, int half) -> bool {
+        // back at the next group barrier in time).  Returns the number of store instructions issued when that number
+        // is exact (8, or 10 with the statistics rows), else 0.
+        auto store_tile = [&](auto has_r, int half) __attribute__((always_inline)) -> int {
             constexpr bool HAS_R = decltype(has_r)::value;
             const int tl = tm.tile(pend);
             const int m0 = (tl / tm.tiles_n) * P_VALID, n0 = (tl % tm.tiles_n) * BN;
             const int img0 = m0 / rpi;                     // a 256-row tile spans at most two images (rpi >= 256)
             const int split = (img0 + 1) * rpi;            // first row of the second image
+            const bool straddle = m0 + P_BM > split;       // (uniform) the tile's last rows belong to the next image
             const int ccol = n0 + wn * 64 + pc * 8;
             u32x4_t res[HAS_R ? 8 : 1];
             if constexpr (HAS_R) {
@@ -151,8 +190,42 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                                         __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
                 }
                 *reinterpret_cast<u32x4_t*>(p.C + (long)r * p.ldc + ccol) = o;
+                if constexpr (QS) {
+                    // statistics of the STORED values (halo rows are zero and add nothing) straight from the packed bf16 pairs:
+                    // v_dot2c_f32_bf16 (acc += a.lo * b.lo + a.hi * b.hi) against (1, 1) gives the sum, against itself the
+                    // sum of squares -- 8 instructions per row, no unpacking.  (Measured: wherever this work is placed -- here,
+                    // or in the later groups where the store waves only issue the DMA -- it costs the kernel its own duration:
+                    // the fewest instructions win, and that is here, where the value is in registers already.)
+                    // Set 0 takes EVERY row; set 1 only the rows of the tile's second image (one tile in ~260 has any: uniform
+                    // branch), selected by masks -- a per-lane branch between two accumulator sets makes the compiler index them
+                    // dynamically, i.e. park them in scratch memory.  The first image's share is set 0 - set 1.
+                    const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);
+                    // (each pair goes through an empty asm into a register of its own: fed with elements of the u32x4 vector,
+                    // hipcc 7.2 emitted every dot product against element 0 -- seen in the ISA, caught by test_hip_gn_qstats.py)
+                    uint32_t ow[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ow[e] = o[e]; asm volatile("" : "+v"(ow[e])); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2_t v = __builtin_bit_cast(bf16x2_t, ow[e]);
+                        qacc[0][(e >> 1) * 2] = __builtin_amdgcn_fdot2_f32_bf16(v, ones, qacc[0][(e >> 1) * 2], false);
+                        qacc[0][(e >> 1) * 2 + 1] = __builtin_amdgcn_fdot2_f32_bf16(v, v, qacc[0][(e >> 1) * 2 + 1], false);
+                    }
+                    if (straddle) {
+                        const uint32_t mb = r >= split ? 0xffffffffu : 0u;
+                        const bf16x2_t mones = __builtin_bit_cast(bf16x2_t, 0x3F803F80u & mb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bf16x2_t v = __builtin_bit_cast(bf16x2_t, ow[e]), vm = __builtin_bit_cast(bf16x2_t, ow[e] & mb);
+                            qacc[1][(e >> 1) * 2] = __builtin_amdgcn_fdot2_f32_bf16(v, mones, qacc[1][(e >> 1) * 2], false);
+                            qacc[1][(e >> 1) * 2 + 1] = __builtin_amdgcn_fdot2_f32_bf16(vm, v, qacc[1][(e >> 1) * 2 + 1], false);
+                        }
+                    }
+                }
             }
-            return m0 + wm * 128 + half * 64 + 64 <= p.M;  // rows 254/255 only mask lanes of the last instruction
+            const bool exact = m0 + wm * 128 + half * 64 + 64 <= p.M;   // rows 254/255 only mask lanes of the last instruction
+            if constexpr (QS) { if (half == 1) { fold_tile(pend); return exact ? 10 : 0; } }
+            return exact ? 8 : 0;
         };
 
         int gin = 0;
@@ -162,7 +235,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         for (int g = 0; g < G; ++g) {
             c3p_barrier();                                 // #g: group g has landed; consumers are done with group g-1
             if (g + 1 < G) issue_group();                  // -> slot (g+1)&1: last read by group g-1 / parked tile already in `ov`
-            bool counted = false;
+            int counted = 0;
             if (pend >= 0) {
                 if (!(p.ablate & 1)) {
                     if (p.R) store_tile(std::true_type{}, phalf);      // its wait retired the DMA above as well
@@ -170,8 +243,9 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                 }
                 if (++phalf == 2) { phalf = 0; pend = -1; }
             }
-            // the DMA of group g+1 must have landed before barrier #g+1; 8 younger stores may stay in flight
-            if (counted) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // the DMA of group g+1 must have landed before barrier #g+1; the younger stores may stay in flight
+            if (counted == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (counted == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (++gin == gpt) {                            // g was the last group of its tile
                 gin = 0;
@@ -344,11 +418,14 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
 // N % 128 == 0, batch == 1, rows_per_image >= 256.
 int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     const NTParams& p = *reinterpret_cast<const NTParams*>(params);
-    static unsigned char attr_set[kMaxDevices], attr_ilv[kMaxDevices];
+    static unsigned char attr_set[4][kMaxDevices];
     static int ilv = -1;
     if (ilv < 0) { const char* e = getenv("SISS_NT_C3P_ILV"); ilv = e ? atoi(e) : 1; }   // measured +2.6 % (1064 -> 1092 TF/s over the 98 launches of a step)
-    if (siss_ensure_smem(ilv ? (const void*)gemm_nt_c3p_kernel<true> : (const void*)gemm_nt_c3p_kernel<false>, P_SMEM,
-                         ilv ? attr_ilv : attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    const bool qs = p.qstats != nullptr;
+    using kern_t = void (*)(const NTParams);
+    const kern_t kern = ilv ? (qs ? gemm_nt_c3p_kernel<true, true> : gemm_nt_c3p_kernel<true, false>)
+                            : (qs ? gemm_nt_c3p_kernel<false, true> : gemm_nt_c3p_kernel<false, false>);
+    if (siss_ensure_smem((const void*)kern, P_SMEM, attr_set[(ilv ? 2 : 0) + (qs ? 1 : 0)]) != SISS_OK) return SISS_ERR_LAUNCH;
     siss_count_dispatch(SISS_K_NT_C3P);
     // Grid = the FEWEST blocks (a multiple of 8: XCD runs) that finish in the same number of tile rounds as the full
     // chip: 550 tiles are 3 rounds on 256 CUs (38 CUs with three tiles, 218 with two) and exactly 3 on 184 -- the idle
@@ -360,7 +437,6 @@ int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     nb = (nb + 7) & ~7;
     if (nb > maxb) nb = maxb;
     if (nb < 8) nb = 8;
-    if (ilv) gemm_nt_c3p_kernel<true><<<dim3(nb), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
-    else gemm_nt_c3p_kernel<false><<<dim3(nb), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
+    kern<<<dim3(nb), P_THREADS, P_SMEM, (hipStream_t)stream>>>(p);
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }

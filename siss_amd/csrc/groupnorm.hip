@@ -165,7 +165,15 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     __shared__ float sh_mean[kMaxG], sh_rstd[kMaxG];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    fold_stats(partial, s, n, eps, sh_mean, sh_rstd, mean_out, rstd_out, chunk == 0);
+    if (partial) fold_stats(partial, s, n, eps, sh_mean, sh_rstd, mean_out, rstd_out, chunk == 0);
+    else {
+        // mean / rstd were finalised by gn_qstats_finalize_kernel (statistics from the producing convolution's epilogue)
+        if (tid < s.G) {
+            const long go = (long)n * s.Gf + blockIdx.z * s.G + tid;
+            sh_mean[tid] = mean_out[go]; sh_rstd[tid] = rstd_out[go];
+        }
+        __syncthreads();
+    }
     const int slot = tid / s.lpp, cc = tid - slot * s.lpp;
     if (slot >= s.ppi) return;
     const int c0 = blockIdx.z * s.C;
@@ -199,6 +207,48 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
         }
         *reinterpret_cast<u32x4_t*>(y + o0 * s.ld + cc * 8) = pack8(v);
         if (two) *reinterpret_cast<u32x4_t*>(y + o1 * s.ld + cc * 8) = pack8(u);
+    }
+}
+
+// Statistics handed over by the producing 3x3 convolution(s) (NTParams::qstats): block (sample n, 4 groups), ONE WAVE per
+// group walks the sample's (half tile, quad) entries four independent loads at a time; sums in double from the first
+// addition on.  The normalised tensor may be the channel concat of two producers' outputs: quads [0, qa) come from qsA (qa
+// quads per entry), the rest from qsB (qb per entry).
+__global__ __launch_bounds__(kThreads) void gn_qstats_finalize_kernel(
+    const float* __restrict__ qsA, int qa, const float* __restrict__ qsB, int qb, int H, int W, int G, int cpg, float eps,
+    float* __restrict__ mean, float* __restrict__ rstd) {
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int g = blockIdx.y * 4 + (tid >> 6);
+    if (g >= G) return;                                    // whole waves only: no barrier below
+    const long rpi = (long)(H + 2) * (W + 2);
+    const int t0 = (int)(n * rpi / kQsTileRows), t1 = (int)(((n + 1) * rpi - 1) / kQsTileRows);
+    const int qpg = cpg >> 2;
+    const int items = (t1 - t0 + 1) * 2 * qpg;
+    auto entry = [&](int it) -> float2 {
+        if (it >= items) return float2{0.f, 0.f};
+        const int hl = it / qpg, qi = it - hl * qpg;
+        const int t = t0 + (hl >> 1), h = hl & 1;
+        const int slot = (int)((long)t * kQsTileRows / rpi) == n ? 0 : 1;       // the tile starts in image n, or in n - 1
+        const int q = g * qpg + qi;
+        const float* src = q < qa ? qsA : qsB;
+        const int stride = q < qa ? qa : qb, qq = q < qa ? q : q - qa;
+        return *reinterpret_cast<const float2*>(src + (((long)(2 * t + h) * 2 + slot) * stride + qq) * 2);
+    };
+    double a = 0.0, b = 0.0;
+    for (int it = lane; it < items; it += 256) {
+        const float2 e0 = entry(it), e1 = entry(it + 64), e2 = entry(it + 128), e3 = entry(it + 192);
+        a += ((double)e0.x + (double)e1.x) + ((double)e2.x + (double)e3.x);
+        b += ((double)e0.y + (double)e1.y) + ((double)e2.y + (double)e3.y);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (lane == 0) {
+        const double cnt = (double)H * W * cpg;
+        const double m = a / cnt;
+        double var = b / cnt - m * m;
+        var = var > 0 ? var : 0;
+        mean[(long)n * G + g] = (float)m;
+        rstd[(long)n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -492,10 +542,16 @@ long siss_gn_partial_words(int n, int H, int W, int C, int G) {
 
 // y = act(GroupNorm(x)); x padded NHWC; y padded or compact ([N][H*W][C]).  Writes mean/rstd [N][G].
 // ldx: row stride of x in elements (0 = C; > C when x is a column view of a wider concat buffer).
-int siss_groupnorm_fwd_ld(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                          float* rstd, float* partial, int N, int H, int W, int C, int G, float eps,
-                          int silu, int out_compact, int ldx, void* stream) {
+// qsA / qsB (optional): the statistics the producing convolution(s) left (siss_gemm_nt_qstats wrote them: *written == 1) --
+// channels [0, ca) of x are the ca output channels of producer A, the remaining C - ca those of producer B (qsB null and
+// ca == C for a single producer).  With them the two-pass form needs no statistics pass; sites served by the one-launch
+// kernels, or whose groups are not whole 4-channel quads, ignore them.
+int siss_groupnorm_fwd_qs(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                          float* rstd, float* partial, const float* qsA, int ca, const float* qsB, int N, int H, int W,
+                          int C, int G, float eps, int silu, int out_compact, int ldx, void* stream) {
     GNShape s;
+    SISS_CHECK_ARG(!qsA || (ca > 0 && ca <= C && ca % 4 == 0 && (ca == C) == (qsB == nullptr)));
+    SISS_CHECK_ARG(((uintptr_t)qsA | (uintptr_t)qsB) % 8 == 0);
     SISS_CHECK_ARG(x && gamma && beta && y && mean && rstd && partial && N > 0);
     SISS_CHECK_ARG(make_shape(H, W, C, G, s, N));
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
@@ -514,12 +570,25 @@ int siss_groupnorm_fwd_ld(const void* x, const float* gamma, const float* beta, 
     partial += siss_gn2p_words(k2pSamples);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, N, s.nslices);
-    gn_stats_kernel<<<grid, kThreads, 0, st>>>((const bf16_t*)x, s, partial);
+    if (qsA && s.cpg % 4 == 0 && (long)(H + 2) * (W + 2) >= 256) {
+        siss_count_dispatch(SISS_K_GN_QSTATS);
+        gn_qstats_finalize_kernel<<<dim3(N, (G + 3) / 4), kThreads, 0, st>>>(qsA, ca / 4, qsB, (C - ca) / 4, H, W, G, s.cpg, eps,
+                                                                             mean, rstd);
+        partial = nullptr;                              // gn_apply_kernel reads mean / rstd instead of folding a slab
+    } else
+        gn_stats_kernel<<<grid, kThreads, 0, st>>>((const bf16_t*)x, s, partial);
     if (silu)
         gn_apply_kernel<true><<<grid, kThreads, 0, st>>>((const bf16_t*)x, gamma, beta, partial, s, eps, out_compact, (bf16_t*)y, mean, rstd);
     else
         gn_apply_kernel<false><<<grid, kThreads, 0, st>>>((const bf16_t*)x, gamma, beta, partial, s, eps, out_compact, (bf16_t*)y, mean, rstd);
     SISS_LAUNCH_RET();
+}
+/* the same without statistics from the producer */
+int siss_groupnorm_fwd_ld(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                          float* rstd, float* partial, int N, int H, int W, int C, int G, float eps,
+                          int silu, int out_compact, int ldx, void* stream) {
+    return siss_groupnorm_fwd_qs(x, gamma, beta, y, mean, rstd, partial, nullptr, C, nullptr, N, H, W, C, G, eps, silu,
+                                 out_compact, ldx, stream);
 }
 /* the same with ldx = C */
 int siss_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,

@@ -23,6 +23,9 @@ struct NTParams {
     float* slab;                      //      ([tile][split][BM*BN] in accumulator order); the LAST block of a tile to arrive
     int* tile_ctr;                    //      (arrival counters, one per tile, zero between launches) sums them and runs the epilogue
     long long* dbg;                   // timing probe buffer (SISS_NT_DEBUG_PTR), normally null
+    float* qstats;                    // optional (persistent 3x3 kernel only): per-(half tile, image slot, 4-channel quad) sums and
+                                      // sums of squares of the bf16 OUTPUT, [2 * row tiles][2][N / 4][2] f32 -- the GroupNorm that
+                                      // consumes the result folds them instead of reading the tensor a second time
     int shift[kMaxPanels];
     int coff[kMaxPanels];
 };

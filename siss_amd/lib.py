@@ -32,6 +32,8 @@ SIGNATURES = {
     "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],
     "siss_conv_weight_dgrad_multi": [P, P, P, I, I, P],
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
+    "siss_gemm_nt_qstats": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, P, IP, P],
+    "siss_conv_qstats_words": [L, I],
     "siss_gemm_nt_set_workspace": [P, L],
     "siss_gemm_nt_set_c3p_blocks": [I],
     "siss_dispatch_count": [I],
@@ -44,6 +46,7 @@ SIGNATURES = {
     "siss_groupnorm_set_two_phase": [I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
     "siss_groupnorm_fwd_ld": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, I, P],
+    "siss_groupnorm_fwd_qs": [P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, F, I, I, I, P],
     "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],
     "siss_groupnorm_bwd_ld": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, I, P],
     "siss_upsample2x": [P, P, I, I, I, I, P],
@@ -86,11 +89,11 @@ SIGNATURES = {
     "siss_linear_small_bwd": [P, P, P, P, P, I, P, P, P, I, I, I, L, L, I, I, I, P],
 }
 _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words",
-             "siss_gn_partial_words", "siss_dispatch_count"}
+             "siss_gn_partial_words", "siss_dispatch_count", "siss_conv_qstats_words"}
 
 # siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
 KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "gemm_nt_c3_kernel": 2, "gemm_nt_conv3_kernel": 3,
-              "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7}
+              "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8}
 
 
 def dispatch_counts(reset=False):
@@ -266,6 +269,11 @@ def call(name, *args):
         s.record()
         rc = fn(*conv, stream_ptr())
         e.record()
+        # variants that only add operands are booked under their plain form (same work, same shape key)
+        if name == "siss_gemm_nt_qstats":
+            name, args = "siss_gemm_nt", list(args[:20]) + [1, 0, 0, 0]
+        elif name == "siss_groupnorm_fwd_qs":
+            name, args = "siss_groupnorm_fwd_ld", list(args[:7]) + list(args[10:])
         base = name[:-3] if name.endswith("_ld") else name          # row-stride variants count as their plain form
         PROF.append((base, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args), hbm_bytes(name, args)))
     else:

@@ -43,7 +43,16 @@ def dgrad_weight(w_native_f32):
 # ---------------------------------------------------------------- panelled NT GEMM
 def gemm_nt(a_ptr, lda, w, c_ptr, ldc, M, N, Kp, shifts, coffs, *, bias=None, rowbias=None, ldrb=None,
             res_ptr=None, ldr=0, rows_per_image=1, hp=0, wp=0, alpha=1.0, batch=1,
-            stride_a=0, stride_w=0, stride_c=0):
+            stride_a=0, stride_w=0, stride_c=0, qstats=None):
+    """qstats (f32 tensor of lib siss_conv_qstats_words(M, N) floats): ask the product to leave the GroupNorm statistics
+    of its output there; returns True when it did (the launch went to the persistent 3x3 kernel), else False/None."""
+    if qstats is not None:
+        assert batch == 1
+        written = lib.C.c_int(0)
+        lib.call("siss_gemm_nt_qstats", a_ptr, lda, w, c_ptr, ldc, bias, rowbias, ldrb if ldrb is not None else N, res_ptr,
+                 ldr, M, N, Kp, len(shifts), lib.int_array(shifts), lib.int_array(coffs), rows_per_image, hp, wp,
+                 float(alpha), qstats, lib.C.byref(written))
+        return bool(written.value)
     lib.call("siss_gemm_nt", a_ptr, lda, w, c_ptr, ldc, bias, rowbias, ldrb if ldrb is not None else N, res_ptr, ldr, M, N, Kp,
              len(shifts), lib.int_array(shifts), lib.int_array(coffs), rows_per_image, hp, wp,
              float(alpha), batch, stride_a, stride_w, stride_c)
@@ -64,6 +73,19 @@ def conv_fprop(x: Act, w_bf16, out: Act, bias=None, rowbias=None, residual: Act 
             ldr=getattr(residual, "ld", residual.c) if residual is not None else 0,
             rows_per_image=x.rows_per_image, hp=x.hp, wp=x.wp)
     return out
+
+
+def conv_fprop_qstats(x: Act, w_bf16, out: Act, qstats, **kw):
+    """conv_fprop that asks for the GroupNorm statistics of `out` (see gemm_nt); returns whether they were written."""
+    t, co, ci = w_bf16.shape
+    assert t == 9 and ci == x.c and co == out.c and (x.n, x.h, x.w) == (out.n, out.h, out.w)
+    shifts, coffs = conv3x3_panels(x.wp, ci)
+    residual = kw.get("residual")
+    return gemm_nt(lib.ptr(x.data), getattr(x, "ld", x.c), w_bf16, lib.ptr(out.data), getattr(out, "ld", out.c), x.rows, co, ci,
+                   shifts, coffs, bias=kw.get("bias"), rowbias=kw.get("rowbias"), ldrb=kw.get("ldrb"),
+                   res_ptr=lib.ptr(residual.data) if residual is not None else None,
+                   ldr=getattr(residual, "ld", residual.c) if residual is not None else 0,
+                   rows_per_image=x.rows_per_image, hp=x.hp, wp=x.wp, qstats=qstats)
 
 
 def conv_dgrad(dy: Act, wT_bf16, out: Act, residual: Act = None, ksize=3):

@@ -189,6 +189,8 @@ class UNetEngine:
         # as grouped launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).  They only feed the flat
         # gradient buffer, so nothing waits for them; their cotangent operand is held back from the buffer pool until the
         # group has run.  0 = off.
+        # GroupNorm statistics from the producing conv's epilogue (no statistics pass at the large sites)
+        self.epi_stats = os.environ.get("SISS_GN_EPI_STATS", "1") != "0"
         self.group_rows = int(os.environ.get("SISS_WGRAD_GROUP_ROWS", "20000"))
         self.group_max = int(os.environ.get("SISS_WGRAD_GROUP_MAX", "42"))
         self.group_attn = self.group_rows and os.environ.get("SISS_WGRAD_GROUP_ATTN", "1") == "1"   # ... the attention blocks' linears too
@@ -470,9 +472,24 @@ class UNetEngine:
             y = self._act(nm + ".y", x.n, x.h, x.w, x.c)
             yptr = y.data
         ldx = getattr(x, "ld", x.c)                 # x may be a column view of a concat buffer (ActView)
-        lib.call("siss_groupnorm_fwd_ld", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
-                 self._gn_partial(x.n, x.h, x.w, x.c), x.n, x.h, x.w, x.c, G, float(eps), int(silu), int(compact_out),
-                 0 if ldx == x.c else ldx)
+        # statistics left by the producing conv(s) (conv(want_stats=True)): x itself, or both parts of a concat
+        qa = qb = None
+        ca = x.c
+        if self.epi_stats:
+            parts = getattr(x, "cat_parts", None)
+            if parts is not None:
+                if parts[0].qstats is not None and parts[1].qstats is not None:
+                    qa, qb, ca = parts[0].qstats, parts[1].qstats, parts[0].c
+            else:
+                qa = x.qstats
+        if qa is not None:
+            lib.call("siss_groupnorm_fwd_qs", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
+                     self._gn_partial(x.n, x.h, x.w, x.c), qa, ca, qb, x.n, x.h, x.w, x.c, G, float(eps), int(silu),
+                     int(compact_out), 0 if ldx == x.c else ldx)
+        else:
+            lib.call("siss_groupnorm_fwd_ld", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
+                     self._gn_partial(x.n, x.h, x.w, x.c), x.n, x.h, x.w, x.c, G, float(eps), int(silu), int(compact_out),
+                     0 if ldx == x.c else ldx)
 
         def bwd(dy, colsum=None, accum: Act = None, colsum_ld=0, accum2: Act = None, split=None):
             """dy: Act (padded) or compact tensor, nb samples.  Returns dx Act (nb samples).
@@ -503,7 +520,7 @@ class UNetEngine:
         return y, bwd
 
     def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None, ldrb=None, cat_with=None,
-             skip_head=None):
+             skip_head=None, want_stats=False):
         """stride-1 'same' conv (3x3 or 1x1) with fused bias / time-embedding row bias / residual.  cat_with: the skip
         activation the result is about to be concatenated with -- the result is then written straight into the head
         columns of that concat buffer (epilogue with ldc = C + C_skip) and concat() only copies the skip."""
@@ -525,7 +542,15 @@ class UNetEngine:
             y = ActView(self._act(self._name("cat"), x.n, x.h, x.w, skip_head + co), skip_head, co)
         else:
             y = self._act(self._name(out_name or pre), x.n, x.h, x.w, co)
-        ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
+        # want_stats: the result feeds a GroupNorm -- at the sites where that GroupNorm would make a statistics pass of its
+        # own (more than 32 x 32 pixels) the conv's epilogue leaves the statistics (y.qstats) when its kernel can
+        y.qstats = None
+        if want_stats and self.epi_stats and ksize == 3 and x.h * x.w > 1024 and co % 128 == 0:
+            qs = self._buf(self._name(pre) + ".qs", (lib.query("siss_conv_qstats_words", x.rows, co),))
+            if ops.conv_fprop_qstats(x, w, y, qs, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ldrb=ldrb):
+                y.qstats = qs
+        else:
+            ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
 
         def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None):
             dW = ps.grads[self.gbase:, ps.specs[pre + ".weight"].off:]
@@ -619,7 +644,7 @@ class UNetEngine:
         B = x.n
         a1, gn1_b = self.gn(x, pre + ".norm1", True)
         col0, _ = self.temb_cols[pre]
-        h, c1_b = self.conv(a1, pre + ".conv1", rowbias=self.tp_all[:, col0:], ldrb=self.temb_ntot)
+        h, c1_b = self.conv(a1, pre + ".conv1", rowbias=self.tp_all[:, col0:], ldrb=self.temb_ntot, want_stats=True)
         a2, gn2_b = self.gn(h, pre + ".norm2", True)
         has_sc = cin != cout
         if has_sc:
@@ -627,7 +652,7 @@ class UNetEngine:
             res = sc
         else:
             res = x
-        out, c2_b = self.conv(a2, pre + ".conv2", residual=res, cat_with=cat_with, skip_head=skip_head)
+        out, c2_b = self.conv(a2, pre + ".conv2", residual=res, cat_with=cat_with, skip_head=skip_head, want_stats=True)
 
         def bwd():
             nb = self.nb
@@ -844,7 +869,7 @@ class UNetEngine:
         C, B = x.c, x.n
         u = self._act(self._name(pre + ".u"), B, 2 * x.h, 2 * x.w, C)
         lib.call("siss_upsample2x", x.data, u.data, B, x.h, x.w, C)
-        y, c_b = self.conv(u, pre + ".conv", cat_with=cat_with)
+        y, c_b = self.conv(u, pre + ".conv", cat_with=cat_with, want_stats=True)
 
         def bwd():
             dy = self._take(y)
