@@ -17,6 +17,7 @@ is replayable from a hipGraph.
 Parameter names are the diffusers state-dict keys, so checkpoints round-trip.
 """
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -153,6 +154,7 @@ class ParamStore:
 
 class UNetEngine:
     """Static-schedule UNet.  ``forward(x, t)`` then ``backward(c, nsets)``."""
+    epi_stats = os.environ.get("SISS_GN_EPI_STATS", "1") != "0"    # (class default: subclasses with their own __init__, e.g. VAEEncoder)
 
     def __init__(self, cfg: UNet2DConfig, device="cuda"):
         lib.load()
