@@ -127,6 +127,9 @@ class SISSStepper:
             errors["serial_direct"] = (str(exc) or type(exc).__name__)[:200]
             del candidates["serial_direct"]
             del candidates["serial_sharded"]                     # its reduce-scatter is the same all-to-all
+        # the timed steps are real optimizer steps: put parameters, AdamW moments and the step counter back afterwards
+        # (the run that follows starts from the weights it was given, whichever candidate wins)
+        saved = [t.clone() for t in (self.opt.p, self.opt.m, self.opt.v, self.opt.scalars)]
         for name, (mode, exch, cus) in candidates.items():
             self.set_overlap(mode, exch)
             lib.query("siss_gemm_nt_set_c3p_blocks", cus)
@@ -140,6 +143,12 @@ class SISSStepper:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
             results[name] = float(tt.item()) / iters
         best = min(results, key=results.get)
+        self._state_shard = None                                 # (the moments are overwritten as a whole below)
+        for dst, src in zip((self.opt.p, self.opt.m, self.opt.v, self.opt.scalars), saved):
+            dst.copy_(src)
+        del saved
+        self.e.refresh_weights(cast_shadow=True)
+        self._micro = 0
         self.set_overlap(best.startswith("overlap"), candidates[best][1])
         self.c3p_blocks = lib.query("siss_gemm_nt_set_c3p_blocks", candidates[best][2])
         self.overlap_timings = {k + "_ms": v * 1e3 for k, v in results.items()}

@@ -78,7 +78,10 @@ def main():
     assert cos > 0.999, cos
     # ... and the measured choice between the two runs on every rank without deadlock and agrees across ranks
     st3 = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, **kw)
+    before = eng.ps.flat.clone()
     choice = st3.autotune_overlap(lambda: st3.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl]), iters=1)
+    # the timed steps were real optimizer steps: parameters, moments and the step counter are put back afterwards
+    assert torch.equal(eng.ps.flat, before) and float(st3.opt.m.abs().max()) == 0.0 and int(st3.opt.scalars[6]) == 0
     flags = [None] * world
     dist.all_gather_object(flags, bool(choice))
     keys = set(st3.overlap_timings)
