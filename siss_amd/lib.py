@@ -199,6 +199,10 @@ def _work(name, a):
                                                        j.row_begin, j.row_end]) for j in a[0])
     if name == "siss_gemm_nt_mulsub":   # 2 * M * N * Kp * batch
         return 2.0 * a[8] * a[9] * a[10] * a[12]
+    if name == "siss_flash_attn_fwd":   # QK^T and PV over the VALID keys (padded queries / head dim counted as laid out)
+        return 2.0 * 2 * a[5] * a[6] * a[9] * a[8]
+    if name == "siss_flash_attn_bwd":   # algorithmic: S, dP, dQ, dK, dV (the two-kernel form recomputes S and dP: 7 products run)
+        return 2.0 * 5 * a[9] * a[11] * a[14] * a[13]
     return 0.0
 
 
@@ -231,6 +235,10 @@ def _shape_key(name, a):
         return ("n", a[7], "H", a[8], "C", a[10])
     if name in ("siss_groupnorm_bwd", "siss_groupnorm_bwd_ld"):
         return ("n2", a[17], "H", a[21], "C", a[23])
+    if name == "siss_flash_attn_fwd":
+        return ("BH", a[5], "Sq", a[6], "Sk", a[9], "D", a[8])
+    if name == "siss_flash_attn_bwd":
+        return ("BH", a[9], "Sq", a[11], "Sk", a[14], "D", a[13])
     return ()
 
 
