@@ -384,7 +384,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
                      const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
                      const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
                      int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream,
-                     float* qstats = nullptr, int* qstats_written = nullptr) {
+                     float* qstats = nullptr, int* qstats_written = nullptr, int d2s = 0) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
     if (qstats_written) *qstats_written = 0;
     SISS_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % BK == 0 && npanels >= 1 && npanels <= kMaxPanels);
@@ -401,7 +401,8 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
-    p.ksplit = 1; p.slab = nullptr; p.tile_ctr = nullptr; p.qstats = nullptr;
+    p.ksplit = 1; p.slab = nullptr; p.tile_ctr = nullptr; p.qstats = nullptr; p.d2s = d2s;
+    SISS_CHECK_ARG(d2s == 0 || (d2s >= 1 && d2s <= 4 && Hp > 2 && Wp > 2 && batch == 1 && !rowsub && !mul_r));
     p.rowsub = rowsub; p.mul_r = mul_r;
     SISS_CHECK_ARG(!mul_r || (R && Hp == 0));              // the multiplicative epilogue has no halo form
     const int dev_ = siss_current_device();
@@ -420,7 +421,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
     // 3x3 filters on large grids: the fused-tap kernel (A tile shared by the three kx taps)
     {
-        bool conv3 = npanels == 9 && batch == 1 && Kp % 32 == 0 && !rowsub && !mul_r;
+        bool conv3 = npanels == 9 && batch == 1 && Kp % 32 == 0 && !rowsub && !mul_r && !d2s;
         for (int g = 0; conv3 && g < 3; ++g)
             conv3 = p.shift[3 * g + 1] == p.shift[3 * g] + 1 && p.shift[3 * g + 2] == p.shift[3 * g] + 2 &&
                     p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
@@ -518,6 +519,19 @@ int siss_gemm_nt_qstats(const void* A, long lda, const void* W, void* C, long ld
     SISS_CHECK_ARG(qstats && written);
     return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, Kp, npanels, shifts, coffs,
                             rows_per_image, Hp, Wp, alpha, 1, 0, 0, 0, nullptr, 0, stream, qstats, written);
+}
+
+// siss_gemm_nt whose rows are the pixels of ONE space-to-depth plane (plane = 2 py + px) of a stride-2 convolution's input: the
+// epilogue writes pixel (y, x) of the plane to pixel (2y + py, 2x + px) of the FULL-resolution padded tensor C (row stride ldc;
+// (2 Hp - 2) x (2 Wp - 2) padded pixels per image) and adds R (optional, same layout; may be C itself) there -- the
+// depth-to-space scatter of the downsample dgrad without a pass of its own.  Four launches (one per plane) cover every
+// interior pixel of C exactly once; C's halo is not touched.
+int siss_gemm_nt_d2s(const void* A, long lda, const void* W, void* C, long ldc, const void* R, long ldr, int M, int N,
+                     int Kp, int npanels, const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp,
+                     int plane, void* stream) {
+    SISS_CHECK_ARG(plane >= 0 && plane < 4);
+    return gemm_nt_dispatch(A, lda, W, C, ldc, nullptr, nullptr, N, R, ldr, M, N, Kp, npanels, shifts, coffs,
+                            rows_per_image, Hp, Wp, 1.0f, 1, 0, 0, 0, nullptr, 0, stream, nullptr, nullptr, 1 + plane);
 }
 
 // floats in the `qstats` buffer of a product with M rows and N output channels

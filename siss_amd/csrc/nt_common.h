@@ -23,6 +23,8 @@ struct NTParams {
     float* slab;                      //      ([tile][split][BM*BN] in accumulator order); the LAST block of a tile to arrive
     int* tile_ctr;                    //      (arrival counters, one per tile, zero between launches) sums them and runs the epilogue
     long long* dbg;                   // timing probe buffer (SISS_NT_DEBUG_PTR), normally null
+    int d2s;                          // 0, or 1 + plane: rows are pixels of space-to-depth plane (py, px) = (plane >> 1, plane & 1); the epilogue
+                                      // writes (and reads R) at the pixel's place in the FULL-resolution tensor (2 Hp - 2) x (2 Wp - 2) padded
     float* qstats;                    // optional (persistent 3x3 kernel only): per-(half tile, image slot, 4-channel quad) sums and
                                       // sums of squares of the bf16 OUTPUT, [2 * row tiles][2][N / 4][2] f32 -- the GroupNorm that
                                       // consumes the result folds them instead of reading the tensor a second time
@@ -99,12 +101,22 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
         const int r = m0 + row;
         if (r >= p.M || row >= vrows) break;
         u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * kCRow + chunk * 16);
+        long ro = r;                          // output (and residual) row
         if (p.Hp > 0) {
-            const int rem = r - (img0 + (row >= b1) + (row >= b2)) * rpi;
+            const int img = img0 + (row >= b1) + (row >= b2);
+            const int rem = r - img * rpi;
             const int y = (int)(((float)rem + 0.5f) * p.inv_wp), x = rem - y * p.Wp;   // exact: see header note
-            if ((y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1)) o = u32x4_t{0u, 0u, 0u, 0u};
+            const bool halo = (y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1);
+            if (p.d2s) {
+                // depth-to-space in the epilogue (stride-2 conv dgrad): this plane's pixel (y, x) is pixel (2y + py, 2x + px) of the
+                // full-resolution tensor; the plane's halo rows have no place there (its halo is zero already and stays so)
+                if (halo) continue;
+                const int pl = p.d2s - 1, wf = 2 * p.Wp - 2;
+                ro = (long)img * (2 * p.Hp - 2) * wf + (long)(2 * y - 1 + (pl >> 1)) * wf + (2 * x - 1 + (pl & 1));
+            }
+            if (halo) o = u32x4_t{0u, 0u, 0u, 0u};
             else if (p.R && nc + 8 <= p.N) {
-                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + (long)r * p.ldr + nc);
+                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(p.R + (long)bz * p.strideC + ro * p.ldr + nc);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
@@ -119,14 +131,14 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
                 o[e] = p.mul_r ? pack_bf2(o0 * r0, o1 * r1) : pack_bf2(o0 + r0, o1 + r1);
             }
         }
-        bf16_t* dst = C + (long)r * p.ldc + nc;
+        bf16_t* dst = C + ro * p.ldc + nc;
         if (nc + 8 <= p.N) {
             *reinterpret_cast<u32x4_t*>(dst) = o;
         } else {        // ragged N tail (N % 8 != 0 never happens for channel counts; kept for safety)
             for (int e = 0; e < 8 && nc + e < p.N; ++e) {
                 const uint32_t wv = o[e >> 1];
                 float v = (e & 1) ? __builtin_bit_cast(float, wv & 0xffff0000u) : __builtin_bit_cast(float, wv << 16);
-                if (p.R) v += bf2f(p.R[(long)bz * p.strideC + (long)r * p.ldr + nc + e]);
+                if (p.R) v += bf2f(p.R[(long)bz * p.strideC + ro * p.ldr + nc + e]);
                 dst[e] = f2bf(v);
             }
         }

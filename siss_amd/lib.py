@@ -34,6 +34,7 @@ SIGNATURES = {
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_nt_qstats": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, P, IP, P],
     "siss_conv_qstats_words": [L, I],
+    "siss_gemm_nt_d2s": [P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, I, P],
     "siss_gemm_nt_set_workspace": [P, L],
     "siss_gemm_nt_set_c3p_blocks": [I],
     "siss_dispatch_count": [I],
@@ -280,6 +281,10 @@ def call(name, *args):
         # variants that only add operands are booked under their plain form (same work, same shape key)
         if name == "siss_gemm_nt_qstats":
             name, args = "siss_gemm_nt", list(args[:20]) + [1, 0, 0, 0]
+        elif name == "siss_gemm_nt_d2s":
+            a = args
+            name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], None, None, a[8], a[5], a[6], a[7], a[8], a[9], a[10],
+                                          a[11], a[12], a[13], a[14], a[15], 1.0, 1, 0, 0, 0]
         elif name == "siss_groupnorm_fwd_qs":
             name, args = "siss_groupnorm_fwd_ld", list(args[:7]) + list(args[10:])
         base = name[:-3] if name.endswith("_ld") else name          # row-stride variants count as their plain form

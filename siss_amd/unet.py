@@ -155,6 +155,7 @@ class ParamStore:
 class UNetEngine:
     """Static-schedule UNet.  ``forward(x, t)`` then ``backward(c, nsets)``."""
     epi_stats = os.environ.get("SISS_GN_EPI_STATS", "1") != "0"    # (class default: subclasses with their own __init__, e.g. VAEEncoder)
+    d2s_epilogue = os.environ.get("SISS_D2S_EPILOGUE", "1") != "0"  # downsample dgrad: depth-to-space in the plane GEMMs' epilogue
 
     def __init__(self, cfg: UNet2DConfig, device="cuda"):
         lib.load()
@@ -848,21 +849,32 @@ class UNetEngine:
             dy = self._take(y)
             dW = ps.grads[gb:, ps.specs[pre + ".conv.weight"].off:]
             self._wgrad(dy, z, dW, C, C, 3, shifts=shifts, coffs=coffs, ldx=4 * C, dbias=ps.g(pre + ".conv.bias", gb))
-            dz = self._get(nb, Ho, Wo, 4 * C)
-            pos = 0
-            for plane in sorted(planes):
-                taps = planes[plane]
-                ops.gemm_nt(lib.ptr(dy.data), C, wds[pos:], lib.ptr(dz.data[:, plane * C:]), 4 * C, dy.rows, C, C,
-                            [-shifts[tap] for tap in taps], [0] * len(taps),
-                            rows_per_image=dy.rows_per_image, hp=dy.hp, wp=dy.wp)
-                pos += len(taps)
-            self._put(dy)
             acc = self.gmap.get(id(x))
             self._wsync(acc)
             dx = acc if acc is not None else self._get(nb, x.h, x.w, C)
-            lib.call("siss_depth_to_space", dz.data, dx.data, int(acc is not None), nb, x.h, x.w, C)
+            pos = 0
+            if self.d2s_epilogue:
+                # each plane GEMM writes its pixels straight to their place in dx (and adds the cotangent x already has):
+                # no dz tensor, no depth-to-space pass
+                for plane in sorted(planes):
+                    taps = planes[plane]
+                    lib.call("siss_gemm_nt_d2s", dy.data, C, wds[pos:], dx.data, C, dx.data if acc is not None else None, C,
+                             dy.rows, C, C, len(taps), lib.int_array([-shifts[tap] for tap in taps]),
+                             lib.int_array([0] * len(taps)), dy.rows_per_image, dy.hp, dy.wp, plane)
+                    pos += len(taps)
+                self._put(dy)
+            else:
+                dz = self._get(nb, Ho, Wo, 4 * C)
+                for plane in sorted(planes):
+                    taps = planes[plane]
+                    ops.gemm_nt(lib.ptr(dy.data), C, wds[pos:], lib.ptr(dz.data[:, plane * C:]), 4 * C, dy.rows, C, C,
+                                [-shifts[tap] for tap in taps], [0] * len(taps),
+                                rows_per_image=dy.rows_per_image, hp=dy.hp, wp=dy.wp)
+                    pos += len(taps)
+                self._put(dy)
+                lib.call("siss_depth_to_space", dz.data, dx.data, int(acc is not None), nb, x.h, x.w, C)
+                self._put(dz)
             self.gmap[id(x)] = dx
-            self._put(dz)
         self.tape.append(bwd)
         return y
 

@@ -397,6 +397,40 @@ def test_direct_concat_writes_equal_the_copying_concat(monkeypatch):
     assert v.ld == 24 and tuple(v.data.shape) == (v.rows, 16) and v.data.data_ptr() == v.base.data.data_ptr()
 
 
+def test_depth_to_space_in_the_dgrad_epilogue_equals_the_separate_pass():
+    """Downsample2D backward: the four plane GEMMs write their pixels straight to their place in dx (siss_gemm_nt_d2s, adding the
+    cotangent x already carries) instead of a dz tensor + siss_depth_to_space.  Same products, same bf16 roundings in the same
+    order -> the gradients agree up to the wgrad atomics' summation order (delete_celeb.py:691,:702 differentiate through
+    diffusers' Downsample2D)."""
+    from siss_amd import lib
+    from siss_amd.unet import UNetEngine
+    hc, _ = _cfgs()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 3, 16, 16, generator=g).cuda()
+    t = torch.tensor([999, 500, 3, 999]).cuda()
+    cot = (torch.randn(8, 3, 16, 16, generator=g) * 1e-2).cuda()
+    outs = {}
+    for fused in (True, False):
+        eng = UNetEngine(hc, "cuda:0")
+        eng.init_random(seed=1)
+        eng.d2s_epilogue = fused
+        calls = []
+        orig = lib.call
+        lib.call = lambda name, *a, _o=orig, _c=calls: (_c.append(name), _o(name, *a))[1]
+        try:
+            eng.forward(x, t)
+            eng.zero_grad()
+            eng.backward(cot, nsets=2)
+            torch.cuda.synchronize()
+        finally:
+            lib.call = orig
+        outs[fused] = (eng.ps.grads.clone(), calls)
+    assert outs[True][1].count("siss_gemm_nt_d2s") == 4 and outs[True][1].count("siss_depth_to_space") == 0
+    assert outs[False][1].count("siss_gemm_nt_d2s") == 0 and outs[False][1].count("siss_depth_to_space") == 1
+    ga, gb = outs[True][0], outs[False][0]
+    assert float((ga - gb).norm() / gb.norm()) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # a-6: the statistics block the reference logs every micro-step (delete_celeb.py:626-663) -- every key the reference
 # emits for the objective, against the oracle's literal restatement (oracle/step.py::batch_stats) on the same step.
