@@ -74,8 +74,11 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         const int prow = lane >> 3, pc = lane & 7;
         const unsigned smem_a = lds_addr(smem);
         int gk = 0, gky = 0, gkc = 0, issued = 0;          // group cursor: (tile k, filter row ky, K chunk kc)
-        const bf16_t* asrc[8];
-        const bf16_t* wsrc[4];
+        // LDS-DMA sources as 32-bit byte offsets from a wave-uniform base (the saddr form of global_load_lds: address = SGPR pair +
+        // VGPR offset): per piece the store waves issue s_mov m0 + the load and NO vector arithmetic -- the 64-bit per-lane
+        // pointer form cost a v_lshl_add_u64 and an m0 save / restore per piece, on a SIMD they share with an MFMA wave.
+        // (m0 is a reserved register the compiler sets itself before each of its own uses; nothing here relies on its value.)
+        unsigned aoffs[8], woffs[4];
         auto set_tile = [&](int k) {
             const int t = tm.tile(k);
             const int m0 = (t / tm.tiles_n) * P_VALID, n0 = (t % tm.tiles_n) * BN;
@@ -83,26 +86,31 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             for (int j = 0; j < 8; ++j) {
                 const int row = (pw * 8 + j) * 8 + prow;
                 int gr = m0 + row; gr = gr < p.M + 1 ? gr : p.M + 1;
-                asrc[j] = p.A + (long)gr * p.lda + ((pc ^ swz3p(row)) << 3);
+                aoffs[j] = (unsigned)(((long)gr * p.lda + ((pc ^ swz3p(row)) << 3)) * 2);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = (pw * 4 + j) * 8 + prow;
-                wsrc[j] = p.W + (long)(n0 + row) * p.Kp + ((pc ^ swz3p(row)) << 3);
+                woffs[j] = (unsigned)(((long)(n0 + row) * p.Kp + ((pc ^ swz3p(row)) << 3)) * 2);
             }
+        };
+        auto dma = [&](unsigned off, const void* base, unsigned dst) __attribute__((always_inline)) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(off), "s"(dst), "s"(base) : "memory");
         };
         auto issue_group = [&]() {
             const long aoff = (long)p.shift[3 * gky] * p.lda + p.coff[3 * gky] + gkc * BK;
             const long woff = 3L * gky * wtap + gkc * BK;
             const unsigned dst = smem_a + (issued & 1) * P_SLOT;
             if (!((p.ablate & 2) && issued >= 2)) {
+                const bf16_t* abase = p.A + aoff;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) glds16_asm(asrc[j] + aoff, dst + (pw * 8 + j) * 1024);
+                for (int j = 0; j < 8; ++j) dma(aoffs[j], abase, dst + (pw * 8 + j) * 1024);
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < 3; ++t) {
+                    const bf16_t* wbase = p.W + woff + t * wtap;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        glds16_asm(wsrc[j] + woff + t * wtap, dst + P_ABYTES + t * P_WBYTES + (pw * 4 + j) * 1024);
+                    for (int j = 0; j < 4; ++j) dma(woffs[j], wbase, dst + P_ABYTES + t * P_WBYTES + (pw * 4 + j) * 1024);
+                }
             }
             ++issued;
             if (++gkc == kchunks) { gkc = 0; if (++gky == 3) { gky = 0; ++gk; if (gk < count) set_tile(gk); } }
