@@ -435,11 +435,15 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
         if (conv3 && Kp % 64 == 0 && N % BN == 0 && rows_per_image >= 256 && (c3 == 1 || (c3 == 2 && tiles >= c3_min))) {
             static int c3p = -1;
             if (c3p < 0) { const char* e = getenv("SISS_NT_C3P"); c3p = e ? atoi(e) : 1; }   // persistent producer/consumer variant
-            if (c3p && qstats && Hp > 0 && ((uintptr_t)qstats % 16) == 0) {
+            // (the persistent kernel addresses C and R by 32-bit byte offsets: tensors of 4 GiB and more take the one-tile kernel)
+            bool persistent = c3p != 0;
+            if ((long)M * ldc * 2 >= (1L << 32) || (R && (long)M * ldr * 2 >= (1L << 32)) || (long)(M + 2) * lda * 2 >= (1L << 32) ||
+                (long)N * Kp * 2 >= (1L << 32)) persistent = false;
+            if (persistent && qstats && Hp > 0 && ((uintptr_t)qstats % 16) == 0) {
                 p.qstats = qstats;                          // only the persistent kernel forms them; the caller is told
                 if (qstats_written) *qstats_written = 1;
             }
-            return c3p ? siss_launch_gemm_nt_c3p(&p, stream) : siss_launch_gemm_nt_c3(&p, stream);
+            return persistent ? siss_launch_gemm_nt_c3p(&p, stream) : siss_launch_gemm_nt_c3(&p, stream);
         }
         if (conv3 && (use3 == 1 || (use3 == 2 && tiles >= 1024))) return siss_launch_gemm_nt_conv3(&p, stream);
     }

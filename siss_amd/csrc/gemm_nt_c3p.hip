@@ -164,15 +164,21 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             const int split = (img0 + 1) * rpi;            // first row of the second image
             const bool straddle = m0 + P_BM > split;       // (uniform) the tile's last rows belong to the next image
             const int ccol = n0 + wn * 64 + pc * 8;
+            // Row addresses as 32-bit byte offsets from the (scalar) tensor bases: one multiply per lane and tile half, then a
+            // scalar stride per row -- the 64-bit form cost two quarter-rate v_mul_lo_u32 + a v_mad_u64_u32 per stored row in
+            // waves that share their SIMD with an MFMA wave.  (siss_launch_gemm_nt_c3p checks that C and R span < 4 GiB.)
+            const unsigned row0 = (unsigned)(m0 + wm * 128 + half * 64 + prow);
+            const unsigned coff0 = (row0 * (unsigned)p.ldc + (unsigned)ccol) * 2u, cstep = (unsigned)p.ldc * 16u;
             u32x4_t res[HAS_R ? 8 : 1];
             if constexpr (HAS_R) {
                 // all residual loads, then ONE wait, before the first store: vmcnt counts loads and stores in one
                 // in-order queue on gfx9 -- a load waited for after a store would wait for that store's round trip
+                const unsigned roff0 = (row0 * (unsigned)p.ldr + (unsigned)ccol) * 2u, rstep = (unsigned)p.ldr * 16u;
+                const unsigned rlast = ((unsigned)(p.M - 1) * (unsigned)p.ldr + (unsigned)ccol) * 2u;   // rows past M read the last row
 #pragma unroll
                 for (int i8 = 0; i8 < 8; ++i8) {
-                    const int row = wm * 128 + (half * 8 + i8) * 8 + prow;
-                    int r = m0 + row; r = r < p.M ? r : p.M - 1;
-                    res[i8] = *reinterpret_cast<const u32x4_t*>(p.R + (long)r * p.ldr + ccol);
+                    unsigned ro = roff0 + i8 * rstep; ro = ro < rlast ? ro : rlast;
+                    res[i8] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.R) + ro);
                 }
 #pragma unroll
                 for (int i8 = 0; i8 < 8; ++i8) asm volatile("" : "+v"(res[i8]));
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                         o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
                                         __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
                 }
-                *reinterpret_cast<u32x4_t*>(p.C + (long)r * p.ldc + ccol) = o;
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(p.C) + (coff0 + i8 * cstep)) = o;
                 if constexpr (QS) {
                     // statistics of the STORED values (halo rows are zero and add nothing) straight from the packed bf16 pairs:
                     // v_dot2c_f32_bf16 (acc += a.lo * b.lo + a.hi * b.hi) against (1, 1) gives the sum, against itself the
@@ -430,6 +436,8 @@ int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     static int ilv = -1;
     if (ilv < 0) { const char* e = getenv("SISS_NT_C3P_ILV"); ilv = e ? atoi(e) : 1; }   // measured +2.6 % (1064 -> 1092 TF/s over the 98 launches of a step)
     const bool qs = p.qstats != nullptr;
+    // 32-bit byte offsets in the store path (callers: gemm_nt_dispatch falls back to the one-tile-per-block kernel otherwise)
+    if ((long)p.M * p.ldc * 2 >= (1L << 32) || (p.R && (long)p.M * p.ldr * 2 >= (1L << 32))) return SISS_ERR_ARG;
     using kern_t = void (*)(const NTParams);
     const kern_t kern = ilv ? (qs ? gemm_nt_c3p_kernel<true, true> : gemm_nt_c3p_kernel<true, false>)
                             : (qs ? gemm_nt_c3p_kernel<false, true> : gemm_nt_c3p_kernel<false, false>);
