@@ -40,6 +40,17 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// (a.lo + b.lo, a.hi + b.hi) of two packed bf16 pairs: f32 adds, ONE rounding (RNE) by v_cvt_pk_bf16_f32 -- 7 instructions.  The
+// conversion is inline asm: written with casts the SLP vectoriser pairs the additions of DIFFERENT words and re-interleaves the
+// halves with two more SDWA ors per word.
+__device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b) {
+    const float lo = __builtin_bit_cast(float, a << 16) + __builtin_bit_cast(float, b << 16);
+    const float hi = __builtin_bit_cast(float, a & 0xffff0000u) + __builtin_bit_cast(float, b & 0xffff0000u);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -432,7 +432,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
         if (c3 < 0) { const char* e = getenv("SISS_NT_C3"); c3 = e ? atoi(e) : 2; }   // 0 off, 1 always, 2 grids of >= SISS_NT_C3_MIN_TILES 128-row tiles
         static long c3_min = -1;
         if (c3_min < 0) { const char* e = getenv("SISS_NT_C3_MIN_TILES"); c3_min = e ? atol(e) : 256; }   // measured (round 1, sweep 2048 .. 32): 256 gives the shortest step
-        if (conv3 && Kp % 64 == 0 && N % BN == 0 && rows_per_image >= 256 && (c3 == 1 || (c3 == 2 && tiles >= c3_min))) {
+        if (conv3 && Kp % 64 == 0 && N % BN == 0 && rows_per_image >= 256 && (Wp == 0 || Wp >= 8) && (c3 == 1 || (c3 == 2 && tiles >= c3_min))) {
             static int c3p = -1;
             if (c3p < 0) { const char* e = getenv("SISS_NT_C3P"); c3p = e ? atoi(e) : 1; }   // persistent producer/consumer variant
             // (the persistent kernel addresses C and R by 32-bit byte offsets: tensors of 4 GiB and more take the one-tile kernel)

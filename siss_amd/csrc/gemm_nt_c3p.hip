@@ -183,26 +183,35 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
 #pragma unroll
                 for (int i8 = 0; i8 < 8; ++i8) asm volatile("" : "+v"(res[i8]));
             }
+            // Image-relative pixel coordinates of this lane's first row of the half; its next rows are 8 apart (Wp >= 8: at most one
+            // row wrap per step; y == Hp is row 0 of the next image).  The row loop below is branch-free up to the one store
+            // predicate: per-row branches (skip / halo / residual) cost more scalar and exec traffic than the arithmetic they saved.
+            int py = 1, px = 1;
+            if (p.Hp > 0) {
+                const int r0i = (int)row0;
+                const int rem = r0i - img0 * rpi - (r0i >= split ? rpi : 0);
+                py = (int)(((float)rem + 0.5f) * p.inv_wp); px = rem - py * p.Wp;
+            }
+            const int ylast = p.Hp > 0 ? p.Hp - 1 : 1 << 30, xlast = p.Hp > 0 ? p.Wp - 1 : 1 << 30, wrap = p.Hp > 0 ? p.Wp : 1 << 30;
 #pragma unroll
             for (int i8 = 0; i8 < 8; ++i8) {
                 const int row = wm * 128 + (half * 8 + i8) * 8 + prow;
                 const int r = m0 + row;
-                if (row >= P_VALID || r >= p.M) continue;
                 u32x4_t o = half ? ov[8 + i8] : ov[i8];
-                bool halo = false;
-                if (p.Hp > 0) {
-                    const int rem = r - img0 * rpi - (r >= split ? rpi : 0);
-                    const int y = (int)(((float)rem + 0.5f) * p.inv_wp), x = rem - y * p.Wp;
-                    halo = (y == 0) | (y == p.Hp - 1) | (x == 0) | (x == p.Wp - 1);
-                }
-                if (halo) o = u32x4_t{0u, 0u, 0u, 0u};
-                else if constexpr (HAS_R) {
+                if constexpr (HAS_R) {
                     const u32x4_t rr = res[i8];
+                    // bf16 + bf16: f32 add, one rounding (the reference's `x + h` under autocast).  (`__bf16` vector arithmetic on the
+                    // elements of a u32x4 is miscompiled by hipcc 7.2 -- every element got element 0's sum -- hence the helper.)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o[e] = pack_bf2(__builtin_bit_cast(float, o[e] << 16) + __builtin_bit_cast(float, rr[e] << 16),
-                                        __builtin_bit_cast(float, o[e] & 0xffff0000u) + __builtin_bit_cast(float, rr[e] & 0xffff0000u));
+                    for (int e = 0; e < 4; ++e) o[e] = add_bf16x2(o[e], rr[e]);
                 }
+                const bool halo = (py == 0) | (py == ylast) | (px == 0) | (px == xlast);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = halo ? 0u : o[e];
+                px += 8;
+                if (px >= wrap) { px -= wrap; ++py; }
+                if (py > ylast) py = 0;
+                if (row >= P_VALID || r >= p.M) continue;
                 *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(p.C) + (coff0 + i8 * cstep)) = o;
                 if constexpr (QS) {
                     // statistics of the STORED values (halo rows are zero and add nothing) straight from the packed bf16 pairs:
