@@ -105,6 +105,12 @@ __device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
 }
+// The same with the address as wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset (the `saddr` form): no vector
+// arithmetic per piece when only the base moves between pieces, and m0 is simply set -- it is a reserved register that
+// compiler-generated code sets itself before each of its own uses, so there is nothing to preserve.
+__device__ __forceinline__ void glds16_saddr(unsigned off, const void* base, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(off), "s"(lds_dst), "s"(base) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }

@@ -124,6 +124,35 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
     }
     const long ystep = (long)BR * p.ldy, xstep = (long)BR * p.ldx;
     const unsigned smem_a = lds_addr(smem);
+    // Fast form of stage() for the steps whose rows all lie inside [r0, r1) of a tile with all 128 + 128 columns (every step but
+    // the last one or two of full tiles): wave-uniform 64-bit base per step + per-lane 32-bit offsets fixed for the block, so a
+    // piece is s_mov m0 + the load.  The general form below spends, per piece, a compare, two selects against the zero page, a
+    // 64-bit add and an m0 save / restore -- ~65 instructions per step in waves that also issue 48 MFMAs and 40 LDS reads.
+    const bool full_tile = n0 + BN <= p.N && c0 + BC <= p.C;
+    unsigned yoff32[NP], xoff32[NP], xoff32_extra = 0;
+    const bf16_t* const ybase0 = p.Y + ((long)set * p.rows_per_set + r0) * p.ldy + n0;
+    const bf16_t* const xbase0 = p.X + xrow0 * p.ldx + p.coff[pn] + c0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = (w * NP + j) * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ swz(row);
+        yoff32[j] = (unsigned)(((long)row * p.ldy + lc * 8) * 2);
+        xoff32[j] = (unsigned)(((long)row * p.ldx + lc * 8) * 2);
+    }
+    if (TAPS == 3) {
+        const int row = BR + (lane >> 4);
+        xoff32_extra = (unsigned)(((long)row * p.ldx + ((lane & 15) ^ swz(row)) * 8) * 2);
+    }
+    auto stage_fast = [&](int buf, int step) {
+        const unsigned base = smem_a + buf * C_::kStageBytes + (w * NP * 4) * 256;
+        const bf16_t* yb = ybase0 + step * ystep;
+        const bf16_t* xb = xbase0 + step * xstep;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16_saddr(yoff32[j], yb, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16_saddr(xoff32[j], xb, base + kYTile + j * 1024);
+        if (TAPS == 3 && w == 0) glds16_saddr(xoff32_extra, xb, smem_a + buf * C_::kStageBytes + kYTile + BR * 256);
+    };
     auto stage = [&](int buf, int step) {
         const unsigned base = smem_a + buf * C_::kStageBytes + (w * NP * 4) * 256;
         const int rbase = r0 + step * BR;
@@ -266,10 +295,12 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
             for (int s = 0; s < steps; ++s) {
                 const int b1 = (buf + 1) & 3, b3 = (buf + 3) & 3;
                 const bool more = s + 3 < steps;
-                if (more && early) stage(b3, s + 3);
+                // (all rows of step s + 3 in range: its Y rows and the X rows two past them)
+                const bool fast = full_tile && r0 + (s + 4) * BR + 4 <= r1;
+                if (more && early) { if (fast) stage_fast(b3, s + 3); else stage(b3, s + 3); }
                 __builtin_amdgcn_sched_barrier(0);
                 half(yf[0], xf[0], yf[1], xf[1], smem + buf * SB, 1);
-                if (more && !early) stage(b3, s + 3);
+                if (more && !early) { if (fast) stage_fast(b3, s + 3); else stage(b3, s + 3); }
                 __builtin_amdgcn_sched_barrier(0);
                 half(yf[1], xf[1], yf[0], xf[0], smem + b1 * SB, 0);
                 if (more) {
