@@ -315,7 +315,9 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
         } else
         for (int s = 0; s < steps; ++s) {
             const int b1 = buf + 1 == 3 ? 0 : buf + 1, b2 = b1 + 1 == 3 ? 0 : b1 + 1;
-            if (s + 2 < steps) stage(b2, s + 2);
+            if (s + 2 < steps) {
+                if (full_tile && r0 + (s + 3) * BR + 4 <= r1) stage_fast(b2, s + 2); else stage(b2, s + 2);
+            }
             const char* sb = smem + buf * SB;
             const char* sbn = smem + b1 * SB;
             // half-step kk = 0
@@ -356,7 +358,9 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
             const int buf = s & 1;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (s + 1 < steps) stage(buf ^ 1, s + 1);
+            if (s + 1 < steps) {
+                if (full_tile && r0 + (s + 2) * BR + 4 <= r1) stage_fast(buf ^ 1, s + 1); else stage(buf ^ 1, s + 1);
+            }
             const char* sb = smem + buf * C_::kStageBytes;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
