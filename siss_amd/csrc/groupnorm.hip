@@ -48,21 +48,35 @@ __device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
 // Walks the interior pixels pi = p0+slot, +ppi, ... of one image; keeps (y, x) incrementally so the
 // hot loop has no integer division.  row() = padded row index within the image.
 struct PixelWalk {
-    int pi, p1, y, x, W, ppi, dy, dx;
+    int pi, p1, x, W, ppi, dx, rw, drw;
     __device__ __forceinline__ PixelWalk(const GNShape& s, int chunk, int slot) {
         const int p0 = chunk * s.chunk_px;
         p1 = p0 + s.chunk_px; p1 = p1 < s.H * s.W ? p1 : s.H * s.W;
         pi = p0 + slot; W = s.W; ppi = s.ppi;
-        y = pi / W; x = pi - y * W;
-        dy = ppi / W; dx = ppi - dy * W;
+        const int y = pi / W; x = pi - y * W;
+        const int dy = ppi / W; dx = ppi - dy * W;
+        rw = (y + 1) * (W + 2) + (x + 1);              // padded row of (y, x) within the image ...
+        drw = dy * (W + 2) + dx;                        // ... and what a step adds to it (+ 2 halo pixels when x wraps)
     }
     __device__ __forceinline__ bool ok() const { return pi < p1; }
-    __device__ __forceinline__ long row() const { return (long)(y + 1) * (W + 2) + (x + 1); }
+    __device__ __forceinline__ int row() const { return rw; }
     __device__ __forceinline__ void next() {
-        pi += ppi; y += dy; x += dx;
-        if (x >= W) { x -= W; ++y; }
+        pi += ppi; x += dx; rw += drw;
+        if (x >= W) { x -= W; rw += 2; }
     }
 };
+
+// Addresses are a wave-uniform 64-bit base (sample, channel slice: SGPRs) + a 32-bit per-lane byte offset = row * row bytes
+// (v_mul_u32_u24: full rate; rows < 2^24, row bytes < 2^24, one sample < 4 GiB) + the lane's channel offset: two vector
+// instructions per access where pointer arithmetic in 64 bits cost two quarter-rate v_mul_lo_u32, a v_mad_u64_u32 and
+// 64-bit adds -- a quarter of the vector work of these VALU-co-limited kernels.
+__device__ __forceinline__ unsigned boff(int row, unsigned row_bytes, unsigned lane_bytes) { return __umul24(row, row_bytes) + lane_bytes; }
+__device__ __forceinline__ u32x4_t ld16(const bf16_t* base, unsigned off) {
+    return *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ void st16(bf16_t* base, unsigned off, u32x4_t v) {
+    *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(base) + off) = v;
+}
 
 // Block-level reduction over the pixel slots WITHOUT atomics (deterministic): every active thread parks its
 // 8 per-channel partial sums in LDS as red[slot][C], then thread c < C adds the slots of channel c.
@@ -94,14 +108,15 @@ __global__ __launch_bounds__(kThreads) void gn_stats_kernel(const bf16_t* __rest
     const bool active = slot < s.ppi;
     float a[8] = {}, b[8] = {};
     if (active) {
-        const bf16_t* base = x + (long)n * (s.H + 2) * (s.W + 2) * s.ldx + c0 + cc * 8;
+        const bf16_t* base = x + (long)n * (s.H + 2) * (s.W + 2) * s.ldx + c0;
+        const unsigned xb = s.ldx * 2, lb = cc * 16;
         PixelWalk w(s, chunk, slot);
         while (w.ok()) {                       // two pixels per trip: both loads are in flight together
-            const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ldx);
+            const u32x4_t r0 = ld16(base, boff(w.row(), xb, lb));
             w.next();
             const bool two = w.ok();
             u32x4_t r1 = u32x4_t{0u, 0u, 0u, 0u};
-            if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ldx); w.next(); }
+            if (two) { r1 = ld16(base, boff(w.row(), xb, lb)); w.next(); }
             float v[8], u[8];
             unpack8(r0, v); unpack8(r1, u);
 #pragma unroll
@@ -185,18 +200,19 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
         sf[e] = beta[c0 + c] - sh_mean[g] * sc[e];
     }
     const long img = (long)n * (s.H + 2) * (s.W + 2);
-    const bf16_t* base = x + img * s.ldx + c0 + cc * 8;
-    y += c0;
-    auto out_row = [&](const PixelWalk& w) { return out_compact ? compact_row(n, w.pi, s.H, s.W) : img + w.row(); };
+    const bf16_t* base = x + img * s.ldx + c0;
+    const unsigned xb = s.ldx * 2, ob = s.ld * 2, lb = cc * 16;
+    bf16_t* const ybase = y + c0 + (out_compact ? (long)n * s.H * s.W : img) * s.ld;
+    auto out_off = [&](const PixelWalk& w) { return boff(out_compact ? w.pi : w.row(), ob, lb); };
     PixelWalk w(s, chunk, slot);
     while (w.ok()) {
-        const u32x4_t r0 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ldx);
-        const long o0 = out_row(w);
+        const u32x4_t r0 = ld16(base, boff(w.row(), xb, lb));
+        const unsigned o0 = out_off(w);
         w.next();
         const bool two = w.ok();
         u32x4_t r1 = u32x4_t{0u, 0u, 0u, 0u};
-        long o1 = 0;
-        if (two) { r1 = *reinterpret_cast<const u32x4_t*>(base + w.row() * s.ldx); o1 = out_row(w); w.next(); }
+        unsigned o1 = 0;
+        if (two) { r1 = ld16(base, boff(w.row(), xb, lb)); o1 = out_off(w); w.next(); }
         float v[8], u[8];
         unpack8(r0, v); unpack8(r1, u);
 #pragma unroll
@@ -205,8 +221,8 @@ __global__ __launch_bounds__(kThreads) void gn_apply_kernel(
             v[e] = SILU ? silu_f(z0) : z0;
             u[e] = SILU ? silu_f(z1) : z1;
         }
-        *reinterpret_cast<u32x4_t*>(y + o0 * s.ld + cc * 8) = pack8(v);
-        if (two) *reinterpret_cast<u32x4_t*>(y + o1 * s.ld + cc * 8) = pack8(u);
+        st16(ybase, o0, pack8(v));
+        if (two) st16(ybase, o1, pack8(u));
     }
 }
 
@@ -282,19 +298,21 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
             ga[e] = gamma[c]; be[e] = beta[c];
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
-        const bf16_t* xb = x + (long)n * rpi * s.ldx + c0 + cc * 8;
+        const bf16_t* xbase = x + (long)n * rpi * s.ldx + c0;
+        const bf16_t* dbase[SETS];                    // cotangent sample n2 = k * nx + n of each set (dy already points at c0)
+#pragma unroll
+        for (int k = 0; k < SETS; ++k)
+            dbase[k] = dy + (dy_compact ? (long)(k * nx + n) * s.H * s.W : (long)(k * nx + n) * rpi) * s.ld;
+        const unsigned xb = s.ldx * 2, db = s.ld * 2, lb = cc * 16;
         // Software pipeline: the loads of pixel i+1 (x + one dy per set) are issued BEFORE pixel i is consumed, so
         // the memory pipe never drains while the SiLU' arithmetic runs (4-5 waves per SIMD only).
         PixelWalk w(s, chunk, slot);
         u32x4_t nx_x = u32x4_t{0u, 0u, 0u, 0u}, nx_d[SETS];
         auto issue = [&](const PixelWalk& q, u32x4_t& ox, u32x4_t (&od)[SETS]) {
-            ox = *reinterpret_cast<const u32x4_t*>(xb + q.row() * s.ldx);
+            ox = ld16(xbase, boff(q.row(), xb, lb));
+            const unsigned doff = boff(dy_compact ? q.pi : q.row(), db, lb);
 #pragma unroll
-            for (int k = 0; k < SETS; ++k) {
-                const int n2 = k * nx + n;
-                const long drow = dy_compact ? compact_row(n2, q.pi, s.H, s.W) : (long)n2 * rpi + q.row();
-                od[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.ld + cc * 8);
-            }
+            for (int k = 0; k < SETS; ++k) od[k] = ld16(dbase[k], doff);
         };
         if (w.ok()) issue(w, nx_x, nx_d);
         while (w.ok()) {
@@ -387,29 +405,40 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
             for (int k = 0; k < SETS; ++k) { m1[k][e] = sh_s1[k][g]; m2[k][e] = sh_s2[k][g]; }
         }
         const long rpi = (long)(s.H + 2) * (s.W + 2);
-        const bf16_t* xb = x + (long)n * rpi * s.ldx + c0 + cc * 8;
+        const bf16_t* xbase = x + (long)n * rpi * s.ldx + c0;
         const int ch = c0 + cc * 8;                       // first channel of this lane in the full tensor
         // Output routing: one tensor of C channels, or (dx2 != null: the input was a channel concat)
         // channels [0, split_c) -> dx (row stride split_c) and [split_c, C) -> dx2 (row stride C - split_c,
         // optionally accumulated): the concat backward costs no extra pass.
         const bool second = dx2 != nullptr && ch >= split_c;
-        bf16_t* const obase = second ? dx2 + (ch - split_c) : dx + ch;
         const int ostride = dx2 ? (second ? s.ld - split_c : split_c) : s.ld;
         const bool oacc = second && accumulate2;
+        const bool any_oacc = dx2 != nullptr && accumulate2;      // (uniform) some lanes of the block accumulate into dx2
+        // per set: wave-uniform bases of the sample's cotangent / running cotangents, per-lane base of its output rows
+        const bf16_t* dbase[SETS]; const bf16_t* abase[SETS]; const bf16_t* bbase[SETS]; bf16_t* obase[SETS];
+#pragma unroll
+        for (int k = 0; k < SETS; ++k) {
+            const long n2 = k * nx + n;
+            dbase[k] = dy + c0 + (dy_compact ? n2 * s.H * s.W : n2 * rpi) * s.ld;
+            abase[k] = accum ? accum + c0 + n2 * rpi * s.ld : nullptr;
+            bbase[k] = accum2 ? accum2 + c0 + n2 * rpi * s.ld : nullptr;
+            obase[k] = (second ? dx2 + (ch - split_c) : dx + ch) + n2 * rpi * ostride;
+        }
+        const unsigned xb = s.ldx * 2, db = s.ld * 2, ob = ostride * 2, lb = cc * 16;
         // Software pipeline (as in the stats kernel): pixel i+1's loads are in flight while pixel i is computed and
         // stored.  Reading the next pixel's accum / output before this pixel's store is safe: different rows.
         struct In { u32x4_t x, d[SETS], a[SETS], b[SETS], c[SETS]; };
         auto issue = [&](const PixelWalk& q, In& o) {
-            o.x = *reinterpret_cast<const u32x4_t*>(xb + q.row() * s.ldx);
+            o.x = ld16(xbase, boff(q.row(), xb, lb));
+            const unsigned roff = boff(q.row(), db, lb);
+            const unsigned doff = dy_compact ? boff(q.pi, db, lb) : roff;
+            const unsigned ooff = __umul24(q.row(), ob);
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
-                const int n2 = k * nx + n;
-                const long orow = (long)n2 * rpi + q.row();
-                const long drow = dy_compact ? compact_row(n2, q.pi, s.H, s.W) : orow;
-                o.d[k] = *reinterpret_cast<const u32x4_t*>(dy + drow * s.ld + ch);
-                o.a[k] = accum ? *reinterpret_cast<const u32x4_t*>(accum + orow * s.ld + ch) : u32x4_t{0u, 0u, 0u, 0u};
-                o.b[k] = accum2 ? *reinterpret_cast<const u32x4_t*>(accum2 + orow * s.ld + ch) : u32x4_t{0u, 0u, 0u, 0u};
-                o.c[k] = oacc ? *reinterpret_cast<const u32x4_t*>(obase + orow * ostride) : u32x4_t{0u, 0u, 0u, 0u};
+                o.d[k] = ld16(dbase[k], doff);
+                if (accum) o.a[k] = ld16(abase[k], roff);
+                if (accum2) o.b[k] = ld16(bbase[k], roff);
+                if (any_oacc) o.c[k] = oacc ? ld16(obase[k], ooff) : u32x4_t{0u, 0u, 0u, 0u};
             }
         };
         PixelWalk w(s, chunk, slot);
@@ -417,15 +446,11 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
         if (w.ok()) issue(w, nxt);
         while (w.ok()) {
             const In cur = nxt;
-            const long wrow = w.row();
+            const unsigned ooff = __umul24(w.row(), ob);
             w.next();
             if (w.ok()) issue(w, nxt);
-            const u32x4_t rx = cur.x;
-            u32x4_t rd[SETS], ra[SETS], rb[SETS], rc[SETS];
-#pragma unroll
-            for (int k = 0; k < SETS; ++k) { rd[k] = cur.d[k]; ra[k] = cur.a[k]; rb[k] = cur.b[k]; rc[k] = cur.c[k]; }
             float v[8], xh[8], dsl[8];
-            unpack8(rx, v);
+            unpack8(cur.x, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 xh[e] = v[e] * rs[e] - mr[e];
@@ -433,16 +458,35 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
             }
 #pragma unroll
             for (int k = 0; k < SETS; ++k) {
-                const long orow = (long)(k * nx + n) * rpi + wrow;
-                float d[8], r[8], r2[8], r3[8], o[8];
-                unpack8(rd[k], d); unpack8(ra[k], r); unpack8(rb[k], r2); unpack8(rc[k], r3);
+                float d[8], o[8];
+                unpack8(cur.d[k], d);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float t = rs[e] * (d[e] * dsl[e] - m1[k][e] - xh[e] * m2[k][e]);
                     cs[k][e] += t;
-                    o[e] = t + r[e] + r2[e] + r3[e];
+                    o[e] = t;
                 }
-                *reinterpret_cast<u32x4_t*>(obase + orow * ostride) = pack8(o);
+                // the cotangents x already carries: (uniform) branches -- most sites have none or one of them, and unpacking
+                // and adding eight zeros per absent operand was a fifth of this loop's vector work
+                if (accum) {
+                    float r[8];
+                    unpack8(cur.a[k], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
+                if (accum2) {
+                    float r[8];
+                    unpack8(cur.b[k], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
+                if (any_oacc) {
+                    float r[8];
+                    unpack8(cur.c[k], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
+                st16(obase[k], ooff, pack8(o));
             }
         }
     }
