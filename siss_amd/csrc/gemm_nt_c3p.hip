@@ -424,8 +424,17 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                     }
                 }
             };
-            // almost every tile lies inside one image: no per-row select between the two images' row biases
-            if (p.rowbias && m0 + P_BM > split) park(std::true_type{}); else park(std::false_type{});
+            // almost every tile lies inside one image: no per-row select between the two images' row biases; a product without
+            // bias, row bias and scale (every dgrad launch) only rounds its accumulators
+            if (!p.bias && !p.rowbias && p.alpha == 1.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4_t v = acc[i][j];
+                        *reinterpret_cast<u32x2_t*>(st + j * 16 * SROW + i * 32) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                    }
+            } else if (p.rowbias && m0 + P_BM > split) park(std::true_type{}); else park(std::false_type{});
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         c3p_barrier();                                     // E2: the tile is parked; the producers take it from here
