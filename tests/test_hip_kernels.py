@@ -126,6 +126,38 @@ def test_conv1x1(dev):
 LOSS_FILES = sorted(glob.glob(os.path.join(HERE, "siss_loss_*.npz")))
 
 
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_with_depth_to_space_epilogue_equals_gemm_then_scatter(dev, accumulate):
+    """siss_gemm_nt_d2s (the downsample dgrad's plane products writing straight into the full-resolution cotangent, adding the
+    one x already carries) against the same product into a plane buffer followed by siss_depth_to_space: the same roundings in
+    the same order, so BITWISE equal; the halo of the full-resolution tensor is untouched (Downsample2D backward:
+    delete_celeb.py:691,:702 differentiate through it)."""
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act
+    n, ho, wo, c = 3, 24, 20, 128                            # plane tensors 24 x 20, full resolution 48 x 40; 3 images per tile row run
+    g = torch.Generator().manual_seed(11 + int(accumulate))
+    dy = Act.from_nchw(torch.randn(n, c, ho, wo, generator=g).bfloat16().float(), dev)
+    prior = torch.randn(n, c, 2 * ho, 2 * wo, generator=g).bfloat16().float()
+    ref_dx, fused_dx = Act.from_nchw(prior, dev), Act.from_nchw(prior, dev)
+    if not accumulate:                                       # fresh buffers: interior garbage that must be overwritten, zero halo
+        for a in (ref_dx, fused_dx):
+            a.interior().fill_(5.0)
+    dz = Act(n, ho, wo, 4 * c, dev)
+    wp = wo + 2
+    taps = {0: [(0, 0), (1, 0), (0, 1), (1, 1)], 1: [(0, 0), (1, 0)], 2: [(0, 0), (0, 1)], 3: [(0, 0)]}   # (dy, dx) row shifts per plane
+    for plane, tl in taps.items():
+        w = (torch.randn(len(tl), c, c, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+        shifts = [-(a * wp + b) for a, b in tl]
+        ops.gemm_nt(lib.ptr(dy.data), c, w, lib.ptr(dz.data[:, plane * c:]), 4 * c, dy.rows, c, c, shifts, [0] * len(tl),
+                    rows_per_image=dy.rows_per_image, hp=dy.hp, wp=dy.wp)
+        lib.call("siss_gemm_nt_d2s", dy.data, c, w, fused_dx.data, c, fused_dx.data if accumulate else None, c, dy.rows, c, c,
+                 len(tl), lib.int_array(shifts), lib.int_array([0] * len(tl)), dy.rows_per_image, dy.hp, dy.wp, plane)
+    lib.call("siss_depth_to_space", dz.data, ref_dx.data, int(accumulate), n, 2 * ho, 2 * wo, c)
+    torch.cuda.synchronize()
+    assert fused_dx.halo_is_zero()
+    assert torch.equal(fused_dx.buf, ref_dx.buf)
+
+
 @pytest.mark.parametrize("path", LOSS_FILES, ids=[os.path.basename(p)[10:-4] for p in LOSS_FILES])
 def test_mixture_and_loss_seed_vs_golden(dev, path):
     """fp32 mode against the golden vectors made by the reference's own loss code."""
