@@ -24,11 +24,10 @@
 
 namespace {
 
-// Two instantiations:
-//   <256, 8 waves, 3 stages>  big layers: one 512-thread block per CU (2 waves / SIMD), 144 KiB LDS ring,
-//                             the DMA of K-step s+2 is issued while step s computes (counted vmcnt), so an
-//                             L2 / Infinity-Cache round trip has two compute phases to land;
-//   <128, 4 waves, 2 stages>  small layers (few tiles): two 256-thread blocks per CU.
+// Instantiations (BM = 128 rows, 4 waves):
+//   STAGES = 1  large grids: single-buffered blocks at 4 per CU (latency hidden by the other three);
+//   STAGES = 2  mid-size grids: two double-buffered blocks per CU, both k-halves' fragments in registers;
+//   STAGES = 4  grids of at most 256 tiles (the 8x8 .. 32x32 layers): a 4-deep ring, optionally split-K.
 template <int BM, int NW, int STAGES>
 struct Cfg {
     static constexpr int kThreads = NW * 64;
@@ -62,12 +61,6 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int bz = blockIdx.z;
-    if (p.ablate & 8) {
-        // stagger probe: co-resident blocks run the same program with identical phase lengths; offset the
-        // blocks of dispatch round k (blockIdx / 256 ~ residency slot) by k * 512 cycles
-        const int slot = (blockIdx.x >> 8) & 3;
-        for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     const bf16_t* A = p.A + (long)bz * p.strideA;
     const bf16_t* W = p.W + (long)bz * p.strideW;
 
@@ -151,13 +144,13 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < steps) stage(s, s);
     int buf = 0, nbuf = STAGES - 1;
-    for (int s = 0; s < ((p.ablate & 16) ? 0 : steps); ++s) {
+    for (int s = 0; s < steps; ++s) {
         if (STAGES == 1) {
             // single buffer, two barriers per step: latency is hidden only by the OTHER resident blocks
             // (34 KiB of LDS per block -> 4 blocks per CU)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (!((p.ablate & 2) && s >= 2)) stage(0, s);
+            stage(0, s);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         } else {
@@ -170,12 +163,11 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
             else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (s + STAGES - 1 < steps && !((p.ablate & 2) && s >= 2)) stage(nbuf, s + STAGES - 1);
+            if (s + STAGES - 1 < steps) stage(nbuf, s + STAGES - 1);
         }
         const char* sb = smem + buf * C_::kStageBytes;
         if constexpr (STAGES == 1 && BM == 128) {
             // 4 blocks per CU (128 VGPRs): no room for a second fragment set; the other three blocks hide the reads
-            if (!(p.ablate & 4))
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8_t af[MT], wf[4];
@@ -189,7 +181,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
                     for (int j = 0; j < MT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
             }
-        } else if (!(p.ablate & 4)) {
+        } else {
             // Both k-halves' fragments live in registers: the kk = 1 reads are issued after the first MFMA row of
             // kk = 0 and land under the remaining rows.  MFMA rows run i = 3 .. 0 so that the first row needs the
             // LAST-issued read (the compiler's wait there is lgkmcnt(0); nothing older is outstanding later).
@@ -235,33 +227,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 *reinterpret_cast<f32x4_t*>(dst + ((i * MT + j) * C_::kThreads + tid) * 4) = acc[i][j];
-        // Opt-in variant (SISS_NT_FUSED_REDUCE=1): the LAST block of the tile to arrive sums the ksplit partial tiles and runs
-        // the epilogue instead of a second launch.  The sum walks the splits in index order whoever is last, so the result
-        // is bitwise independent of the arrival order.  Measured slower than the reduce kernel (see gemm_nt_dispatch).
-        if (!p.tile_ctr) return;                               // SISS_NT_FUSED_REDUCE=0: gemm_nt_reduce_kernel finishes the tile
-        __shared__ int s_last;
-        __threadfence();                                       // this block's partial tile is visible device-wide
-        __syncthreads();
-        if (tid == 0) s_last = __hip_atomic_fetch_add(p.tile_ctr + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == p.ksplit - 1;
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();                                       // the other blocks' partial tiles, too
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = *reinterpret_cast<const f32x4_t*>(base + ((i * MT + j) * C_::kThreads + tid) * 4);
-        for (int k = 1; k < p.ksplit; ++k) {
-            const float* src = base + (long)k * (BM * BN);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + ((i * MT + j) * C_::kThreads + tid) * 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] += v[r];
-                }
-        }
-        if (tid == 0) p.tile_ctr[tile] = 0;                    // as found: zero for the next launch
+        return;                                                // gemm_nt_reduce_kernel finishes the tile
     }
     nt_epilogue<BM, C_::kThreads, MT>(p, acc, smem, m0, n0, bz, tid, wm, wn, frow, fq);
 }
@@ -306,7 +272,7 @@ int launch_nt(const NTParams& p, int batch, hipStream_t st) {
     siss_count_dispatch(p.ksplit > 1 ? SISS_K_NT_SPLITK : SISS_K_NT);
     dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.ksplit > 1 ? p.ksplit : 1, batch);
     gemm_nt_kernel<BM, NW, STAGES><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
-    if (p.ksplit > 1 && !p.tile_ctr) {                      // (kept for A/B: SISS_NT_FUSED_REDUCE=0)
+    if (p.ksplit > 1) {
         static unsigned char attr2[kMaxDevices];
         if (siss_ensure_smem((const void*)gemm_nt_reduce_kernel<BM, NW>, BM * kCRow, attr2) != SISS_OK) return SISS_ERR_LAUNCH;
         gemm_nt_reduce_kernel<BM, NW><<<grid.x, C_::kThreads, BM * kCRow, st>>>(p);
@@ -320,15 +286,13 @@ long g_slab_bytes_dev[kMaxDevices];
 
 }  // namespace
 
-int siss_launch_gemm_nt_conv3(const void* params, void* stream);   // gemm_nt_conv3.hip
-int siss_launch_gemm_nt_c3(const void* params, void* stream);      // gemm_nt_c3.hip
 int siss_launch_gemm_nt_c3p(const void* params, void* stream);     // gemm_nt_c3p.hip
 
 static int g_c3p_blocks[kMaxDevices];      // per device; 0 = not set yet
 int nt_c3p_blocks() {
     const int dev = siss_current_device();
     if (dev < 0) return 256;
-    if (g_c3p_blocks[dev] == 0) { const char* e = getenv("SISS_NT_C3P_BLOCKS"); const int n = e ? atoi(e) : 256; g_c3p_blocks[dev] = (n >= 8 && n <= 256 && n % 8 == 0) ? n : 256; }
+    if (g_c3p_blocks[dev] == 0) g_c3p_blocks[dev] = 256;
     return g_c3p_blocks[dev];
 }
 
@@ -364,12 +328,12 @@ int siss_dispatch_reset() {
 }
 
 /* Number of CUs the persistent 3x3 kernel (gemm_nt_c3p) occupies: a multiple of 8 in [8, 256]; 0 restores the default
-   (256, or $SISS_NT_C3P_BLOCKS).  That kernel takes all 160 KiB of LDS of every CU it runs on for its whole duration,
+   (256).  That kernel takes all 160 KiB of LDS of every CU it runs on for its whole duration,
    so a data-parallel run that overlaps RCCL's all-reduce with the backward may leave a few CUs to the collective
    (SISSStepper.autotune_overlap measures whether that pays on the node).  Returns the value now in effect, -1 for a
    value out of range.  Takes no stream: it only changes how LATER launches are shaped. */
 int siss_gemm_nt_set_c3p_blocks(int n) {
-    if (n == 0) { const char* e = getenv("SISS_NT_C3P_BLOCKS"); n = e ? atoi(e) : 256; }
+    if (n == 0) n = 256;
     if (n < 8 || n > 256 || n % 8) return -1;
     const int dev = siss_current_device();
     if (dev < 0) return -1;
@@ -400,101 +364,67 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.M = M; p.N = N; p.Kp = Kp; p.npanels = npanels;
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
+    p.ksplit = 1; p.slab = nullptr; p.qstats = nullptr; p.d2s = d2s;
+#ifdef SISS_PROBE
     { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
-    p.ksplit = 1; p.slab = nullptr; p.tile_ctr = nullptr; p.qstats = nullptr; p.d2s = d2s;
+    { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     SISS_CHECK_ARG(d2s == 0 || (d2s >= 1 && d2s <= 4 && Hp > 2 && Wp > 2 && batch == 1 && !rowsub && !mul_r));
     p.rowsub = rowsub; p.mul_r = mul_r;
     SISS_CHECK_ARG(!mul_r || (R && Hp == 0));              // the multiplicative epilogue has no halo form
     const int dev_ = siss_current_device();
     float* const g_slab = dev_ >= 0 ? g_slab_dev[dev_] : nullptr;
-    constexpr long kCtrBytes = 4096;                           // arrival counters of the split-K tiles live at the workspace's end
-    const long g_slab_bytes = dev_ >= 0 && g_slab_bytes_dev[dev_] > kCtrBytes ? g_slab_bytes_dev[dev_] - kCtrBytes : 0;
-    static int fused_reduce = -1;
-    // opt-in: measured 2.3 ms per step SLOWER than the separate reduce launch (64.8 vs 62.5 ms, same box): the two device-scope
-    // fences around the arrival counter (L2 write-back + invalidate on every split block) cost more than 48 tiny launches
-    if (fused_reduce < 0) { const char* e = getenv("SISS_NT_FUSED_REDUCE"); fused_reduce = e ? atoi(e) : 0; }
-    int* const g_ctr = (fused_reduce && g_slab_bytes > 0) ? reinterpret_cast<int*>(reinterpret_cast<char*>(g_slab) + g_slab_bytes) : nullptr;
-    { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+    const long g_slab_bytes = dev_ >= 0 ? g_slab_bytes_dev[dev_] : 0;
     SISS_CHECK_ARG((!rowbias && Hp == 0) || rows_per_image >= 64);   // <= 3 images per 128/256-row tile
     SISS_CHECK_ARG(N % 8 == 0 && (!rowbias || ldrb % 4 == 0) && (!bias || (uintptr_t)bias % 16 == 0));
     for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
-    // 3x3 filters on large grids: the fused-tap kernel (A tile shared by the three kx taps)
+    // 3x3 filters on grids of at least kC3pMinTiles 128-row tiles: the persistent kernel (gemm_nt_c3p.hip; A tile shared by the three
+    // kx taps, DMA / store waves beside the MFMA waves).  Measured sweep of the threshold (round 1, 2048 .. 32): 256 gives the
+    // shortest step.  It addresses its tensors by 32-bit byte offsets: tensors of 4 GiB and more stay on the kernels below.
     {
-        bool conv3 = npanels == 9 && batch == 1 && Kp % 32 == 0 && !rowsub && !mul_r && !d2s;
+        bool conv3 = npanels == 9 && batch == 1 && !rowsub && !mul_r && !d2s;
         for (int g = 0; conv3 && g < 3; ++g)
             conv3 = p.shift[3 * g + 1] == p.shift[3 * g] + 1 && p.shift[3 * g + 2] == p.shift[3 * g] + 2 &&
                     p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
-        static int use3 = -1;
-        if (use3 < 0) { const char* e = getenv("SISS_NT_CONV3"); use3 = e ? atoi(e) : 0; }   // opt-in: measured a wash
+        constexpr long kC3pMinTiles = 256;
         const long tiles = (long)cdiv(M, 128) * cdiv(N, BN);
-        static int c3 = -1;
-        if (c3 < 0) { const char* e = getenv("SISS_NT_C3"); c3 = e ? atoi(e) : 2; }   // 0 off, 1 always, 2 grids of >= SISS_NT_C3_MIN_TILES 128-row tiles
-        static long c3_min = -1;
-        if (c3_min < 0) { const char* e = getenv("SISS_NT_C3_MIN_TILES"); c3_min = e ? atol(e) : 256; }   // measured (round 1, sweep 2048 .. 32): 256 gives the shortest step
-        if (conv3 && Kp % 64 == 0 && N % BN == 0 && rows_per_image >= 256 && (Wp == 0 || Wp >= 8) && (c3 == 1 || (c3 == 2 && tiles >= c3_min))) {
-            static int c3p = -1;
-            if (c3p < 0) { const char* e = getenv("SISS_NT_C3P"); c3p = e ? atoi(e) : 1; }   // persistent producer/consumer variant
-            // (the persistent kernel addresses C and R by 32-bit byte offsets: tensors of 4 GiB and more take the one-tile kernel)
-            bool persistent = c3p != 0;
-            if ((long)M * ldc * 2 >= (1L << 32) || (R && (long)M * ldr * 2 >= (1L << 32)) || (long)(M + 2) * lda * 2 >= (1L << 32) ||
-                (long)N * Kp * 2 >= (1L << 32)) persistent = false;
-            if (persistent && qstats && Hp > 0 && ((uintptr_t)qstats % 16) == 0) {
+        const bool fits32 = (long)M * ldc * 2 < (1L << 32) && (!R || (long)M * ldr * 2 < (1L << 32)) && (long)(M + 2) * lda * 2 < (1L << 32) &&
+                            (long)N * Kp * 2 < (1L << 32);
+        if (conv3 && N % BN == 0 && rows_per_image >= 256 && (Wp == 0 || Wp >= 8) && tiles >= kC3pMinTiles && fits32) {
+            if (qstats && Hp > 0 && ((uintptr_t)qstats % 16) == 0) {
                 p.qstats = qstats;                          // only the persistent kernel forms them; the caller is told
                 if (qstats_written) *qstats_written = 1;
             }
-            return persistent ? siss_launch_gemm_nt_c3p(&p, stream) : siss_launch_gemm_nt_c3(&p, stream);
+            return siss_launch_gemm_nt_c3p(&p, stream);
         }
-        if (conv3 && (use3 == 1 || (use3 == 2 && tiles >= 1024))) return siss_launch_gemm_nt_conv3(&p, stream);
     }
-    // big problems: 256-row tiles (one 8-wave block per CU, 3-stage ring); otherwise 128-row tiles
-    const long big_tiles = (long)cdiv(M, 256) * cdiv(N, BN) * batch;
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("SISS_NT_TILE"); force = e ? atoi(e) : 0; }
-    // measured (tools/bench_kernels.py, round 1): the 8-wave / 3-stage variant is 5-15 % SLOWER than two
-    // co-resident 4-wave blocks at every CelebA-HQ layer shape, so it is opt-in (SISS_NT_TILE=256)
-    const bool big = force == 256 && big_tiles >= 1;
-    static int stages = -1;
-    if (stages < 0) { const char* e = getenv("SISS_NT_STAGES"); stages = e ? atoi(e) : 0; }
-    if (big) return launch_nt<256, 8, 3>(p, batch, (hipStream_t)stream);
-    if (force == 2564) return launch_nt<256, 4, 1>(p, batch, (hipStream_t)stream);    // 128x64 wave tiles, 2 blocks / CU
-    if (force == 2562) return launch_nt<256, 4, 2>(p, batch, (hipStream_t)stream);
     // Large grids: single-buffered blocks at 4 per CU (latency hidden by the other three) measured 10-15 %
     // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;
-    if (stages == 1 || (stages == 0 && tiles128 >= 2048)) return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
+    if (tiles128 >= 2048) return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
     // at most one block per CU anyway: a 4-deep ring (128 KiB) keeps three K-steps of DMA in flight, so a step
     // costs its MFMA time instead of an L2 round trip (the 8x8 .. 32x32 layers are bound by the serial K loop)
-    static int deep = -1;
-    if (deep < 0) { const char* e = getenv("SISS_NT_DEEP"); deep = e ? atoi(e) : 1; }
-    if (deep && tiles128 <= 256) {
+    if (tiles128 <= 256) {
         // Few tiles and a long K loop: split K over up to 8 blocks per tile so that (nearly) every CU holds one
         // block; each block keeps >= 6 K-steps.  Partial tiles go through the host-provided slab.
-        static int splitk = -1;
-        if (splitk < 0) { const char* e = getenv("SISS_NT_SPLITK"); splitk = e ? atoi(e) : 1; }
         const int steps = npanels * (Kp / BK);
-        if (splitk && batch == 1 && tiles128 <= 128 && steps >= 12 && g_slab) {
+        if (batch == 1 && tiles128 <= 128 && steps >= 12 && g_slab) {
             int S = (int)(256 / tiles128);
             if (S > 8) S = 8;
             if (S > steps / 6) S = steps / 6;
             if (S >= 2 && (long)tiles128 * S * 128 * BN * (long)sizeof(float) <= g_slab_bytes) {
-                p.ksplit = S; p.slab = g_slab; p.tile_ctr = g_ctr;
+                p.ksplit = S; p.slab = g_slab;
             }
         }
         // 129..256 tiles (the 16x16 layers): two double-buffered blocks per CU, each with half the K loop
-        static int split2 = -1;
-        if (split2 < 0) { const char* e = getenv("SISS_NT_SPLIT2"); split2 = e ? atoi(e) : 1; }
-        if (splitk && split2 && batch == 1 && tiles128 > 128 && steps >= 24 && g_slab &&
+        if (batch == 1 && tiles128 > 128 && steps >= 24 && g_slab &&
             (long)tiles128 * 2 * 128 * BN * (long)sizeof(float) <= g_slab_bytes) {
-            p.ksplit = 2; p.slab = g_slab; p.tile_ctr = g_ctr;
+            p.ksplit = 2; p.slab = g_slab;
             return launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
         }
         return launch_nt<128, 4, 4>(p, batch, (hipStream_t)stream);
     }
-    // tiny grids (8x8 / 16x16 layers, attention): 64-row tiles double the block count
-    static int small = -1;
-    if (small < 0) { const char* e = getenv("SISS_NT_SMALL"); small = e ? atoi(e) : 0; }   // opt-in: measured +-5 % (these layers are K-latency-bound, not block-count-bound)
-    if (small && tiles128 < 256) return launch_nt<64, 2, 2>(p, batch, (hipStream_t)stream);
     return launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
 }
 }  // namespace

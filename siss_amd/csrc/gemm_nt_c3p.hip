@@ -22,8 +22,15 @@
 // group g-1 just left.  The group sequence simply continues over tile boundaries: while the consumers run the
 // epilogue of tile i, tile i+1's first group is already landing.
 #include "nt_common.h"
-#include <stdlib.h>
 #include <type_traits>
+
+// Probe build (-DSISS_PROBE, tools/probes/build_probe.sh): in-kernel phase timers (NTParams::dbg) and ablation switches
+// (NTParams::ablate); the product build compiles none of it.
+#ifdef SISS_PROBE
+#define C3P_ABLATE(bit) (p.ablate & (bit))
+#else
+#define C3P_ABLATE(bit) false
+#endif
 
 namespace {
 
@@ -47,7 +54,7 @@ struct TileMap {
 
 // QS: the producers also form the GroupNorm statistics of what they store (NTParams::qstats): the tensor's consumer is a
 // GroupNorm, whose statistics pass (one more read of the whole tensor) then disappears.
-template <bool ILV, bool QS>
+template <bool QS>
 __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             const long aoff = (long)p.shift[3 * gky] * p.lda + p.coff[3 * gky] + gkc * BK;
             const long woff = 3L * gky * wtap + gkc * BK;
             const unsigned dst = smem_a + (issued & 1) * P_SLOT;
-            if (!((p.ablate & 2) && issued >= 2)) {
+            if (!(C3P_ABLATE(2) && issued >= 2)) {
                 const bf16_t* abase = p.A + aoff;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dma(aoffs[j], abase, dst + (pw * 8 + j) * 1024);
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             if (g + 1 < G) issue_group();                  // -> slot (g+1)&1: last read by group g-1 / parked tile already in `ov`
             int counted = 0;
             if (pend >= 0) {
-                if (!(p.ablate & 1)) {
+                if (!C3P_ABLATE(1)) {
                     if (p.R) store_tile(std::true_type{}, phalf);      // its wait retired the DMA above as well
                     else counted = store_tile(std::false_type{}, phalf);
                 }
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                 pend = g / gpt;
             }
         }
-        if (pend >= 0 && !(p.ablate & 1)) {
+        if (pend >= 0 && !C3P_ABLATE(1)) {
             for (; phalf < 2; ++phalf) {
                 if (p.R) store_tile(std::true_type{}, phalf); else store_tile(std::false_type{}, phalf);
             }
@@ -302,9 +309,13 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
     f32x4_t acc[4][8];   // [n-tile][m-tile]
     bf16x8_t wf[2][4], af[2][4];
     int gg = 0;                                            // global group index (slot = gg & 1)
+#ifdef SISS_PROBE
     long long tk[6] = {0, 0, 0, 0, 0, 0};
     long long t0 = clock64();
 #define C3P_TICK(i) do { if (p.dbg) { const long long t1 = clock64(); tk[i] += t1 - t0; t0 = t1; } } while (0)
+#else
+#define C3P_TICK(i) do { } while (0)
+#endif
     for (int k = 0; k < count; ++k) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -323,13 +334,13 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                     dst[i] = *reinterpret_cast<const bf16x8_t*>(sl + (w_base ^ (kk << 6)) + t * P_WBYTES + i * 2048);
             };
             c3p_barrier();                                 // #gg: this group's slot has landed
-            if (p.ablate & 4) continue;
+            if (C3P_ABLATE(4)) continue;
             ldW(wf[0], 0, 0);
             ldA(af[0], 0, 0, 0);
-            if constexpr (ILV) {
-                // Interleaved variant: the (4 or 8) fragment reads of block b+1 are issued ONE behind each of the first MFMAs
-                // of block b instead of as a burst in front of them -- a consumer wave is alone on its SIMD as far as MFMAs
-                // go, so every cycle it spends issuing a burst of reads is a cycle the matrix pipe drains.
+            {
+                // The (4 or 8) fragment reads of block b+1 are issued ONE behind each of the first MFMAs of block b instead of as a
+                // burst in front of them -- a consumer wave is alone on its SIMD as far as MFMAs go, so every cycle it spends
+                // issuing a burst of reads is a cycle the matrix pipe drains (measured +2.6 %: 1064 -> 1092 TF/s over a step).
 #pragma unroll
                 for (int b = 0; b < 12; ++b) {
                     const int h = b & 1;
@@ -350,33 +361,6 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                continue;
-            }
-            // 12 blocks of 16 MFMAs: block b = (tap t, k-half kk, m-half h); the fragments of block b+1 are read
-            // before block b's MFMAs (counted lgkmcnt leaves them in flight).  Block 0 runs one MFMA row first:
-            // the wait in front of it is lgkmcnt(0) and must not cover fresh reads.
-#pragma unroll
-            for (int b = 0; b < 12; ++b) {
-                const int h = b & 1;
-                if (b == 0) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc[0][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][0], af[0][jj], acc[0][jj], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (b + 1 < 12) {
-                    const int nb = b + 1, nt = nb >> 2, nkk = (nb >> 1) & 1, nh = nb & 1;
-                    ldA(af[nb & 1], nt, nkk, nh);
-                    if (nh == 0) ldW(wf[(nb >> 1) & 1], nt, nkk);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = (b == 0 ? 1 : 0); i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        acc[i][h * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(b >> 1) & 1][i], af[b & 1][jj],
-                                                                                      acc[i][h * 4 + jj], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         C3P_TICK(0);
@@ -440,8 +424,10 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         c3p_barrier();                                     // E2: the tile is parked; the producers take it from here
         C3P_TICK(2);
     }
+#ifdef SISS_PROBE
     if (p.dbg && blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 6; ++i) p.dbg[w * 8 + i] = tk[i];
+#endif
 }
 
 }  // namespace
@@ -450,16 +436,13 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
 // N % 128 == 0, batch == 1, rows_per_image >= 256.
 int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     const NTParams& p = *reinterpret_cast<const NTParams*>(params);
-    static unsigned char attr_set[4][kMaxDevices];
-    static int ilv = -1;
-    if (ilv < 0) { const char* e = getenv("SISS_NT_C3P_ILV"); ilv = e ? atoi(e) : 1; }   // measured +2.6 % (1064 -> 1092 TF/s over the 98 launches of a step)
+    static unsigned char attr_set[2][kMaxDevices];
     const bool qs = p.qstats != nullptr;
-    // 32-bit byte offsets in the store path (callers: gemm_nt_dispatch falls back to the one-tile-per-block kernel otherwise)
+    // 32-bit byte offsets in the store path (gemm_nt_dispatch sends larger tensors to the one-tile-per-block kernels)
     if ((long)p.M * p.ldc * 2 >= (1L << 32) || (p.R && (long)p.M * p.ldr * 2 >= (1L << 32))) return SISS_ERR_ARG;
     using kern_t = void (*)(const NTParams);
-    const kern_t kern = ilv ? (qs ? gemm_nt_c3p_kernel<true, true> : gemm_nt_c3p_kernel<true, false>)
-                            : (qs ? gemm_nt_c3p_kernel<false, true> : gemm_nt_c3p_kernel<false, false>);
-    if (siss_ensure_smem((const void*)kern, P_SMEM, attr_set[(ilv ? 2 : 0) + (qs ? 1 : 0)]) != SISS_OK) return SISS_ERR_LAUNCH;
+    const kern_t kern = qs ? gemm_nt_c3p_kernel<true> : gemm_nt_c3p_kernel<false>;
+    if (siss_ensure_smem((const void*)kern, P_SMEM, attr_set[qs ? 1 : 0]) != SISS_OK) return SISS_ERR_LAUNCH;
     siss_count_dispatch(SISS_K_NT_C3P);
     // Grid = the FEWEST blocks (a multiple of 8: XCD runs) that finish in the same number of tile rounds as the full
     // chip: 550 tiles are 3 rounds on 256 CUs (38 CUs with three tiles, 218 with two) and exactly 3 on 184 -- the idle

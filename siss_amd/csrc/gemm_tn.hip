@@ -17,7 +17,6 @@
 // Split-K over row ranges; partial tiles are accumulated with f32 global atomics (no-return
 // global_atomic_add_f32; 16 consecutive floats per lane group).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -469,16 +468,14 @@ int launch_tn(const TNParams& p, hipStream_t st) {
     static unsigned char attr_set[kMaxDevices], attr_ilv[kMaxDevices];
     siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
     dim3 grid(cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits);
-    static int ilv = -1;
-    if (ilv < 0) { const char* e = getenv("SISS_TN_INTERLEAVE"); ilv = e ? atoi(e) : 1; }   // measured +5 % (996 -> 1044, 1057 -> 1112 TF/s)
-    if (TAPS == 3 && ilv) {
+    if constexpr (TAPS == 3) {                             // fragment reads interleaved with the MFMAs: measured +5 % (996 -> 1044, 1057 -> 1112 TF/s)
         constexpr int smem_ilv = TCfg<3, true>::kSmemBytes;
         if (siss_ensure_smem((const void*)gemm_tn_kernel<3, true>, smem_ilv, attr_ilv) != SISS_OK) return SISS_ERR_LAUNCH;
         gemm_tn_kernel<3, true><<<grid, C_::kThreads, smem_ilv, st>>>(p);
-        return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+    } else {
+        if (siss_ensure_smem((const void*)gemm_tn_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+        gemm_tn_kernel<TAPS><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
     }
-    if (siss_ensure_smem((const void*)gemm_tn_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
-    gemm_tn_kernel<TAPS><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
 
@@ -514,9 +511,7 @@ static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW,
     for (int g = 0; triples && g < npanels / 3; ++g)
         triples = p.shift[3 * g + 1] == p.shift[3 * g] + 1 && p.shift[3 * g + 2] == p.shift[3 * g] + 2 &&
                   p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
-    static int force1 = -1;
-    if (force1 < 0) { const char* e = getenv("SISS_TN_TAPS"); force1 = e ? atoi(e) : 0; }
-    bool fused3 = triples && force1 != 1;
+    bool fused3 = triples;
     const int rows = row_end - row_begin;
     const bool overwrite = nsplits == -1;                  // one split per tile, dW = product (no read, no zero fill needed)
     if (overwrite) nsplits = 1;
@@ -535,8 +530,6 @@ static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW,
         //   owns its tile and read-add-writes it with plain accesses.
         // The one-tap variant is only considered for short reductions (the 8x8 / 16x16 layers), where it puts 3x the
         // blocks on the chip without any split; on long reductions it re-reads X three times.
-        static int small1 = -1;
-        if (small1 < 0) { const char* e = getenv("SISS_TN_SMALL1"); small1 = e ? atoi(e) : 1; }
         const double bytes = (double)nsets * npanels * N * C * 4.0;
         const long tiles = (long)cdiv(N, BN) * cdiv(C, BC);
         double best = 1e30;
@@ -545,7 +538,7 @@ static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW,
         for (int v = 0; v < 2; ++v) {
             const bool f3 = v == 0;
             if (f3 && !fused3) continue;
-            if (!f3 && fused3 && (rows >= 8192 || !small1)) continue;
+            if (!f3 && fused3 && rows >= 8192) continue;
             const long base = tiles * (f3 ? npanels / 3 : npanels) * nsets;
             const long slots = f3 ? 256 : 512;
             const int max_ns = rows / 256 > 1 ? rows / 256 : 1;

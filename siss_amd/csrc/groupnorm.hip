@@ -15,7 +15,6 @@
 // the dual-cotangent backward of the SISS step.
 // Output / cotangent rows may be "compact" ([N][H*W][C], no halo) for the attention block.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -536,19 +535,11 @@ bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16) {
     return true;
 }
 
-// The workspace starts with the two-phase kernels' region (groupnorm2p.hip: counters + fixed-point accumulators for up
-// to k2pSamples samples, ZERO-filled by the caller once and left zero by every launch); the two-pass kernels' partial
-// slab follows it.
-constexpr int k2pSamples = 64;
-int g_use_2p = -1;
-int use_2p() {
-    if (g_use_2p < 0) { const char* e = getenv("SISS_GN_2P"); g_use_2p = e ? atoi(e) : 4; }
-    return g_use_2p;
-}
+// slab kernels at the small sites (groupnorm_slab.hip); siss_groupnorm_set_slab(0) sends every site to the two-pass kernels (tests)
+int g_use_slab = 1;
 
 }  // namespace
 
-long siss_gn2p_words(int n);      // groupnorm2p.hip
 int siss_gn_slab_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int N, int H,
                      int W, int C, int G, float eps, int silu, int out_compact, int ldx, void* stream);
 int siss_gn_slab_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
@@ -556,24 +547,14 @@ int siss_gn_slab_bwd(const void* dy, const void* x, const float* gamma, const fl
                      int accumulate2, float* dgamma, float* dbeta, float* colsum, long colsum_ld, int n2, int nx,
                      int set_images, long set_stride, int H, int W, int C, int G, int silu, int dy_compact, int ldx,
                      void* stream);
-int siss_gn2p_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* ws,
-                  int N, int H, int W, int C, int G, float eps, int silu, int out_compact, int ldx, void* stream);
-int siss_gn2p_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
-                  const float* rstd, void* dx, const void* accum, const void* accum2, void* dx2, int split_c,
-                  int accumulate2, float* dgamma, float* dbeta, float* colsum, long colsum_ld, float* ws, int n2, int nx,
-                  int set_images, long set_stride, int H, int W, int C, int G, int silu, int dy_compact, int ldx,
-                  void* stream);
-
 extern "C" {
 
-// Selects the GroupNorm kernels: bit 2 (4) = slab kernels for the small sites (<= 32 x 32 pixels: one launch, a block holds its
-// (sample, channel slice) on chip); bit 0 / bit 1 = two-phase forward / backward with a per-sample barrier (groupnorm2p.hip);
-// 0 = the two-pass kernels everywhere; -1 = back to the default ($SISS_GN_2P, else 4: measured on MI355X the slab kernels
-// win at the small sites, while the barrier chain of the two-phase form costs more than the second read it saves --
-// DESIGN.md section 3.2).  Returns the value in effect.
-int siss_groupnorm_set_two_phase(int mask) {
-    g_use_2p = mask < 0 ? -1 : (mask & 7);
-    return use_2p();
+// 1 (default): the small sites (<= 32 x 32 pixels forward, <= 16 x 16 backward) run on the one-launch slab kernels
+// (groupnorm_slab.hip); 0: every site takes the two-pass kernels (the parity tests compare the two); -1: back to the default.
+// Process-wide; returns the value in effect.
+int siss_groupnorm_set_slab(int on) {
+    g_use_slab = on != 0;
+    return g_use_slab;
 }
 
 // floats needed in `partial` for n samples.  The buffer must be ZERO-filled once before its first use (every launch
@@ -581,7 +562,7 @@ int siss_groupnorm_set_two_phase(int mask) {
 long siss_gn_partial_words(int n, int H, int W, int C, int G) {
     GNShape s;
     if (!make_shape(H, W, C, G, s, 1)) return -1;   // N = 1 gives the largest chunk count -> upper bound
-    return siss_gn2p_words(k2pSamples) + (long)n * s.nslices * s.nchunks * 2 * s.G;
+    return (long)n * s.nslices * s.nchunks * 2 * s.G;
 }
 
 // y = act(GroupNorm(x)); x padded NHWC; y padded or compact ([N][H*W][C]).  Writes mean/rstd [N][G].
@@ -601,17 +582,11 @@ int siss_groupnorm_fwd_qs(const void* x, const float* gamma, const float* beta, 
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
     if (ldx) s.ldx = ldx;
     SISS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y | (uintptr_t)partial) % 16 == 0);
-    if ((use_2p() & 4) && s.nslices == 1) {
-        // small sites: one launch, the block holds its (sample, channel slice) on chip (groupnorm2p.hip, slab kernels)
+    if (g_use_slab && s.nslices == 1) {
+        // small sites: one launch, the block holds its (sample, channel slice) on chip (groupnorm_slab.hip)
         const int rc = siss_gn_slab_fwd(x, gamma, beta, y, mean, rstd, N, H, W, C, G, eps, silu, out_compact, ldx, stream);
         if (rc >= 0) return rc;
     }
-    if ((use_2p() & 1) && s.nslices == 1 && N <= k2pSamples) {
-        // one launch, every byte once (groupnorm2p.hip); -1: shape not covered -> the two-pass kernels below
-        const int rc = siss_gn2p_fwd(x, gamma, beta, y, mean, rstd, partial, N, H, W, C, G, eps, silu, out_compact, ldx, stream);
-        if (rc >= 0) return rc;
-    }
-    partial += siss_gn2p_words(k2pSamples);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, N, s.nslices);
     if (qsA && s.cpg % 4 == 0 && (long)(H + 2) * (W + 2) >= 256) {
@@ -663,17 +638,11 @@ int siss_groupnorm_bwd_ld(const void* dy, const void* x, const float* gamma, con
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
     SISS_CHECK_ARG((uintptr_t)partial % 16 == 0);
     if (ldx) s.ldx = ldx;
-    if ((use_2p() & 4) && s.nslices == 1 && (n2 == nx || n2 == 2 * nx) && n2 / set_images <= 2) {
+    if (g_use_slab && s.nslices == 1 && (n2 == nx || n2 == 2 * nx) && n2 / set_images <= 2) {
         const int rc = siss_gn_slab_bwd(dy, x, gamma, beta, mean, rstd, dx, accum, accum2, dx2, split_c, accumulate2, dgamma, dbeta,
                                         colsum, colsum_ld, n2, nx, set_images, set_stride, H, W, C, G, silu, dy_compact, ldx, stream);
         if (rc >= 0) return rc;
     }
-    if ((use_2p() & 2) && s.nslices == 1 && nx <= k2pSamples) {
-        const int rc = siss_gn2p_bwd(dy, x, gamma, beta, mean, rstd, dx, accum, accum2, dx2, split_c, accumulate2, dgamma, dbeta,
-                                     colsum, colsum_ld, partial, n2, nx, set_images, set_stride, H, W, C, G, silu, dy_compact, ldx, stream);
-        if (rc >= 0) return rc;
-    }
-    partial += siss_gn2p_words(k2pSamples);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(s.nchunks, nx, s.nslices);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;

@@ -16,13 +16,14 @@ struct NTParams {
     int M, N, Kp, npanels;
     int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
     float alpha, inv_wp;
-    int ablate;
     const float* rowsub;              // optional f32 [batch][M]: subtracted from the accumulator row before alpha
     int mul_r;                        // 1: the epilogue MULTIPLIES by R instead of adding it  (C = R o (alpha (acc - rowsub)))
     int ksplit;                       // > 1: split-K -- gridDim.y blocks per tile write f32 partial tiles to `slab`
-    float* slab;                      //      ([tile][split][BM*BN] in accumulator order); the LAST block of a tile to arrive
-    int* tile_ctr;                    //      (arrival counters, one per tile, zero between launches) sums them and runs the epilogue
-    long long* dbg;                   // timing probe buffer (SISS_NT_DEBUG_PTR), normally null
+    float* slab;                      //      ([tile][split][BM*BN] in accumulator order); gemm_nt_reduce_kernel sums them and runs the epilogue
+#ifdef SISS_PROBE                     // probe build only (tools/probes/build_probe.sh): phase timers and ablation switches of gemm_nt_c3p
+    long long* dbg;                   // timing probe buffer ($SISS_NT_DEBUG_PTR), normally null
+    int ablate;                       // $SISS_NT_ABLATE: 1 no stores, 2 no DMA after the first two groups, 4 no MFMAs
+#endif
     int d2s;                          // 0, or 1 + plane: rows are pixels of space-to-depth plane (py, px) = (plane >> 1, plane & 1); the epilogue
                                       // writes (and reads R) at the pixel's place in the FULL-resolution tensor (2 Hp - 2) x (2 Wp - 2) padded
     float* qstats;                    // optional (persistent 3x3 kernel only): per-(half tile, image slot, 4-channel quad) sums and
@@ -89,7 +90,6 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
         }
     }
     __syncthreads();
-    if (p.ablate & 1) return;
     bf16_t* C = p.C + (long)bz * p.strideC;
     const int chunk = tid & 15;           // 8 channels per chunk
     const int nc = n0 + chunk * 8;

@@ -44,7 +44,7 @@ SIGNATURES = {
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gemm_tn_grouped": [P, I],
     "siss_gn_partial_words": [I, I, I, I, I],
-    "siss_groupnorm_set_two_phase": [I],
+    "siss_groupnorm_set_slab": [I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
     "siss_groupnorm_fwd_ld": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, I, P],
     "siss_groupnorm_fwd_qs": [P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, F, I, I, I, P],
@@ -253,7 +253,7 @@ def kernel_symbol(name, a):
         M, N, Kp, npan, batch, rpi = a[10], a[11], a[12], a[13], a[20], a[16]
         tiles = -(-M // 128) * -(-N // 128)
         if (npan == 9 and batch == 1 and Kp % 64 == 0 and N % 128 == 0 and rpi >= 256
-                and tiles >= int(os.environ.get("SISS_NT_C3_MIN_TILES", "256"))
+                and tiles >= 256
                 and triples(a[14], a[15], 9)):
             return "gemm_nt_c3p_kernel"
         return "gemm_nt_kernel"

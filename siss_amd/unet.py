@@ -17,7 +17,6 @@ is replayable from a hipGraph.
 Parameter names are the diffusers state-dict keys, so checkpoints round-trip.
 """
 import math
-import os
 from dataclasses import dataclass
 
 import torch
@@ -27,7 +26,6 @@ from .config import UNet2DConfig
 from .layout import Act, ActView
 
 ALIGN = 64  # floats; keeps every bf16 shadow slice 128-B aligned
-_BUSY = {}   # id(buffer) -> event recorded on the side stream after the last wgrad that reads the buffer
 
 
 @dataclass
@@ -154,8 +152,18 @@ class ParamStore:
 
 class UNetEngine:
     """Static-schedule UNet.  ``forward(x, t)`` then ``backward(c, nsets)``."""
-    epi_stats = os.environ.get("SISS_GN_EPI_STATS", "1") != "0"    # (class default: subclasses with their own __init__, e.g. VAEEncoder)
-    d2s_epilogue = os.environ.get("SISS_D2S_EPILOGUE", "1") != "0"  # downsample dgrad: depth-to-space in the plane GEMMs' epilogue
+    # Schedule switches: plain attributes, the defaults are the measured-best settings (DESIGN.md section 3.2); the parity
+    # tests flip them on an instance to compare the two forms of the same math.
+    epi_stats = True       # GroupNorm statistics from the producing conv's epilogue (no statistics pass at the large sites)
+    d2s_epilogue = True    # downsample dgrad: depth-to-space in the plane GEMMs' epilogue (no dz tensor, no scatter pass)
+    direct_cat = True      # convs that feed a concat write into the concat buffer directly (False: copy both parts)
+    # Weight gradients of the LOW-RESOLUTION layers (at most group_rows reduction rows per set: the 8x8 .. 32x32 levels) are not
+    # launched one by one -- each alone leaves most CUs idle and pays a launch's fixed ~10-40 us -- but queued and run as grouped
+    # launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).  They only feed the flat gradient buffer, so
+    # nothing waits for them; their cotangent operand is held back from the buffer pool until the group has run.  0 = off.
+    group_rows = 20000
+    group_max = 42
+    group_attn = True      # ... the attention blocks' linears too
 
     def __init__(self, cfg: UNet2DConfig, device="cuda"):
         lib.load()
@@ -177,26 +185,6 @@ class UNetEngine:
         self.gmap = {}
         self._uid = 0
         self.on_early_grads_final = None
-        # weight-gradient GEMMs only feed the flat gradient buffer, so they CAN run on a second HIP stream beside
-        # the dgrad -> GroupNorm-backward chain.  Measured on MI355X: +1.5 % step rate only (the 8-wave wgrad
-        # blocks leave too few VGPRs for co-resident blocks) while per-kernel times inflate, so it is opt-in.
-        import os
-        self.side = torch.cuda.Stream(device=self.device) if os.environ.get("SISS_SIDE_STREAM", "0") == "1" else None
-        # only wgrads over at most this many rows per set go to the side stream (the low-resolution levels, whose
-        # grids leave CUs idle); 0 = all of them
-        self.side_max_rows = int(os.environ.get("SISS_SIDE_MAX_ROWS", "0"))
-        # convs that feed a concat write into the concat buffer directly (SISS_DIRECT_CAT=0: copy both parts)
-        self.direct_cat = os.environ.get("SISS_DIRECT_CAT", "1") == "1"
-        # Weight gradients of the LOW-RESOLUTION layers (at most this many reduction rows per set: the 8x8 .. 32x32 levels) are
-        # not launched one by one -- each alone leaves most CUs idle and pays a launch's fixed ~10-40 us -- but queued and run
-        # as grouped launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).  They only feed the flat
-        # gradient buffer, so nothing waits for them; their cotangent operand is held back from the buffer pool until the
-        # group has run.  0 = off.
-        # GroupNorm statistics from the producing conv's epilogue (no statistics pass at the large sites)
-        self.epi_stats = os.environ.get("SISS_GN_EPI_STATS", "1") != "0"
-        self.group_rows = int(os.environ.get("SISS_WGRAD_GROUP_ROWS", "20000"))
-        self.group_max = int(os.environ.get("SISS_WGRAD_GROUP_MAX", "42"))
-        self.group_attn = self.group_rows and os.environ.get("SISS_WGRAD_GROUP_ATTN", "1") == "1"   # ... the attention blocks' linears too
         self._wq, self._held, self._held_release = [], {}, []
 
     # ------------------------------------------------------------------ parameters
@@ -397,14 +385,10 @@ class UNetEngine:
         self._wsync(a)
         return a
 
-    # -- side-stream bookkeeping: a buffer still being READ by a wgrad on the side stream carries the event
-    #    that marks the end of that read; anyone about to overwrite it waits for the event first.
     def _wsync(self, a):
+        """`a` is about to be overwritten: a queued (grouped) wgrad that still reads it must run first."""
         if a is not None and self._held and id(getattr(a, "base", a).buf) in self._held:
-            self._flush_wgrads()                          # about to be overwritten while a queued wgrad still reads it
-        ev = _BUSY.pop(id(a.buf), None) if a is not None else None
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            self._flush_wgrads()
 
     def _flush_wgrads(self):
         """Run the queued weight-gradient products as grouped launches and give their operands back to the pool."""
@@ -416,20 +400,6 @@ class UNetEngine:
         rel, self._held_release = self._held_release, []
         for a in rel:
             self._put(a)
-
-    def _on_side(self, fn, reads, rows=0):
-        if self.side is None or (self.side_max_rows and rows > self.side_max_rows):
-            fn()
-            return
-        ready = torch.cuda.Event()
-        ready.record()                                   # everything the wgrad reads is complete at this point
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            fn()
-            done = torch.cuda.Event()
-            done.record(self.side)
-        for a in reads:
-            _BUSY[id(getattr(a, "base", a).buf)] = done
 
     def _put(self, a):
         if a is not None:
@@ -588,7 +558,7 @@ class UNetEngine:
         ns = ops._nsplits(tiles, t, self.nsets, re - rb, ops.is_conv3_panels(shifts, coffs))
         sh, cf, zp = lib.int_array(shifts), lib.int_array(coffs), ops.zero_page(self.device)
         nsets = self.nsets
-        if self.group_rows and re - rb <= self.group_rows and self.side is None and isinstance(dy, Act):
+        if self.group_rows and re - rb <= self.group_rows and isinstance(dy, Act):
             job = lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
                             dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
                             rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=0, x_set_rows=x_set_rows,
@@ -600,9 +570,8 @@ class UNetEngine:
             if len(self._wq) >= self.group_max:
                 self._flush_wgrads()
             return
-        self._on_side(lambda: lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or getattr(x, "ld", x.c), dW_view, ps.total, co, ci, t,
-                                       sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2),
-                      reads=[dy, x], rows=re - rb)
+        lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or getattr(x, "ld", x.c), dW_view, ps.total, co, ci, t,
+                 sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2)
 
     # ------------------------------------------------------------------ time embedding
     def time_embed(self, t):
@@ -741,7 +710,7 @@ class UNetEngine:
             tb = lambda s, shape, dt=torch.bfloat16: self._buf("attn" + s, shape, dt)
             # the operands of this site's four weight-gradient products get buffers of their OWN (8 MB each at B = 16): the
             # products are queued and run later in a grouped launch, when the shared scratch has long been reused
-            own = (lambda s, shape: self._buf(nm + ".bwd" + s, shape, torch.bfloat16)) if self.group_attn else tb
+            own = (lambda s, shape: self._buf(nm + ".bwd" + s, shape, torch.bfloat16)) if self.group_attn and self.group_rows else tb
             dy = own(".dy", (rows2, C))
             lib.call("siss_pad_to_compact", dout.data, dy, nb, x.h, x.w, C)
             zp = ops.zero_page(self.device)
@@ -750,7 +719,7 @@ class UNetEngine:
                 """dyt [rows2,C] cotangent of y = xin W^T + b (xin has B*S rows shared by the sets)."""
                 dW = ps.grads[gb:, ps.specs[wname + ".weight"].off:]
                 tiles = (-(-C // 128)) ** 2
-                if self.group_attn and self.side is None:
+                if self.group_attn and self.group_rows:
                     z9 = (lib.I * 9)(*([0] * 9))
                     self._wq.append((lib.TNJob(Y=dyt.data_ptr(), ldy=C, X=xin.data_ptr(), ldx=C, dW=dW.data_ptr(),
                                                set_stride=ps.total, N=C, C=C, npanels=1, nsets=ns, rows_per_set=si * S,
@@ -1076,14 +1045,6 @@ class UNetEngine:
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail
-                if self.side is not None:
-                    # wgrads of the early-final parameters may still be running on the side stream: the collective
-                    # the hook starts must see complete gradients (and later side-stream work must not race with it)
-                    torch.cuda.current_stream().wait_stream(self.side)
-                    _BUSY.clear()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
         self._flush_wgrads()
-        if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)     # join: every wgrad has landed in ps.grads
-            _BUSY.clear()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"

@@ -33,10 +33,9 @@ class UNetCondEngine(UNetEngine):
     def __init__(self, cfg: UNet2DConditionConfig, device="cuda"):
         super().__init__(cfg, device)
         self.ctx = None
-        import os
-        # fused attention (csrc/flash_attn.hip) for the transformer blocks; SISS_FLASH_ATTN=0: batched GEMMs + row softmax
-        # with the S x S matrices in HBM (the round-1 form, kept as the A/B baseline)
-        self.flash = os.environ.get("SISS_FLASH_ATTN", "1") == "1"
+        # fused attention (csrc/flash_attn.hip) for the transformer blocks; False: batched GEMMs + row softmax with the
+        # S x S matrices in HBM (the round-1 form: the parity tests compare the two)
+        self.flash = True
 
     # ------------------------------------------------------------------ parameters
     def _declare_transformer(self, pre, ch):
@@ -134,7 +133,7 @@ class UNetCondEngine(UNetEngine):
         dW = ps.grads[gb:, ps.specs[wname + ".weight"].off:]
         tiles = (-(-n_out // 128)) * (-(-k_in // 128))
         zp = ops.zero_page(self.device)
-        if self.group_attn and self.side is None:
+        if self.group_attn and self.group_rows:
             # queued for a grouped launch (UNetEngine._flush_wgrads): dy lives in a per-site buffer (see transformer())
             z9 = (lib.I * 9)(*([0] * 9))
             self._wq.append((lib.TNJob(Y=dy.data_ptr(), ldy=n_out, X=xin.data_ptr(), ldx=k_in, dW=dW.data_ptr(),
@@ -177,7 +176,7 @@ class UNetCondEngine(UNetEngine):
         bb = lambda s, shape, dt=torch.bfloat16: self._buf(nm + s, shape, dt)      # saved for the backward
         # scratch shared by all sites -- or, when the weight-gradient products are queued for grouped launches, per site
         # (a queued product reads its cotangent operand long after the next site would have reused the buffer)
-        tb = lambda s, shape, dt=torch.bfloat16: self._buf((nm if self.group_attn else "tfm") + ".scr" + s, shape, dt)
+        tb = lambda s, shape, dt=torch.bfloat16: self._buf((nm if self.group_attn and self.group_rows else "tfm") + ".scr" + s, shape, dt)
         sb = lambda s, shape, dt=torch.bfloat16: self._buf("tfm" + s, shape, dt)   # always shared: the S x S matrices of the materialised path
         rq, rk = B * Sq, B * Sk
         q, k, v = tb(".q", (rq, C)), tb(".k", (rk, C)), tb(".v", (rk, C))
@@ -296,7 +295,7 @@ class UNetCondEngine(UNetEngine):
             nb = self.nb
             rows2 = nb * S
             dout = self._take(out)
-            tb = lambda s, shape, dt=torch.bfloat16: self._buf((nm if self.group_attn else "tfm") + ".scr" + s, shape, dt)
+            tb = lambda s, shape, dt=torch.bfloat16: self._buf((nm if self.group_attn and self.group_rows else "tfm") + ".scr" + s, shape, dt)
             dy = tb(".dy", (rows2, C))
             lib.call("siss_pad_to_compact", dout.data, dy, nb, x.h, x.w, C)
             dx3 = tb(".dx3", (rows2, C))

@@ -51,7 +51,6 @@ class VAEEncoder(UNetEngine):
         self.wT, self._wds, self._acts, self._bufs, self._pool = {}, {}, {}, {}, {}
         self.tape, self.gmap, self._uid = [], {}, 0
         self.on_early_grads_final = None
-        self.side = None
 
     # ------------------------------------------------------------------ parameters
     def _declare_enc_resnet(self, pre, cin, cout):

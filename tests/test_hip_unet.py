@@ -372,8 +372,8 @@ def test_direct_concat_writes_equal_the_copying_concat(monkeypatch):
     cot = (torch.randn(8, 3, 16, 16, generator=g) * 1e-2).cuda()
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SISS_DIRECT_CAT", mode)
         eng = UNetEngine(hc, "cuda:0")
+        eng.direct_cat = mode == "1"
         eng.init_random(seed=1)
         calls = []
         orig = lib.call

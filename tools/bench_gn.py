@@ -1,4 +1,4 @@
-"""GroupNorm sites of the CelebA-HQ step (B = 16): two-pass kernels vs the two-phase on-chip kernels, us per launch and
+"""GroupNorm sites of the CelebA-HQ step (B = 16): two-pass kernels vs the default (slab kernels at the small sites), us per launch and
 algorithmic GB/s (x + y forward; x + 2 dy + 2 dx backward)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,8 +20,8 @@ for (hw, ci) in SITES:
     dg = torch.zeros(2, ci, device=dev); db = torch.zeros(2, ci, device=dev)
     xb = x.rows * ci * 2 / 1e9
     line = f"{hw:3d}^2 C={ci:4d} "
-    for mode in (0, 4):
-        lib.query("siss_groupnorm_set_two_phase", mode)
+    for mode in (0, 1):
+        lib.query("siss_groupnorm_set_slab", mode)
         t = timeit(lambda: lib.call("siss_groupnorm_fwd", x.data, gamma, beta, yy.data, mean, rstd, part, B, hw, hw, ci, G, 1e-6, 1, 0), 20)
         t2 = timeit(lambda: lib.call("siss_groupnorm_bwd", dyy.data, x.data, gamma, beta, mean, rstd, dxx.data, None, None, None, 0, 0, dg, db, None, 0, part,
                                      2 * B, B, B, ci, hw, hw, ci, G, 1, 0), 20)
@@ -29,4 +29,4 @@ for (hw, ci) in SITES:
                                      2 * B, B, B, ci, hw, hw, ci, G, 1, 0), 20)
         line += f"| {'2pass' if mode == 0 else 'slab  '} fwd {t*1e3:7.1f} us {2*xb/t*1e3:5.0f} GB/s  bwd {t2*1e3:7.1f} us {5*xb/t2*1e3:5.0f} GB/s  bwd+acc {t3*1e3:7.1f} us "
     print(line, flush=True)
-lib.query("siss_groupnorm_set_two_phase", -1)
+lib.query("siss_groupnorm_set_slab", -1)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Probe build of the C-ABI library: the product sources compiled with -DSISS_PROBE, which adds the in-kernel phase timers
+# ($SISS_NT_DEBUG_PTR) and the ablation switches ($SISS_NT_ABLATE: 1 no stores, 2 no DMA after the first two groups,
+# 4 no MFMAs) of the persistent 3x3 kernel.  Output: tools/probes/libsiss_hip_probe.so -- load it with
+#   SISS_LIB_PATH=tools/probes/libsiss_hip_probe.so python tools/probes/c3p_ticks.py
+# The product library (siss_amd/libsiss_hip.so) contains none of this.
+# Also here, as records of measured-and-rejected kernels (they are NOT part of either build):
+#   gemm_nt_c3.hip     one-tile-per-block predecessor of gemm_nt_c3p      gemm_nt_conv3.hip  A tile shared by three taps in the generic kernel
+#   groupnorm2p.hip    two-phase on-chip GroupNorm (2x slower than two passes)
+set -e
+cd "$(dirname "$0")/../.."
+out=tools/probes/_probe_build; mkdir -p $out
+for f in siss_amd/csrc/*.hip; do
+  b=$(basename $f .hip); extra=""
+  case $b in siss_loss|optimizer) extra="-ffp-contract=off";; esac
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSISS_PROBE $extra -c $f -o $out/$b.o &
+  if (( $(jobs -r | wc -l) >= 4 )); then wait -n; fi
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC $out/*.o -o tools/probes/libsiss_hip_probe.so
+echo built tools/probes/libsiss_hip_probe.so

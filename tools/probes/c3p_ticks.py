@@ -1,9 +1,9 @@
+# needs the probe build: tools/probes/build_probe.sh, then SISS_LIB_PATH=tools/probes/libsiss_hip_probe.so
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 dev = torch.device("cuda:0")
 dbg = torch.zeros(64, dtype=torch.int64, device=dev)
 os.environ["SISS_NT_DEBUG_PTR"] = str(dbg.data_ptr())
-os.environ["SISS_NT_C3P"] = "1"
 from siss_amd import lib, ops
 from siss_amd.layout import Act
 lib.load()
