@@ -280,13 +280,11 @@ def main():
         nbytes = g.numel() * g.element_size()
         exchange = {"payload_bytes": nbytes,
                     "note": "bus = 2 (N-1)/N x payload / time; per link = bus / min(N-1, 7) xGMI links per GPU; "
-                            "allreduce = RCCL all-reduce, direct = all-to-all reduce-scatter + all-gather (siss_amd/dp.py)"}
+                            "allreduce = RCCL all-reduce of the whole flat pair (siss_amd/dp.py)"}
         timings = getattr(st, "overlap_timings", None) or {}
         for name, fn in EXCHANGES.items():
             if fn is None:
                 continue                                  # "sharded" is a whole update, not an exchange of the flat pair
-            if name == "direct" and "serial_direct_ms" not in timings and timings:
-                continue                                  # the autotune's probe found no all-to-all on this backend
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             g.fill_(1e-3)
             fn(g, pg)                                     # warm the communicator
@@ -407,8 +405,7 @@ def main():
                        "hipgraph": bool(use_graph), "rng_in_timed_region": True,
                        "eager_task_loop_ms_per_step": round(eager_ms, 3) if eager_ms else None,
                        **({"dp_selfcheck": selfcheck} if selfcheck else {}),
-                       **({"dp_exchange": ("overlapped all-reduce, persistent 3x3 kernel on %d CUs" % getattr(st, "c3p_blocks", 256))
-                           if st.overlap else "serial " + st.exchange,
+                       **({"dp_exchange": "overlapped all-reduce (two grouped collectives)" if st.overlap else "serial " + st.exchange,
                            "dp_autotune": getattr(st, "overlap_timings", None),
                            "dp_allreduce": exchange} if world > 1 else {})},
             "step_tflop_algorithmic": step_tflop,

@@ -557,8 +557,7 @@ int siss_groupnorm_set_slab(int on) {
     return g_use_slab;
 }
 
-// floats needed in `partial` for n samples.  The buffer must be ZERO-filled once before its first use (every launch
-// leaves the part that needs it zero again) and 16-B aligned.
+// floats needed in `partial` for n samples: scratch between a site's statistics and apply launches, 16-B aligned.
 long siss_gn_partial_words(int n, int H, int W, int C, int G) {
     GNShape s;
     if (!make_shape(H, W, C, G, s, 1)) return -1;   // N = 1 gives the largest chunk count -> upper bound

@@ -23,32 +23,26 @@ def allreduce_flat_grads(flat_pair, group=None):
 _SCRATCH = {}
 
 
-def direct_exchange_flat_grads(flat_pair, group=None):
-    """The same sum over ranks as `allreduce_flat_grads`, as a DIRECT reduce-scatter + all-gather:
-    every rank sends slice j of its flat pair straight to rank j (one all-to-all: all 7 xGMI links of a GPU carry
-    S/8 each, concurrently, instead of a ring pushing 2 (N-1)/N S over one link), sums the N slices it received in
-    rank order, and the reduced slices are all-gathered back.  Each element is summed by exactly ONE rank in a fixed
-    order, so the replicas are bit-identical by construction.  Falls back to the all-reduce when the buffer does not
-    split evenly."""
-    if not (dist.is_available() and dist.is_initialized()):
-        return flat_pair
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if world <= 1:
-        return flat_pair
-    flat = flat_pair.view(-1)
-    n = flat.numel()
-    if n % world != 0 or not flat_pair.is_contiguous():
-        return allreduce_flat_grads(flat_pair, group)
-    shard = n // world
-    key = (flat.device, flat.dtype, n, world)
-    scratch = _SCRATCH.get(key)
-    if scratch is None:
-        scratch = _SCRATCH[key] = torch.empty(n + shard, dtype=flat.dtype, device=flat.device)
-    recv, mine = scratch[:n], scratch[n:]
-    dist.all_to_all_single(recv, flat, group=group)                 # recv[i*shard:(i+1)*shard] = rank i's slice `rank`
-    torch.sum(recv.view(world, shard), dim=0, out=mine)             # fixed rank order
-    dist.all_gather_into_tensor(flat, mine, group=group)
-    return flat_pair
+def allreduce_pieces(tensors, group=None, async_op=False):
+    """Sum over ranks of several (contiguous) pieces of the flat pair as ONE collective call: the pieces are issued inside
+    a coalescing window, which RCCL runs as one grouped launch (ncclGroupStart / End) -- the overlapped exchange is two
+    such calls per step ([tail_x, tail_a] from inside the backward, [head_x, head_a] after it), not four all-reduces.
+    Returns a handle with .wait() when async_op."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return None
+    from torch.distributed.distributed_c10d import _coalescing_manager
+    # (no `device`: the fast path -- the window records the all-reduces and hands them to the backend's allreduce_coalesced,
+    # which RCCL and gloo both implement)
+    with _coalescing_manager(group=group, async_ops=async_op) as cm:
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return cm if async_op else None
+
+
+def can_shard(P, world, align=4):
+    """The sharded update hands every rank the parameter range [r P / N, (r + 1) P / N): the ranges must be equal and start
+    on 16-byte boundaries (the flat kernels take float4 accesses)."""
+    return world > 1 and P % world == 0 and (P // world) % align == 0
 
 
 def reduce_scatter_param_shards(flat_pair, group=None):
@@ -86,7 +80,7 @@ def all_gather_params(flat_params, lo, hi, group=None):
 
 # "sharded" is not a gradient exchange with the replicated update behind it: SISSStepper handles it (reduce-scatter ->
 # shard-local norm-fix / clip / AdamW -> all-gather of the parameters); listed here so that the name validates.
-EXCHANGES = {"allreduce": allreduce_flat_grads, "direct": direct_exchange_flat_grads, "sharded": None}
+EXCHANGES = {"allreduce": allreduce_flat_grads, "sharded": None}
 
 
 def recombine_reference(gx, ga, scaling_norm, max_norm=1.0):

@@ -20,7 +20,7 @@ the single-process step on the concatenated batch.
 import torch
 
 from . import lib
-from .dp import EXCHANGES, allreduce_flat_grads
+from .dp import EXCHANGES, allreduce_flat_grads, allreduce_pieces, can_shard
 from .loss import loss_bwd_seed, mixture_fwd, mse_bwd_seed
 from .optim import FlatAdamW
 from .unet import UNetEngine
@@ -75,19 +75,19 @@ class SISSStepper:
         # ~85 % of the bytes) is final long before the high-resolution down blocks finish their backward;
         # its all-reduce is started from a hook inside the backward pass and runs beside the rest of it.
         import os
-        self.exchange = os.environ.get("SISS_DP_EXCHANGE", "allreduce")      # serial mode: "allreduce" | "direct" | "sharded"
+        self.exchange = os.environ.get("SISS_DP_EXCHANGE", "allreduce")      # serial mode: "allreduce" | "sharded"
+        self._state_shard = None                # (lo, hi) while AdamW's moments are current on this rank's shard only
         assert self.exchange in EXCHANGES
         self.set_overlap(self.pg is not None and self.world > 1 and engine.ps.split < engine.ps.total
                          and os.environ.get("SISS_DP_OVERLAP", "1") != "0")
 
     def set_overlap(self, on, exchange=None):
         """Overlapped (tail all-reduce started from inside the backward) or serial (one exchange after it: RCCL's
-        all-reduce, or the direct all-to-all reduce-scatter + all-gather of dp.direct_exchange_flat_grads)."""
+        all-reduce, or the sharded update).  Moments left on a shard by sharded steps are re-gathered where the next
+        replicated update needs them (_sync_and_update), whichever way the mode was changed."""
         self.overlap = bool(on)
         if exchange is not None:
             assert exchange in EXCHANGES
-            if exchange != "sharded" or on:
-                self._gather_optimizer_state()      # leaving the sharded update: every rank needs the whole m / v again
             self.exchange = exchange
         self.e.on_early_grads_final = self._early_allreduce if self.overlap else None
 
@@ -95,13 +95,18 @@ class SISSStepper:
         """The sharded update advances AdamW's moments on this rank's parameter shard only.  Before a REPLICATED update
         follows (another exchange mode, a checkpoint of the optimizer) the shards are all-gathered once, so that every
         rank holds identical full moments again."""
-        if getattr(self, "_state_shard", None) is None:
+        if self._state_shard is None:
             return
         from .dp import all_gather_params
         lo, hi = self._state_shard
         all_gather_params(self.opt.m, lo, hi, self.pg)
         all_gather_params(self.opt.v, lo, hi, self.pg)
         self._state_shard = None
+
+    def optimizer_state(self):
+        """(m, v, scalars) with the moments complete on every rank -- what a checkpoint of the optimizer saves."""
+        self._gather_optimizer_state()
+        return self.opt.m, self.opt.v, self.opt.scalars
 
     def autotune_overlap(self, step_fn, iters=3):
         """Measure, don't guess: the overlapped exchange shares the chip with the persistent one-block-per-CU GEMMs of
@@ -111,28 +116,19 @@ class SISSStepper:
             return self.overlap
         import time
         dist = torch.distributed
-        from .dp import direct_exchange_flat_grads
-        results, errors = {}, {}
-        # overlap_cu248: the overlapped exchange with the persistent 3x3 kernel on 248 of the 256 CUs -- it holds all
-        # the LDS of every CU it runs on for its whole duration, so RCCL's workgroups otherwise wait for kernel gaps
-        candidates = {"overlap": (True, "allreduce", 256), "overlap_cu248": (True, "allreduce", 248),
-                      "serial": (False, "allreduce", 256), "serial_direct": (False, "direct", 256),
-                      "serial_sharded": (False, "sharded", 256)}
-        try:                                                     # a backend without all-to-all keeps the all-reduce
-            probe = torch.ones(2, 8 * self.world, device=self.e.device)
-            direct_exchange_flat_grads(probe, self.pg)
-            torch.cuda.synchronize()
-            assert float(probe.sum()) == 16.0 * self.world * self.world
-        except (RuntimeError, AssertionError, NotImplementedError) as exc:
-            errors["serial_direct"] = (str(exc) or type(exc).__name__)[:200]
-            del candidates["serial_direct"]
-            del candidates["serial_sharded"]                     # its reduce-scatter is the same all-to-all
-        # the timed steps are real optimizer steps: put parameters, AdamW moments and the step counter back afterwards
-        # (the run that follows starts from the weights it was given, whichever candidate wins)
+        results = {}
+        # the three settings a node can tell apart: one all-reduce after the backward, the same exchange overlapped with it,
+        # and the sharded update (reduce-scatter -> shard-local AdamW -> all-gather of the parameters)
+        candidates = {"overlap": (True, "allreduce"), "serial": (False, "allreduce")}
+        if can_shard(self.e.ps.total, self.world):
+            candidates["serial_sharded"] = (False, "sharded")
+        # the timed steps are real optimizer steps: put parameters, AdamW moments, the step counter and the stepper's own
+        # state (NegGrad's decaying superfactor, the last step's statistics) back afterwards -- the run that follows starts
+        # from what it was given, whichever candidate wins
         saved = [t.clone() for t in (self.opt.p, self.opt.m, self.opt.v, self.opt.scalars)]
-        for name, (mode, exch, cus) in candidates.items():
+        saved_state = (self.superfactor, self.last, self._micro)
+        for name, (mode, exch) in candidates.items():
             self.set_overlap(mode, exch)
-            lib.query("siss_gemm_nt_set_c3p_blocks", cus)
             step_fn()                                            # settle (scratch buffers, communicator channels)
             dist.barrier(group=self.pg); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -147,13 +143,10 @@ class SISSStepper:
         for dst, src in zip((self.opt.p, self.opt.m, self.opt.v, self.opt.scalars), saved):
             dst.copy_(src)
         del saved
+        self.superfactor, self.last, self._micro = saved_state
         self.e.refresh_weights(cast_shadow=True)
-        self._micro = 0
         self.set_overlap(best.startswith("overlap"), candidates[best][1])
-        self.c3p_blocks = lib.query("siss_gemm_nt_set_c3p_blocks", candidates[best][2])
         self.overlap_timings = {k + "_ms": v * 1e3 for k, v in results.items()}
-        if errors:
-            self.overlap_timings["errors"] = errors
         return self.overlap
 
     # ------------------------------------------------------------------ one micro-batch
@@ -261,22 +254,24 @@ class SISSStepper:
             raise RuntimeError("the overlapped gradient exchange issues async collectives from inside the backward pass "
                                "and cannot be captured into a hipGraph: run N > 1 eagerly or set_overlap(False)")
         ps = self.e.ps
-        for s in range(ps.grads.shape[0]):
-            self._pending.append(torch.distributed.all_reduce(ps.grads[s, ps.split:], group=self.pg, async_op=True))
+        # ONE grouped collective: the early-final tails of both gradient sets
+        self._pending.append(allreduce_pieces([ps.grads[k, ps.split:] for k in range(ps.grads.shape[0])], self.pg, async_op=True))
 
     def _sync_and_update(self):
         g = self.e.ps.grads
         sharded = (self.pg is not None and self.world > 1 and self.exchange == "sharded" and not self.overlap
-                   and g.shape[1] % self.world == 0)
+                   and can_shard(g.shape[1], self.world))
+        if not sharded:
+            self._gather_optimizer_state()      # a replicated update after sharded ones: every rank needs the whole m / v
         if self.pg is not None and self.world > 1 and not sharded:
             # the exchange of the step: sum of [g_x ; g_a] over ranks (RCCL over xGMI) -- one flat buffer; with
             # the overlap hook the early-final tail is already in flight and only the head remains
             if self.overlap and self._pending:
-                split = self.e.ps.split
-                for s in range(g.shape[0]):
-                    self._pending.append(torch.distributed.all_reduce(g[s, :split], group=self.pg, async_op=True))
+                split = self.e.ps.split                 # ... the second (and last) grouped collective of the step: the heads
+                self._pending.append(allreduce_pieces([g[k, :split] for k in range(g.shape[0])], self.pg, async_op=True))
                 for w in self._pending:
-                    w.wait()
+                    if w is not None:
+                        w.wait()
                 self._pending = []
             else:
                 (EXCHANGES.get(self.exchange) or allreduce_flat_grads)(g, self.pg)     # 'sharded' that cannot shard: all-reduce

@@ -118,6 +118,16 @@ class _DeleteBase(Task):
         """The dict the reference splats into the UNet call (delete_celeb.py:622: {})."""
         return None
 
+    def lr_schedule_args(self, world):
+        """(num_warmup_steps, num_training_steps) as the reference hands them to get_scheduler
+        (delete_celeb.py:296-301: cfg.warmup_steps, cfg.training_steps)."""
+        cfg = self.cfg
+        return int(cfg.get("warmup_steps") or 0), int(cfg.get("training_steps") or 0)
+
+    def sample_noise(self, shape, device, generator):
+        """noise = torch.randn_like(images) (delete_celeb.py:583); the SAME noise for the keep and the forget batch."""
+        return torch.randn(shape, device=device, generator=generator)
+
     def seed(self):
         return int(self.cfg.random_seed)
 
@@ -170,9 +180,9 @@ class _DeleteBase(Task):
         lr, betas, eps, wd = self.optimizer_args()
         from .scheduler import lr_multiplier
         lr_name = str(cfg.get("lr_scheduler") or "constant")
-        # get_scheduler(cfg.lr_scheduler, num_warmup_steps=cfg.warmup_steps, num_training_steps=cfg.training_steps)
-        # (delete_celeb.py:296-301; delete_sd.py passes lr_warmup_steps * GA / max_train_steps * GA)
-        warm, total = int(cfg.get("warmup_steps") or 0), int(cfg.get("training_steps") or 0)
+        # get_scheduler(cfg.lr_scheduler, num_warmup_steps=..., num_training_steps=...): delete_celeb.py:296-301 passes
+        # cfg.warmup_steps / cfg.training_steps, delete_sd.py:714-719 cfg.lr_warmup_steps * num_processes / cfg.training_steps
+        warm, total = self.lr_schedule_args(world)
         lr_multiplier(lr_name, 0, warm, total)                  # raises now for a schedule that is not implemented
         d = cfg.deletion
         B, ga = int(cfg.train_batch_size), int(cfg.gradient_accumulation_steps)
@@ -207,7 +217,7 @@ class _DeleteBase(Task):
             for _ in range(ga):
                 x0 = self.prepare_batch(next(it_all).to(device, non_blocking=True), g)
                 a0 = self.prepare_batch(next(it_del).to(device, non_blocking=True), g)
-                noise = torch.randn(x0.shape, device=device, generator=g)           # SAME noise for both batches
+                noise = self.sample_noise(x0.shape, device, g)                      # SAME noise for both batches
                 t = torch.randint(self.timestep_low, T, (B,), device=device, generator=g)
                 u = torch.rand(B, device=device, generator=g)
                 stepper.micro_step(x0, a0, noise, t, u, cond)
@@ -295,10 +305,42 @@ class DeleteSD(_DeleteBase):
         # the SD v1 scheduler_config.json: scaled-linear betas 0.00085 -> 0.012 (delete_sd.py:412)
         return DDPMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
 
+    def check_supported(self):
+        """delete_sd.py reads more knobs than the pixel-space loops; the ones this loop does not implement are refused
+        instead of silently training something else (all at their shipped defaults in config/delete_sd.yaml:99-102,125)."""
+        super().check_supported()
+        cfg = self.cfg
+        if cfg.get("input_perturbation"):
+            raise NotImplementedError(f"input_perturbation={cfg.get('input_perturbation')!r}: perturbed noising with an unperturbed "
+                                      "target (delete_sd.py:899-903,:920-926) is not implemented; null in config/delete_sd.yaml")
+        if cfg.get("snr_gamma") is not None:
+            raise NotImplementedError(f"snr_gamma={cfg.get('snr_gamma')!r}: the reference's only live loss branch is "
+                                      "`if self.cfg.snr_gamma is None` (delete_sd.py:962); min-SNR weighting is not implemented")
+        if cfg.get("prediction_type") not in (None, "null", "epsilon"):
+            raise NotImplementedError(f"prediction_type={cfg.get('prediction_type')!r}: only the epsilon objective is on this "
+                                      "path (the v-prediction target is commented out in the reference too: delete_sd.py:953-958)")
+        if cfg.get("use_8bit_adam"):
+            raise NotImplementedError("use_8bit_adam=true: bitsandbytes' 8-bit AdamW (delete_sd.py:555-565) is not implemented; "
+                                      "the fused step keeps f32 moments")
+
+    def lr_schedule_args(self, world):
+        cfg = self.cfg                                          # delete_sd.py:714-719
+        return int(cfg.get("lr_warmup_steps") or 0) * world, int(cfg.get("training_steps") or 0)
+
+    def sample_noise(self, shape, device, generator):
+        noise = torch.randn(shape, device=device, generator=generator)
+        off = float(self.cfg.get("noise_offset") or 0.0)
+        if off:                                                 # delete_sd.py:893-898 (offset noise, one draw per (sample, channel))
+            noise = noise + off * torch.randn((shape[0], shape[1], 1, 1), device=device, generator=generator)
+        return noise
+
     def optimizer_args(self):
-        c = self.cfg                                            # delete_sd.py:567-573
-        return (float(c.learning_rate), (float(c.adam_beta1), float(c.adam_beta2)), float(c.adam_epsilon),
-                float(c.adam_weight_decay))
+        c = self.cfg                                            # delete_sd.py:546-552 (scale_lr), :567-573
+        lr = float(c.learning_rate)
+        if c.get("scale_lr"):
+            world = int(os.environ.get("WORLD_SIZE", "1"))
+            lr *= int(c.gradient_accumulation_steps) * int(c.train_batch_size) * world
+        return lr, (float(c.adam_beta1), float(c.adam_beta2)), float(c.adam_epsilon), float(c.adam_weight_decay)
 
     def datasets(self, shape):
         cfg = self.cfg

@@ -85,21 +85,17 @@ def main():
     flags = [None] * world
     dist.all_gather_object(flags, bool(choice))
     keys = set(st3.overlap_timings)
-    # the direct exchange (all-to-all reduce-scatter + all-gather) is timed too when the backend has an all-to-all for
-    # device tensors; otherwise the probe's error is recorded and the all-reduce kept
-    assert len(set(flags)) == 1 and {"overlap_ms", "overlap_cu248_ms", "serial_ms"} <= keys <= {
-        "overlap_ms", "overlap_cu248_ms", "serial_ms", "serial_direct_ms", "serial_sharded_ms", "errors"}
-    assert st3.c3p_blocks in (248, 256)
-    assert ("serial_direct_ms" in keys) != ("errors" in keys), st3.overlap_timings
-    if "serial_direct_ms" in keys:
-        # ... and gives the all-reduce's update
-        eng.load_state_dict(sd)
-        st4 = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, **kw)
-        st4.set_overlap(False, "direct")
-        st4.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
-        d3 = eng.ps.flat - base
-        cos = float((d3 * d2).sum() / (d3.norm() * d2.norm()))
-        assert cos > 0.999, cos
+    # three candidates a node can tell apart: serial all-reduce, overlapped all-reduce, sharded update (when P shards evenly)
+    from siss_amd.dp import can_shard
+    want = {"overlap_ms", "serial_ms"} | ({"serial_sharded_ms"} if can_shard(eng.ps.total, world) else set())
+    assert len(set(flags)) == 1 and keys == want, (keys, want)
+    # the stepper's own state is put back too (NegGrad's decaying superfactor, the last statistics)
+    eng.load_state_dict(sd)
+    kw_ng = dict(kw, loss_fn="simple_neg_del")
+    st_ng = SISSStepper(eng, ac, train_batch_size=per, process_group=dist.group.WORLD, superfactor=2.0, superfactor_decay=0.5, **kw_ng)
+    st_ng.autotune_overlap(lambda: st_ng.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl]), iters=1)
+    assert st_ng.superfactor == 2.0 and st_ng.last is None and st_ng._micro == 0
+    if "serial_sharded_ms" in keys:
         # the SHARDED update (reduce-scatter -> this rank's half of norm-fix / clip / AdamW -> all-gather of the parameters,
         # SURVEY.md section 5) is the same step: same scalars, same update, replicas bit-identical
         eng.load_state_dict(sd)
@@ -117,14 +113,22 @@ def main():
         d5 = p5 - base
         cos = float((d5 * d2).sum() / (d5.norm() * d2.norm()))
         assert cos > 0.999, cos
-        # leaving the sharded mode gathers AdamW's moments (each rank advanced only its shard): a replicated step that
-        # follows must keep the replicas bit-identical
-        st5.set_overlap(False, "allreduce")
+        # Leaving the sharded mode WITHOUT naming a new exchange (set_overlap(True): ADVICE r02) -- the replicated update that
+        # follows gathers AdamW's moments itself (each rank advanced only its shard) and keeps the replicas bit-identical
+        st5.set_overlap(True)
         st5.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
         for buf in (eng.ps.flat, st5.opt.m, st5.opt.v):
             both = [torch.zeros_like(buf) for _ in range(world)]
             dist.all_gather(both, buf.clone())
             assert all(torch.equal(both[0], o) for o in both), "replicas diverged after switching from the sharded update"
+        # ... and so does a checkpoint of the optimizer taken right after a sharded step
+        st5.set_overlap(False, "sharded")
+        st5.step(x0[sl], a0[sl], noise[sl], t[sl].to(dev), u[sl])
+        m_all, v_all, _ = st5.optimizer_state()
+        for buf in (m_all, v_all):
+            both = [torch.zeros_like(buf) for _ in range(world)]
+            dist.all_gather(both, buf.clone())
+            assert all(torch.equal(both[0], o) for o in both), "optimizer_state() must return complete moments on every rank"
     print("dp exchange timings", rank, st3.overlap_timings)
     dist.barrier()
     dist.destroy_process_group()

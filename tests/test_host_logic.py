@@ -169,12 +169,13 @@ sys.path.insert(0, sys.argv[1])
 from oracle import schedule as S
 from oracle.loss import OracleDeletionLoss, siss_terms, mix
 from oracle.toy import ToyEps
-from siss_amd.dp import allreduce_flat_grads, direct_exchange_flat_grads, recombine_reference
+from siss_amd.dp import (all_gather_params, allreduce_flat_grads, allreduce_pieces, can_shard, recombine_reference,
+                         reduce_scatter_param_shards)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 ac = S.alphas_cumprod(); gam, sig = S.gamma_sigma(ac)
 g = torch.Generator().manual_seed(123)
-Bg, c, hw = 4, 3, 8                                 # GLOBAL batch 4, 2 per rank
+Bg, c, hw = 8, 3, 8                                 # GLOBAL batch 8: 4 per rank at N = 2, 1 per rank at N = 8
 x0 = torch.rand(Bg, c, hw, hw, generator=g) * 2 - 1
 a0 = (torch.rand(1, c, hw, hw, generator=g) * 2 - 1).repeat(Bg, 1, 1, 1)
 noise = torch.randn(Bg, c, hw, hw, generator=g); t = torch.full((Bg,), 999); u = torch.rand(Bg, generator=g)
@@ -188,38 +189,93 @@ def flat_pair(sl):
     lx = (iwx[:, None, None, None] * (pred - ex) ** 2).sum() / Bg      # normaliser = GLOBAL batch
     la = (iwa[:, None, None, None] * (pred - ea) ** 2).sum() / Bg
     gx = torch.autograd.grad(lx, params, retain_graph=True); ga = torch.autograd.grad(la, params)
-    return torch.stack([torch.cat([v.flatten() for v in gx]), torch.cat([v.flatten() for v in ga])])
+    fp = torch.stack([torch.cat([v.flatten() for v in gx]), torch.cat([v.flatten() for v in ga])])
+    pad = (-fp.shape[1]) % (4 * 8)                    # the flat buffers are 64-float aligned in the engine: shards at N = 8 too
+    return torch.cat([fp, torch.zeros(2, pad)], 1).contiguous()
 per = Bg // world
-mine = flat_pair(slice(rank * per, (rank + 1) * per))
-direct = mine.clone()
-allreduce_flat_grads(mine)
-# the direct exchange (all-to-all reduce-scatter + all-gather) is the same sum, replicas bit-identical
-if direct.numel() % world:
-    direct = torch.cat([direct, torch.zeros(2, 1)], 1).contiguous()
-direct_exchange_flat_grads(direct)
-torch.testing.assert_close(direct[:, :mine.shape[1]], mine, rtol=1e-6, atol=1e-7)
-both = [torch.zeros_like(direct) for _ in range(world)]; dist.all_gather(both, direct)
-assert all(torch.equal(both[0], q) for q in both)
+local = flat_pair(slice(rank * per, (rank + 1) * per))
+P = local.shape[1]
 whole = flat_pair(slice(0, Bg))                       # single-process global-batch oracle
-torch.testing.assert_close(mine, whole, rtol=1e-4, atol=1e-6)
+
+# (1) the serial exchange: one all-reduce of the flat pair = the global-batch gradients, replicas identical
+mine = local.clone()
+allreduce_flat_grads(mine)
+torch.testing.assert_close(mine, whole, rtol=1e-4, atol=1e-5)      # f32 sums in a different order
 g1, s1 = recombine_reference(mine[0], mine[1], 5.0); g2, s2 = recombine_reference(whole[0], whole[1], 5.0)
-torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-6)
+torch.testing.assert_close(g1, g2, rtol=1e-4, atol=1e-5)
 gathered = [torch.zeros_like(g1) for _ in range(world)]; dist.all_gather(gathered, g1)
 assert all(torch.equal(gathered[0], q) for q in gathered)   # replicas stay identical
+
+# (2) the overlapped exchange: TWO grouped collectives -- [tail_x, tail_a] (async, from inside the backward), then
+#     [head_x, head_a] -- give the same sums as the one all-reduce, for any split point
+for split in (0, 7, P // 3, P):
+    ov = local.clone()
+    pend = [allreduce_pieces([ov[k, split:] for k in range(2)], None, async_op=True)] if split < P else []
+    if split > 0:
+        pend.append(allreduce_pieces([ov[k, :split] for k in range(2)], None, async_op=True))
+    for w in pend:
+        w.wait()
+    torch.testing.assert_close(ov, mine, rtol=1e-5, atol=1e-5)           # (gloo sums pieces in another ring order)
+    both = [torch.zeros_like(ov) for _ in range(world)]; dist.all_gather(both, ov)
+    assert all(torch.equal(both[0], q) for q in both), split
+
+# (3) the sharded update: reduce-scatter -> shard-local norm sums (3 doubles all-reduced) / recombine / clip / AdamW ->
+#     all-gather of the parameters.  Slice arithmetic at this world size; same update as the replicated one; moments live on
+#     the owner's shard until they are gathered (mode switch / checkpoint).
+assert can_shard(P, world) and not can_shard(P + 2, world) and not can_shard(P, 1)
+def adamw(p, m, v, gx, ga, sums, step, lr=1e-2, b1=0.9, b2=0.999, eps=1e-8, wd=1e-2, sn=5.0, max_norm=1.0):
+    nx2, na2, dot = (float(q) for q in sums)
+    s = sn / na2 ** 0.5
+    pre = max(nx2 - 2 * s * dot + s * s * na2, 0.0) ** 0.5
+    coef = min(1.0, max_norm / (pre + 1e-6))
+    gg = (gx - s * ga) * coef
+    m.mul_(b1).add_(gg, alpha=1 - b1); v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+    p.mul_(1 - lr * wd).addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
+p_rep = torch.linspace(-1, 1, P).double(); m_rep, v_rep = torch.zeros(P).double(), torch.zeros(P).double()
+p_sh, m_sh, v_sh = p_rep.clone(), m_rep.clone(), v_rep.clone()
+p0 = p_rep.clone()
+full = mine.double()
+for step in (1, 2):
+    sums = torch.stack([full[0] @ full[0], full[1] @ full[1], full[0] @ full[1]])
+    adamw(p_rep, m_rep, v_rep, full[0], full[1], sums, step)                 # replicated update on the all-reduced pair
+    gx_s, ga_s, lo, hi = reduce_scatter_param_shards(local.clone())
+    assert (lo, hi) == (rank * P // world, (rank + 1) * P // world)
+    torch.testing.assert_close(gx_s, mine[0, lo:hi], rtol=1e-4, atol=1e-5)     # rank-order sum vs gloo's ring order
+    part = torch.stack([gx_s.double() @ gx_s.double(), ga_s.double() @ ga_s.double(), gx_s.double() @ ga_s.double()])
+    dist.all_reduce(part)
+    adamw(p_sh[lo:hi], m_sh[lo:hi], v_sh[lo:hi], gx_s.double(), ga_s.double(), part, step)
+    all_gather_params(p_sh, lo, hi)
+    du_s, du_r = p_sh - p0, p_rep - p0                 # same update (AdamW's first steps are sign-like: compare directions)
+    assert float((du_s @ du_r) / (du_s.norm() * du_r.norm())) > 0.9999 and float((du_s - du_r).abs().max()) < 2e-3
+    both = [torch.zeros_like(p_sh) for _ in range(world)]; dist.all_gather(both, p_sh)
+    assert all(torch.equal(both[0], q) for q in both), "sharded update: replicas diverged"
+# outside its shard a rank's moments are stale (still zero) ...
+other = (rank + 1) % world
+assert float(m_sh[other * P // world:(other + 1) * P // world].abs().max()) == 0.0
+# ... until they are gathered: then every rank holds the replicated moments
+all_gather_params(m_sh, lo, hi); all_gather_params(v_sh, lo, hi)
+torch.testing.assert_close(m_sh, m_rep, rtol=1e-3, atol=1e-7); torch.testing.assert_close(v_sh, v_rep, rtol=1e-3, atol=1e-10)
+for buf in (m_sh, v_sh):
+    both = [torch.zeros_like(buf) for _ in range(world)]; dist.all_gather(both, buf)
+    assert all(torch.equal(both[0], q) for q in both), "gathered moments differ between ranks"
 dist.destroy_process_group()
 print("dp ok", rank)
 '''
 
 
-def test_dp_two_ranks_equals_global_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_dp_ranks_equal_global_batch(tmp_path, world):
+    """N = 2 and N = 8 gloo ranks on the CPU: serial all-reduce, the overlapped exchange's two grouped collectives and the
+    sharded update (slice arithmetic, moment re-gather) against the single-process global batch."""
     script = tmp_path / "dp_worker.py"
     script.write_text(DP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT],
-                       env=env, capture_output=True, text=True, timeout=300)
+    port = str(29533 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert r.stdout.count("dp ok") == 2
+    assert r.stdout.count("dp ok") == world
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -317,3 +373,37 @@ def test_lr_multiplier_matches_the_published_schedules():
             opt.step(); sch.step()
     with pytest.raises(NotImplementedError):
         lr_multiplier("polynomial", 0, W, T)
+
+
+def test_delete_sd_schedule_args_noise_offset_and_refusals(monkeypatch):
+    """delete_sd.py:714-719 builds its schedule from lr_warmup_steps * num_processes (config/delete_sd.yaml has no
+    `warmup_steps` key); :546-552 scales the LR; :893-898 adds offset noise; the knobs the loop does not implement
+    (input_perturbation, snr_gamma, a non-epsilon prediction_type, 8-bit Adam) are refused, not ignored."""
+    from siss_amd import hydra_lite as H
+    from siss_amd.tasks import DeleteCeleb, DeleteSD
+    cfgdir = os.path.join(ROOT, "config")
+    c = H.compose("delete_sd", cfgdir, ["lr_warmup_steps=5", "lr_scheduler=constant_with_warmup"])
+    t = DeleteSD(c)
+    assert t.lr_schedule_args(world=1) == (5, int(c.training_steps))
+    assert t.lr_schedule_args(world=8) == (40, int(c.training_steps))
+    cc = H.compose("delete_celeb", cfgdir, ["warmup_steps=7"])
+    assert DeleteCeleb(cc).lr_schedule_args(world=8) == (7, int(cc.training_steps))      # delete_celeb.py:296-301: no world factor
+    t.check_supported()                                                                  # the shipped values pass
+    # scale_lr (delete_sd.py:546-552)
+    lr0 = t.optimizer_args()[0]
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    cs = H.compose("delete_sd", cfgdir, ["scale_lr=true", "train_batch_size=2", "gradient_accumulation_steps=3"])
+    assert abs(DeleteSD(cs).optimizer_args()[0] - lr0 * 3 * 2 * 4) < 1e-18
+    monkeypatch.delenv("WORLD_SIZE")
+    # offset noise: plain noise + offset * one draw per (sample, channel), same generator stream
+    co = H.compose("delete_sd", cfgdir, ["noise_offset=0.1"])
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    got = DeleteSD(co).sample_noise((2, 4, 8, 8), "cpu", g1)
+    base = torch.randn((2, 4, 8, 8), generator=g2)
+    want = base + 0.1 * torch.randn((2, 4, 1, 1), generator=g2)
+    assert torch.equal(got, want)
+    assert torch.equal(t.sample_noise((2, 4, 8, 8), "cpu", torch.Generator().manual_seed(3)), base)
+    for ov, pat in (("input_perturbation=0.1", "input_perturbation"), ("snr_gamma=5.0", "snr_gamma"),
+                    ("prediction_type=v_prediction", "prediction_type"), ("use_8bit_adam=true", "use_8bit_adam")):
+        with pytest.raises(NotImplementedError, match=pat):
+            DeleteSD(H.compose("delete_sd", cfgdir, [ov])).check_supported()
