@@ -48,14 +48,17 @@ def parse():
     return ap.parse_args()
 
 
-CPU_SAMPLE_BATCH = 2
+CPU_MICRO_BATCH = 4          # the CPU oracle walks the B samples of a step in micro-batches of 4 (bounded host memory)
+CPU_CROSS_BATCH = 2          # round 1-2's sample, kept beside the full-size figure as a cross-check
 
 
-def cpu_baseline(cfg_kw, seed, sd=False):
-    """The oracle (CPU restatement pinned by the reference's golden vectors) timed on the host cores on a bounded
-    sample: optimizer steps at batch CPU_SAMPLE_BATCH (1/8 of the GPU workload), fp32 -- one untimed warm-up step
-    (thread pool, oneDNN primitive caches, first-touch of the 0.45 GB of parameters + optimizer state), then one timed.
-    The B = 16 figure derived from it is an EXTRAPOLATION (per-sample cost at batch 2) and is flagged as such."""
+def cpu_baseline(cfg_kw, seed, sd=False, B=16):
+    """The oracle (CPU restatement pinned by the reference's golden vectors) timed on the host cores at the STATED
+    configuration: ONE optimizer step over the full per-GPU batch B, fp32 -- executed as B / 4
+    micro-batches of 4 with gradient accumulation, the way config/delete_celeb.yaml itself ships the step (batch 4 x GA 16;
+    same arithmetic: the loss is normalised by B, GroupNorm / attention are per sample), which bounds the autograd memory on
+    the host.  One untimed warm-up step at batch 4 first (thread pool, oneDNN primitive caches, first touch of the
+    parameters + optimizer state).  Returns (seconds for the B-sample step, cores, seconds for a batch-2 step)."""
     from oracle import schedule as S
     from oracle.loss import OracleDeletionLoss
     from oracle.step import unlearning_step
@@ -79,47 +82,66 @@ def cpu_baseline(cfg_kw, seed, sd=False):
     g = torch.Generator().manual_seed(seed)
     hw = cfg_kw["sample_size"]
     c = cfg_kw["in_channels"]
-    nb = CPU_SAMPLE_BATCH
-    x0 = torch.rand(nb, c, hw, hw, generator=g) * 2 - 1
-    a0 = (torch.rand(1, c, hw, hw, generator=g) * 2 - 1).repeat(nb, 1, 1, 1)
-    noise = torch.randn(nb, c, hw, hw, generator=g)
-    t = torch.full((nb,), 999, dtype=torch.long)
-    u = torch.rand(nb, generator=g)
-    cond = None
+    x0 = torch.rand(B, c, hw, hw, generator=g) * 2 - 1
+    a0 = (torch.rand(1, c, hw, hw, generator=g) * 2 - 1).repeat(B, 1, 1, 1)
+    noise = torch.randn(B, c, hw, hw, generator=g)
+    t = torch.full((B,), 999, dtype=torch.long)
+    u = torch.rand(B, generator=g)
+    ctx = None
     if sd:
         ac = S.alphas_cumprod(beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012)
         x0, a0 = 0.18215 * x0, 0.18215 * a0
-        cond = {"encoder_hidden_states": torch.randn(1, 77, cfg_kw["cross_attention_dim"], generator=g).repeat(nb, 1, 1)}
+        ctx = torch.randn(1, 77, cfg_kw["cross_attention_dim"], generator=g)
     else:
         ac = S.alphas_cumprod()
     opt = torch.optim.AdamW(net.parameters(), lr=5e-6, betas=(0.95, 0.999), weight_decay=1e-6)
     L = OracleDeletionLoss(*S.gamma_sigma(ac))
-    def step():
-        unlearning_step(net, opt, L, "importance_sampling_with_mixture", ac,
-                        [dict(x0=x0, a0=a0, noise=noise, t=t, u=u)], train_batch_size=nb, scaling_norm=500.0,
+
+    def step(n, micro):
+        """one optimizer step over the first n samples in micro-batches of `micro` (train_batch_size x GA = n)"""
+        mbs = [dict(x0=x0[i:i + micro], a0=a0[i:i + micro], noise=noise[i:i + micro], t=t[i:i + micro], u=u[i:i + micro])
+               for i in range(0, n, micro)]
+        cond = {"encoder_hidden_states": ctx.repeat(micro, 1, 1)} if sd else None
+        t0 = time.perf_counter()
+        unlearning_step(net, opt, L, "importance_sampling_with_mixture", ac, mbs, train_batch_size=micro, scaling_norm=500.0,
                         loss_params={"lambd": 0.5}, conditioning=cond)
-    step()                                      # warm-up, untimed
-    t0 = time.perf_counter()
-    step()
-    dt = time.perf_counter() - t0
-    return dt, cores
+        return time.perf_counter() - t0
+    micro = min(CPU_MICRO_BATCH, B)
+    step(micro, micro)                                              # warm-up, untimed
+    dt_cross = step(min(CPU_CROSS_BATCH, B), min(CPU_CROSS_BATCH, B))
+    dt = step(B - B % micro if B >= micro else B, micro)
+    return dt, cores, dt_cross
 
 
 def hbm_traffic(launcher):
     """Average HBM bytes per launch of `launcher`'s kernels from the last committed PMC run
     (profiles/latest_hbm_traffic.json, written by tools/pmc_traffic.sh: 2 x FETCH_SIZE + WRITE_SIZE in separate
     --pmc passes).  PMC counters cannot be read from inside this process, so this is a recorded value of the
-    same command, or None when no profile is committed."""
+    same command, or None when no profile is committed.  Returns (bytes per launch, provenance): the profile carries a
+    fingerprint of the kernel sources it was taken on; a mismatch with the sources of THIS build is reported (and warned
+    about), so a stale profile cannot pass for a measurement of the running kernels."""
     fn = os.path.join(ROOT, "profiles", "latest_hbm_traffic.json")
     if not os.path.exists(fn):
-        return None
+        return None, "no committed profile"
+    prof = json.load(open(fn))
+    meta = prof.pop("__meta__", {})
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from parse_pmc import csrc_fingerprint
+    now = csrc_fingerprint(ROOT)
+    fresh = meta.get("csrc_sha16") == now
+    src = ("profiles/latest_hbm_traffic.json (tag %s): 2 x FETCH_SIZE + WRITE_SIZE of this kernel from two separate rocprofv3 --pmc "
+           "passes of the same command (tools/pmc_traffic.sh); kernel sources of the profile %s, of this build %s: %s"
+           % (meta.get("tag", "?"), meta.get("csrc_sha16", "unrecorded"), now,
+              "SAME sources" if fresh else "STALE -- re-run tools/pmc_traffic.sh"))
+    if not fresh:
+        print("[bench] warning: profiles/latest_hbm_traffic.json was not taken on this build's kernel sources", file=sys.stderr)
     stem = launcher.replace("siss_", "")              # a kernel symbol (gemm_nt_c3p_kernel) or a launcher's family
     tot = n = 0.0
-    for k, v in json.load(open(fn)).items():
+    for k, v in prof.items():
         if k.startswith(stem):
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             n += v["launches"]
-    return round(tot / n) if n else None
+    return (round(tot / n) if n else None), src
 
 
 def main():
@@ -339,12 +361,11 @@ def main():
         dom = max(ksym, key=lambda k: ksym[k][1])
         n, tms, work = ksym[dom]
         ach = work / (tms * 1e-3) / 1e12
-        launcher = "siss_gemm_nt" if dom.startswith("gemm_nt") else "siss_gemm_tn"
+        traffic, traffic_src = hbm_traffic(dom)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": hbm_traffic(dom) if a.config == "celebahq256" else None,     # HBM bytes per launch
-                "traffic_source": "profiles/latest_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel from two "
-                                  "separate rocprofv3 --pmc passes of the same command (tools/pmc_traffic.sh)",
+                "traffic": traffic if a.config == "celebahq256" else None,     # HBM bytes per launch
+                "traffic_source": traffic_src,
                 "launches_per_step": n // ksteps, "avg_launch_us": round(tms / n * 1e3, 2),
                 "tflop_per_launch": round(work / n / 1e12, 4),
                 **({"by_grid": {k: {"achieved": round(v[2] / (v[1] * 1e-3) / 1e12, 2), "launches_per_step": v[0] // ksteps,
@@ -369,17 +390,22 @@ def main():
                                                 "attention_head_dim", "norm_num_groups", "norm_eps",
                                                 "downsample_padding", "flip_sin_to_cos", "freq_shift")
                   + (("cross_attention_dim",) if sd else ())}
-        cdt, cores = cpu_baseline(cfg_kw, 42, sd)
+        cdt, cores, cdt2 = cpu_baseline(cfg_kw, 42, sd, B)
         try:
             model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
         except Exception:
             model = None
-        cpu = {"value": round(CPU_SAMPLE_BATCH / cdt, 5), "unit": "samples/sec", "cores": cores, "cpu_model": model,
+        Bc = B - B % min(CPU_MICRO_BATCH, B) if B >= CPU_MICRO_BATCH else B
+        cpu = {"value": round(Bc / cdt, 5), "unit": "samples/sec", "cores": cores, "cpu_model": model,
                "kind": "port",
-               "sample": f"1 untimed warm-up + 1 timed optimizer step at batch {CPU_SAMPLE_BATCH} ({CPU_SAMPLE_BATCH}/{B} of "
-                         f"the per-GPU batch) of the same UNet/resolution, fp32 torch CPU oracle, {cdt:.1f} s",
-               "extrapolated": True,
-               "steps_per_sec_at_bs%d" % B: round(CPU_SAMPLE_BATCH / (cdt * B), 6)}
+               "sample": f"1 untimed warm-up step at batch {min(CPU_MICRO_BATCH, B)}, then ONE timed optimizer step over the full per-GPU "
+                         f"batch of {Bc} (as {max(Bc // CPU_MICRO_BATCH, 1)} micro-batches of {min(CPU_MICRO_BATCH, B)} with gradient accumulation: "
+                         f"same arithmetic, bounded host memory) of the same UNet / resolution, fp32 torch CPU oracle, {cdt:.1f} s",
+               "extrapolated": False,
+               "steps_per_sec_at_bs%d" % Bc: round(1.0 / cdt, 6),
+               "cross_check": {"batch": min(CPU_CROSS_BATCH, B), "seconds": round(cdt2, 2),
+                               "samples_per_sec": round(min(CPU_CROSS_BATCH, B) / cdt2, 5),
+                               "note": "rounds 1-2 reported this batch-2 step, extrapolated"}}
 
     if rank == 0:
         steps_per_sec = 1e3 / ms

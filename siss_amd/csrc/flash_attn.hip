@@ -364,6 +364,7 @@ int siss_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, fl
                         int D_pad, int valid_k, float scale, void* stream) {
     SISS_CHECK_ARG(q && k && v && o && lse2 && BH > 0 && fa_shape_ok(Sq_pad, Sk_pad, D_pad, valid_k));
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0);
+    siss_count_dispatch(SISS_K_FLASH_FWD);
     const dim3 grid(Sq_pad / kTQ, BH);
     const float sl2 = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
@@ -389,6 +390,7 @@ int siss_flash_attn_bwd(const void* q, const void* k, const void* v, const void*
     SISS_CHECK_ARG(fa_shape_ok(Sq_pad, Sk_pad, D_pad, valid_k));
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 16 == 0);
     SISS_CHECK_ARG(((uintptr_t)lse2 | (uintptr_t)delta) % 16 == 0);
+    siss_count_dispatch(SISS_K_FLASH_BWD);
     const float sl2 = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
 #define FA_BWD(DP)                                                                                                          \

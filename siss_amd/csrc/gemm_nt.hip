@@ -315,7 +315,7 @@ int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
 }
 
 // Diagnostics: number of launches dispatched to device kernel `kernel_id` since the last reset (process-wide):
-// 0 gemm_nt_kernel, 1 gemm_nt_c3p_kernel, 2 gemm_nt_c3_kernel, 3 gemm_nt_conv3_kernel, 4 gemm_nt_kernel split-K (+ reduce),
+// 0 gemm_nt_kernel, 1 gemm_nt_c3p_kernel, 2 flash_fwd_kernel, 3 flash_bwd_dkdv_kernel + flash_bwd_dq_kernel (one count per siss_flash_attn_bwd), 4 gemm_nt_kernel split-K (+ reduce),
 // 5 gemm_tn_kernel<1>, 6 gemm_tn_kernel<3>, 7 GroupNorm slab kernels (forward or backward, small sites),
 // 8 GroupNorm forward on the statistics its producing convolution left (no statistics pass).
 // -1 for an unknown id.  siss_dispatch_reset() zeroes them all.  (Tests use these to prove which kernel a case ran on.)

@@ -93,7 +93,7 @@ _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_sc
              "siss_gn_partial_words", "siss_dispatch_count", "siss_conv_qstats_words"}
 
 # siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
-KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "gemm_nt_c3_kernel": 2, "gemm_nt_conv3_kernel": 3,
+KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "flash_attn_fwd": 2, "flash_attn_bwd": 3,
               "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8}
 
 

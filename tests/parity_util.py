@@ -39,3 +39,31 @@ def assert_update_direction(before, after_ref, after_got, grads_ref, what=""):
     assert frac > 0.5, (what, "mask kept only", frac)
     assert cos >= UPDATE_COS, (what, "masked update cosine", cos, "kept", frac)
     return cos
+
+
+def cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
+def assert_grads_match(eng, names, grads_by_set, dev, zero_ok=("to_k.bias",)):
+    """Per-tensor gradient cosine >= 0.99 and set norms within 5e-2 for every set; returns the worst cosine."""
+    bad, worst = [], (1.0, None)
+    for s, grads in enumerate(grads_by_set):
+        got = {n: v.to(dev) for n, v in eng.ps.grads_ref(s).items()}
+        tot_r = torch.sqrt(sum(v.double().square().sum() for v in grads))
+        tot_g = torch.sqrt(sum(v.double().square().sum() for v in got.values()))
+        assert abs(float(tot_g / tot_r) - 1) < 5e-2, (s, float(tot_g), float(tot_r))
+        for n, r in zip(names, grads):
+            if float(r.norm()) < 1e-8 * float(tot_r):
+                # mathematically zero (softmax is invariant to a constant added to every key's logit): f32 noise in the oracle
+                assert n.endswith(zero_ok), (n, float(r.norm()))
+                assert float(got[n].norm()) < 1e-6 * float(tot_r), (n, float(got[n].norm()), float(tot_r))
+                continue
+            c_ = cos(got[n], r)
+            if c_ < worst[0]:
+                worst = (c_, (s, n))
+            if c_ < 0.99:
+                bad.append((s, n, round(c_, 4), float(r.norm() / tot_r)))
+    assert not bad, (len(bad), bad[:12])
+    return worst

@@ -225,6 +225,54 @@ def test_full_size_forward_and_dual_backward_match_the_fp32_oracle(dev, B):
     assert not bad, (len(bad), bad[:12])
 
 
+def test_full_size_no_is_double_forward_matches_the_fp32_oracle(dev):
+    """BASELINE configs[3] (SISS-No-IS, losses/ddpm_deletion_loss.py:60-67) at full size: ONE 32-image forward (the keep
+    batch q_sample(x0) stacked on the forget batch q_sample(a0), B = 16 each) and the dual backward with
+    x_set_rows = rows_per_set -- set 0 differentiates images [0, 16), set 1 images [16, 32): other grids and tile rounds
+    than the shared-forward SISS step.  Oracle: the fp32 torch network on the same GPU, one 16-image half at a time (samples
+    do not interact: GroupNorm and attention are per sample), which is exactly g_x / g_a of delete_celeb.py:691,:702."""
+    from siss_amd import lib
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.unet import UNetEngine
+    from oracle.unet import OracleUNet2D, UNetConfig
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    B, HW = 16, 256
+    eng = UNetEngine(UNet2DConfig.celebahq256(), dev)
+    sd = eng.init_random(seed=43)
+    net = OracleUNet2D(UNetConfig.celebahq256())
+    net.load_state_dict(sd)
+    net = net.to(dev).float()
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(2 * B, 3, HW, HW, generator=g, device=dev).to(torch.bfloat16)
+    t = torch.full((2 * B,), 999, device=dev)
+    t[1], t[B + 1] = 250, 250
+    cot = torch.randn(2 * B, 3, HW, HW, generator=g, device=dev) * 1e-3
+
+    lib.dispatch_counts(reset=True)
+    pred = eng.forward(x, t).clone()
+    eng.zero_grad()
+    eng.backward(cot.contiguous(), nsets=2)          # nb = nf = 32: every set reads its OWN saved rows
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    assert cnt["gemm_nt_c3p_kernel"] >= 40 and cnt["gemm_tn_kernel<3>"] >= 30, cnt
+
+    names = [n for n, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    grads_by_set, err, scale = [], 0.0, 0.0
+    for s in range(2):
+        sl = slice(s * B, (s + 1) * B)
+        ref = net(x[sl].float(), t[sl])[0]
+        err = max(err, (pred[sl] - ref.detach()).abs().max().item())
+        scale = max(scale, ref.detach().abs().max().item())
+        grads_by_set.append(torch.autograd.grad(ref, params, cot[sl]))
+        del ref
+    assert err <= 3e-2 * scale, (err, scale)
+    from parity_util import assert_grads_match
+    worst = assert_grads_match(eng, names, grads_by_set, dev)
+    print(f"\nfull-size No-IS parity: pred rel err {err / scale:.3g}; worst per-tensor gradient cosine {worst[0]:.5f} at {worst[1]}")
+
+
 def test_grouped_weight_gradient_launch_equals_single_launches(dev):
     """siss_gemm_tn_grouped: a mixed job table (3x3 filters on two resolutions -> the fused 3-tap variant, a linear and a
     1x1 conv -> the one-tap variant; one and two cotangent sets; bias gradients) in ONE call against the same products

@@ -267,6 +267,51 @@ def test_sd15_full_size_step_runs():
     assert abs(s["scaling_factor"] * s["norm_loss_a"] - 750.0) < 1.0       # norm fixing: ||s g_a|| = scaling_norm
 
 
+def test_sd15_full_size_forward_and_dual_backward_match_the_fp32_oracle(dev):
+    """BASELINE configs[4] at full size: the SD v1.5 UNet (859,520,964 parameters, 686 tensors), B = 2, 64 x 64 latents,
+    77 x 768 text -- forward + ONE dual-cotangent backward on HIP against `OracleUNet2DCondition` in fp32 on the same GPU
+    (two autograd passes with retain_graph, like delete_sd.py:1045-1060).  pred max-err <= 3e-2 max|pred|; per-tensor
+    gradient cosine >= 0.99 for all 686 tensors of both sets; set norms within 5e-2; the fused attention kernels ran."""
+    from siss_amd import lib
+    from siss_amd.config import UNet2DConditionConfig
+    from siss_amd.unet_cond import UNetCondEngine
+    from oracle.unet_cond import OracleUNet2DCondition, UNetCondConfig
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    B = 2
+    eng = UNetCondEngine(UNet2DConditionConfig.sd15(), dev)
+    sd = eng.init_random(seed=2)
+    assert len(sd) == 686 and sum(v.numel() for v in sd.values()) == 859_520_964
+    net = OracleUNet2DCondition(UNetCondConfig.sd15())
+    net.load_state_dict(sd)
+    net = net.to(dev).float()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(B, 4, 64, 64, generator=g, device=dev).to(torch.bfloat16)
+    t = torch.tensor([999, 250], device=dev)
+    ctx = torch.randn(B, 77, 768, generator=g, device=dev).to(torch.bfloat16)
+    cx = torch.randn(B, 4, 64, 64, generator=g, device=dev) * 1e-3
+    ca = torch.randn(B, 4, 64, 64, generator=g, device=dev) * 1e-3
+
+    lib.dispatch_counts(reset=True)
+    pred = eng.forward(x, t, encoder_hidden_states=ctx).clone()
+    eng.zero_grad()
+    eng.backward(torch.cat([cx, ca]).contiguous(), nsets=2)
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    assert cnt["flash_attn_fwd"] == 32 and cnt["flash_attn_bwd"] == 32, cnt      # 16 transformer blocks x (self, cross)
+
+    ref = net(x.float(), t, ctx.float())[0]
+    err = (pred - ref.detach()).abs().max().item()
+    scale = ref.detach().abs().max().item()
+    assert err <= 3e-2 * scale, (err, scale)
+    names = [n for n, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    grads_by_set = [torch.autograd.grad(ref, params, c, retain_graph=(s == 0)) for s, c in enumerate((cx, ca))]
+    from parity_util import assert_grads_match
+    worst = assert_grads_match(eng, names, grads_by_set, dev, zero_ok=("to_k.bias",))
+    print(f"\nSD v1.5 full-size parity: pred rel err {err / scale:.3g}; worst per-tensor gradient cosine {worst[0]:.5f} at {worst[1]}")
+
+
 # ---------------------------------------------------------------- drop-in surface for delete_sd.py
 @pytest.mark.parametrize("loss_fn", ["importance_sampling_with_mixture", "double_forward_with_neg_del"])
 def test_reference_style_sd_loop_on_hip_surface(dev, loss_fn):

@@ -30,6 +30,18 @@ def counters(d, counter):
     return acc
 
 
+def csrc_fingerprint(root):
+    """sha256 over the kernel sources (sorted siss_amd/csrc/*): bench.py recomputes it to say whether the committed traffic
+    profile was taken on the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "siss_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fetch_dir, write_dir, prof_dir, tag = sys.argv[1:5]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,7 +55,9 @@ def main():
         wb = w[1] * 1024 / max(w[0], 1)
         traffic[k] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wb,
                       "hbm_bytes_per_launch": rd + wb}
+    traffic["__meta__"] = {"tag": tag, "csrc_sha16": csrc_fingerprint(root)}
     json.dump(traffic, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1, sort_keys=True)
+    del traffic["__meta__"]
     stats = glob.glob(os.path.join(prof_dir, "*", "*_kernel_stats.csv"))[0]
     rows = list(csv.DictReader(open(stats)))
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
