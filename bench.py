@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--loss-fn", default="importance_sampling_with_mixture")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("SISS_GRAPH", "1")),
                     help="replay the step from a captured hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--engine-attr", action="append", default=[], help="name=int: set a schedule switch of the engine (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -183,6 +184,10 @@ def main():
                            up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D"))
     B, hw, cin = a.batch, cfg.sample_size, cfg.in_channels
     eng = UNetCondEngine(cfg, dev) if sd else UNetEngine(cfg, dev)
+    for kv in filter(None, a.engine_attr):                   # A/B of a schedule switch on one box, e.g. --engine-attr fold_shortcut=0
+        k, v = kv.split("=")
+        assert hasattr(eng, k), k
+        setattr(eng, k, type(getattr(eng, k))(int(v)))
     eng.init_random(seed=42)                       # same weights on every rank (config/delete_celeb.yaml:4)
     g = torch.Generator(device=dev).manual_seed(42 + rank)      # per-rank shard of the synthetic stream
     cond = None

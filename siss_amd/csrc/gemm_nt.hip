@@ -348,7 +348,8 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
                      const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
                      const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
                      int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream,
-                     float* qstats = nullptr, int* qstats_written = nullptr, int d2s = 0) {
+                     float* qstats = nullptr, int* qstats_written = nullptr, int d2s = 0, const void* A2 = nullptr, long lda2 = 0,
+                     const void* W2 = nullptr, int K2 = 0, const float* bias2 = nullptr) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
     if (qstats_written) *qstats_written = 0;
     SISS_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % BK == 0 && npanels >= 1 && npanels <= kMaxPanels);
@@ -365,6 +366,9 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     p.ksplit = 1; p.slab = nullptr; p.qstats = nullptr; p.d2s = d2s;
+    p.A2 = (const bf16_t*)A2; p.W2 = (const bf16_t*)W2; p.bias2 = A2 ? bias2 : nullptr; p.lda2 = lda2; p.K2 = A2 ? K2 : 0;
+    SISS_CHECK_ARG(!A2 || (W2 && K2 > 0 && K2 % BK == 0 && lda2 % 8 == 0 && lda2 >= K2 && !R && npanels == 9 &&
+                           ((uintptr_t)A2 | (uintptr_t)W2) % 16 == 0 && (!bias2 || (uintptr_t)bias2 % 16 == 0)));
 #ifdef SISS_PROBE
     { const char* e = getenv("SISS_NT_ABLATE"); p.ablate = e ? atoi(e) : 0; }
     { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
@@ -390,7 +394,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
         constexpr long kC3pMinTiles = 256;
         const long tiles = (long)cdiv(M, 128) * cdiv(N, BN);
         const bool fits32 = (long)M * ldc * 2 < (1L << 32) && (!R || (long)M * ldr * 2 < (1L << 32)) && (long)(M + 2) * lda * 2 < (1L << 32) &&
-                            (long)N * Kp * 2 < (1L << 32);
+                            (long)N * Kp * 2 < (1L << 32) && (!A2 || ((long)(M + 2) * lda2 * 2 < (1L << 32) && (long)N * K2 * 2 < (1L << 32)));
         if (conv3 && N % BN == 0 && rows_per_image >= 256 && (Wp == 0 || Wp >= 8) && tiles >= kC3pMinTiles && fits32) {
             if (qstats && Hp > 0 && ((uintptr_t)qstats % 16) == 0) {
                 p.qstats = qstats;                          // only the persistent kernel forms them; the caller is told
@@ -399,6 +403,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
             return siss_launch_gemm_nt_c3p(&p, stream);
         }
     }
+    SISS_CHECK_ARG(!A2);                                       // only the persistent kernel folds a shortcut in (callers ask siss_conv3x3_sc_takes first)
     // Large grids: single-buffered blocks at 4 per CU (latency hidden by the other three) measured 10-15 %
     // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;
@@ -453,6 +458,27 @@ int siss_gemm_nt_qstats(const void* A, long lda, const void* W, void* C, long ld
     SISS_CHECK_ARG(qstats && written);
     return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, Kp, npanels, shifts, coffs,
                             rows_per_image, Hp, Wp, alpha, 1, 0, 0, 0, nullptr, 0, stream, qstats, written);
+}
+
+// A ResnetBlock2D's tail in ONE product: C = conv3x3(A; W) + conv1x1(A2; W2) + bias + bias2 (+ rowbias) -- the 1x1 shortcut convolution
+// (A2: the block's input, row stride lda2, K2 channels, a multiple of 64; W2 [N][K2] bf16; bias2 f32 [N] or null) rides in the 3x3
+// product as K2 / 64 more K-groups per tile with an A base of their own (centre tap), instead of a launch of its own whose output
+// comes back as the 3x3 product's residual.  Only the persistent 3x3 kernel does this: siss_conv3x3_sc_takes says (host side, no
+// launch) whether a product of this shape lands there; when it does not, run the 1x1 product and pass its result as R to siss_gemm_nt.
+// qstats / written: as siss_gemm_nt_qstats (both may be null).  Each term is accumulated in f32 and rounded ONCE (the two-launch form
+// rounds the shortcut's output to bf16 first).
+int siss_conv3x3_sc_takes(int M, int N, int Kp, int K2, int rows_per_image, int Wp, long lda, long ldc, long lda2) {
+    if (M <= 0 || N <= 0 || Kp <= 0 || Kp % BK || K2 <= 0 || K2 % BK || N % BN || rows_per_image < 256 || (Wp != 0 && Wp < 8)) return 0;
+    if ((long)cdiv(M, 128) * cdiv(N, BN) < 256) return 0;
+    return (long)M * ldc * 2 < (1L << 32) && (long)(M + 2) * lda * 2 < (1L << 32) && (long)N * Kp * 2 < (1L << 32) &&
+           (long)(M + 2) * lda2 * 2 < (1L << 32) && (long)N * K2 * 2 < (1L << 32);
+}
+int siss_conv3x3_sc(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const float* rowbias, long ldrb,
+                    const void* A2, long lda2, const void* W2, int K2, const float* bias2, int M, int N, int Kp, const int* shifts,
+                    const int* coffs, int rows_per_image, int Hp, int Wp, float* qstats, int* written, void* stream) {
+    SISS_CHECK_ARG(A2 && W2 && siss_conv3x3_sc_takes(M, N, Kp, K2, rows_per_image, Wp, lda, ldc, lda2));
+    return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, nullptr, 0, M, N, Kp, 9, shifts, coffs, rows_per_image, Hp, Wp,
+                            1.0f, 1, 0, 0, 0, nullptr, 0, stream, qstats, written, 0, A2, lda2, W2, K2, bias2);
 }
 
 // siss_gemm_nt whose rows are the pixels of ONE space-to-depth plane (plane = 2 py + px) of a stride-2 convolution's input: the

@@ -21,6 +21,13 @@
 // the producers pass barrier #g only after group g has landed (vmcnt(0)), then issue group g+1 into the slot that
 // group g-1 just left.  The group sequence simply continues over tile boundaries: while the consumers run the
 // epilogue of tile i, tile i+1's first group is already landing.
+//
+// Folded 1x1 shortcut (NTParams::A2): a resnet's conv_shortcut(x) + conv2(h) is ONE accumulation -- after the 3 * Kp / 64 groups
+// of the 3x3 filter every tile runs K2 / 64 "shortcut groups": the A tile comes from the second tensor (its own row stride),
+// staged at the centre row's shift so that the centre tap's read offset (row + 1) lands on the pixel itself, beside ONE weight
+// tile in the centre tap's slot; the consumers run the 4 centre-tap blocks of 16 MFMAs.  The 1x1 product's own launch (an
+// HBM-bound GEMM: 173 us at 256 x 256, 256 -> 128 channels), its output tensor and the residual read of the 3x3 launch's store
+// path (+ 50 us) disappear for K2 / (9 Kp) more MFMA work.
 #include "nt_common.h"
 #include <type_traits>
 
@@ -66,7 +73,9 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
     int count = 0;
     while (tm.tile(count) < tm.ntiles) ++count;
     const int kchunks = p.Kp / BK;
-    const int gpt = 3 * kchunks;                           // groups per tile
+    const int k2chunks = p.A2 ? p.K2 / BK : 0;             // folded 1x1 shortcut: more K-groups per tile, centre tap only
+    const int g3 = 3 * kchunks;                            // groups of the 3x3 filter per tile
+    const int gpt = g3 + k2chunks;                         // groups per tile
     const int G = count * gpt;
     if (G == 0) return;
     const long wtap = (long)p.N * p.Kp;
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         // VGPR offset): per piece the store waves issue s_mov m0 + the load and NO vector arithmetic -- the 64-bit per-lane
         // pointer form cost a v_lshl_add_u64 and an m0 save / restore per piece, on a SIMD they share with an MFMA wave.
         // (m0 is a reserved register the compiler sets itself before each of its own uses; nothing here relies on its value.)
-        unsigned aoffs[8], woffs[4];
+        unsigned aoffs[8], woffs[4], aoffs2[8], woffs2[4];
         auto set_tile = [&](int k) {
             const int t = tm.tile(k);
             const int m0 = (t / tm.tiles_n) * P_VALID, n0 = (t % tm.tiles_n) * BN;
@@ -100,27 +109,54 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                 const int row = (pw * 4 + j) * 8 + prow;
                 woffs[j] = (unsigned)(((long)(n0 + row) * p.Kp + ((pc ^ swz3p(row)) << 3)) * 2);
             }
+            if (k2chunks) {                                // (uniform) the shortcut operand: other row strides
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int row = (pw * 8 + j) * 8 + prow;
+                    int gr = m0 + row; gr = gr < p.M + 1 ? gr : p.M + 1;
+                    aoffs2[j] = (unsigned)(((long)gr * p.lda2 + ((pc ^ swz3p(row)) << 3)) * 2);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = (pw * 4 + j) * 8 + prow;
+                    woffs2[j] = (unsigned)(((long)(n0 + row) * p.K2 + ((pc ^ swz3p(row)) << 3)) * 2);
+                }
+            }
         };
         auto dma = [&](unsigned off, const void* base, unsigned dst) __attribute__((always_inline)) {
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(off), "s"(dst), "s"(base) : "memory");
         };
         auto issue_group = [&]() {
-            const long aoff = (long)p.shift[3 * gky] * p.lda + p.coff[3 * gky] + gkc * BK;
-            const long woff = 3L * gky * wtap + gkc * BK;
             const unsigned dst = smem_a + (issued & 1) * P_SLOT;
-            if (!(C3P_ABLATE(2) && issued >= 2)) {
-                const bf16_t* abase = p.A + aoff;
+            if (gky < 3) {
+                const long aoff = (long)p.shift[3 * gky] * p.lda + p.coff[3 * gky] + gkc * BK;
+                const long woff = 3L * gky * wtap + gkc * BK;
+                if (!(C3P_ABLATE(2) && issued >= 2)) {
+                    const bf16_t* abase = p.A + aoff;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dma(aoffs[j], abase, dst + (pw * 8 + j) * 1024);
+                    for (int j = 0; j < 8; ++j) dma(aoffs[j], abase, dst + (pw * 8 + j) * 1024);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const bf16_t* wbase = p.W + woff + t * wtap;
+                    for (int t = 0; t < 3; ++t) {
+                        const bf16_t* wbase = p.W + woff + t * wtap;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dma(woffs[j], wbase, dst + P_ABYTES + t * P_WBYTES + (pw * 4 + j) * 1024);
+                        for (int j = 0; j < 4; ++j) dma(woffs[j], wbase, dst + P_ABYTES + t * P_WBYTES + (pw * 4 + j) * 1024);
+                    }
                 }
+            } else {
+                // shortcut group: A2 staged at the centre ROW's shift (shift[3] = shift[4] - 1), so the centre tap's read offset
+                // (tile row + 1) is the pixel itself; one weight tile, in the centre tap's slot
+                const bf16_t* abase = p.A2 + (long)p.shift[3] * p.lda2 + gkc * BK;
+                const bf16_t* wbase = p.W2 + gkc * BK;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dma(aoffs2[j], abase, dst + (pw * 8 + j) * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dma(woffs2[j], wbase, dst + P_ABYTES + P_WBYTES + (pw * 4 + j) * 1024);
             }
             ++issued;
-            if (++gkc == kchunks) { gkc = 0; if (++gky == 3) { gky = 0; ++gk; if (gk < count) set_tile(gk); } }
+            if (++gkc == (gky < 3 ? kchunks : k2chunks)) {
+                gkc = 0;
+                if (++gky == (k2chunks ? 4 : 3)) { gky = 0; ++gk; if (gk < count) set_tile(gk); }
+            }
         };
 
         // The parked tile of the previous tile, in registers: lane -> (row = it*8 + lane>>3, 16-B chunk = lane&7).
@@ -321,48 +357,45 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int g = 0; g < gpt; ++g, ++gg) {
+        // One group: blocks [B0, B1) of 16 MFMAs, block b = (tap t = b >> 2, k-half kk = (b >> 1) & 1, m-half h = b & 1).  The (4 or
+        // 8) fragment reads of block b+1 are issued ONE behind each of the first MFMAs of block b instead of as a burst in front
+        // of them -- a consumer wave is alone on its SIMD as far as MFMAs go, so every cycle it spends issuing a burst of reads is
+        // a cycle the matrix pipe drains (measured +2.6 %: 1064 -> 1092 TF/s over a step).
+        auto run_group = [&](auto b0c, auto b1c) __attribute__((always_inline)) {
+            constexpr int B0 = decltype(b0c)::value, B1 = decltype(b1c)::value;
             const char* sl = smem + (gg & 1) * P_SLOT;
-            auto ldA = [&](bf16x8_t (&dst)[4], int t, int kk, int h) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    dst[jj] = *reinterpret_cast<const bf16x8_t*>(sl + (a_base[t] ^ (kk << 6)) + (h * 4 + jj) * 2048);
-            };
-            auto ldW = [&](bf16x8_t (&dst)[4], int t, int kk) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    dst[i] = *reinterpret_cast<const bf16x8_t*>(sl + (w_base ^ (kk << 6)) + t * P_WBYTES + i * 2048);
-            };
             c3p_barrier();                                 // #gg: this group's slot has landed
-            if (C3P_ABLATE(4)) continue;
-            ldW(wf[0], 0, 0);
-            ldA(af[0], 0, 0, 0);
-            {
-                // The (4 or 8) fragment reads of block b+1 are issued ONE behind each of the first MFMAs of block b instead of as a
-                // burst in front of them -- a consumer wave is alone on its SIMD as far as MFMAs go, so every cycle it spends
-                // issuing a burst of reads is a cycle the matrix pipe drains (measured +2.6 %: 1064 -> 1092 TF/s over a step).
+            if (C3P_ABLATE(4)) return;
 #pragma unroll
-                for (int b = 0; b < 12; ++b) {
-                    const int h = b & 1;
-                    const int nb = b + 1, nt = nb >> 2, nkk = (nb >> 1) & 1, nh = nb & 1;
-                    const bool more = b + 1 < 12;
-                    const int nreads = more ? (nh == 0 ? 8 : 4) : 0;
+            for (int i = 0; i < 4; ++i)
+                wf[(B0 >> 1) & 1][i] = *reinterpret_cast<const bf16x8_t*>(sl + (w_base ^ (((B0 >> 1) & 1) << 6)) + (B0 >> 2) * P_WBYTES + i * 2048);
 #pragma unroll
-                    for (int m = 0; m < 16; ++m) {
-                        const int i = m >> 2, jj = m & 3;
-                        acc[i][h * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(b >> 1) & 1][i], af[b & 1][jj],
-                                                                                     acc[i][h * 4 + jj], 0, 0, 0);
-                        if (m < nreads) {
-                            if (m < 4)
-                                af[nb & 1][m] = *reinterpret_cast<const bf16x8_t*>(sl + (a_base[nt] ^ (nkk << 6)) + (nh * 4 + m) * 2048);
-                            else
-                                wf[(nb >> 1) & 1][m - 4] = *reinterpret_cast<const bf16x8_t*>(sl + (w_base ^ (nkk << 6)) + nt * P_WBYTES + (m - 4) * 2048);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+            for (int jj = 0; jj < 4; ++jj)
+                af[B0 & 1][jj] = *reinterpret_cast<const bf16x8_t*>(sl + (a_base[B0 >> 2] ^ (((B0 >> 1) & 1) << 6)) + ((B0 & 1) * 4 + jj) * 2048);
+#pragma unroll
+            for (int b = B0; b < B1; ++b) {
+                const int h = b & 1;
+                const int nb = b + 1, nt = nb >> 2, nkk = (nb >> 1) & 1, nh = nb & 1;
+                const bool more = b + 1 < B1;
+                const int nreads = more ? (nh == 0 ? 8 : 4) : 0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const int i = m >> 2, jj = m & 3;
+                    acc[i][h * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(b >> 1) & 1][i], af[b & 1][jj],
+                                                                                 acc[i][h * 4 + jj], 0, 0, 0);
+                    if (m < nreads) {
+                        if (m < 4)
+                            af[nb & 1][m] = *reinterpret_cast<const bf16x8_t*>(sl + (a_base[nt] ^ (nkk << 6)) + (nh * 4 + m) * 2048);
+                        else
+                            wf[(nb >> 1) & 1][m - 4] = *reinterpret_cast<const bf16x8_t*>(sl + (w_base ^ (nkk << 6)) + nt * P_WBYTES + (m - 4) * 2048);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        }
+        };
+        // (two loops, not one loop with a branch: the accumulators must not meet at a merge point of two code paths)
+        for (int g = 0; g < g3; ++g, ++gg) run_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
+        for (int g = g3; g < gpt; ++g, ++gg) run_group(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});   // shortcut: centre tap
         C3P_TICK(0);
 
         // ---- consumer half of the epilogue: alpha, bias and the per-image row bias in f32, ONE rounding to bf16
@@ -380,6 +413,11 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             b0[i] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + ncol + i * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (p.bias2) {
+                const f32x4_t s2 = *reinterpret_cast<const f32x4_t*>(p.bias2 + ncol + i * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b0[i][e] += s2[e];
+            }
             b1[i] = b0[i];
         }
         if (p.rowbias) {
@@ -410,7 +448,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             };
             // almost every tile lies inside one image: no per-row select between the two images' row biases; a product without
             // bias, row bias and scale (every dgrad launch) only rounds its accumulators
-            if (!p.bias && !p.rowbias && p.alpha == 1.f) {
+            if (!p.bias && !p.bias2 && !p.rowbias && p.alpha == 1.f) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll

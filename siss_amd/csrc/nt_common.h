@@ -29,6 +29,11 @@ struct NTParams {
     float* qstats;                    // optional (persistent 3x3 kernel only): per-(half tile, image slot, 4-channel quad) sums and
                                       // sums of squares of the bf16 OUTPUT, [2 * row tiles][2][N / 4][2] f32 -- the GroupNorm that
                                       // consumes the result folds them instead of reading the tensor a second time
+    // Optional 1x1 shortcut convolution folded into a 3x3 one (persistent 3x3 kernel only; ResnetBlock2D.conv_shortcut beside conv2):
+    //   C += A2[r, 0:K2] . W2[n][0:K2] + bias2[n]   -- K2 / 64 more K-groups per tile with an A base of their own, centre tap only
+    const bf16_t* A2; const bf16_t* W2; const float* bias2;
+    long lda2;
+    int K2;
     int shift[kMaxPanels];
     int coff[kMaxPanels];
 };

@@ -88,6 +88,27 @@ def conv_fprop_qstats(x: Act, w_bf16, out: Act, qstats, **kw):
                    rows_per_image=x.rows_per_image, hp=x.hp, wp=x.wp, qstats=qstats)
 
 
+def conv3x3_sc_takes(x: Act, co, out, x2: Act):
+    """Whether conv_fprop_sc can fold the 1x1 shortcut over `x2` into the 3x3 product over `x` (the persistent kernel takes it)."""
+    return bool(lib.query("siss_conv3x3_sc_takes", x.rows, co, x.c, x2.c, x.rows_per_image, x.wp, getattr(x, "ld", x.c),
+                          getattr(out, "ld", out.c), getattr(x2, "ld", x2.c)))
+
+
+def conv_fprop_sc(x: Act, w_bf16, out: Act, x2: Act, w2_bf16, bias=None, bias2=None, rowbias=None, ldrb=None, qstats=None):
+    """out = conv3x3(x; w) + conv1x1(x2; w2) + bias + bias2 (+ rowbias[img]) in ONE product (siss_conv3x3_sc): a resnet's
+    conv2 + conv_shortcut.  Returns whether the GroupNorm statistics were written to `qstats`."""
+    t, co, ci = w_bf16.shape
+    assert t == 9 and ci == x.c and co == out.c and (x.n, x.h, x.w) == (out.n, out.h, out.w) == (x2.n, x2.h, x2.w)
+    assert tuple(w2_bf16.shape[-2:]) == (co, x2.c)
+    shifts, coffs = conv3x3_panels(x.wp, ci)
+    written = lib.C.c_int(0)
+    lib.call("siss_conv3x3_sc", x.data, getattr(x, "ld", x.c), w_bf16, out.data, getattr(out, "ld", out.c), bias, rowbias,
+             ldrb if ldrb is not None else co, x2.data, getattr(x2, "ld", x2.c), w2_bf16, x2.c, bias2, x.rows, co, ci,
+             lib.int_array(shifts), lib.int_array(coffs), x.rows_per_image, x.hp, x.wp, qstats,
+             lib.C.byref(written) if qstats is not None else None)
+    return bool(written.value)
+
+
 def conv_dgrad(dy: Act, wT_bf16, out: Act, residual: Act = None, ksize=3):
     """out = conv_transpose(dy) for a stride-1 'same' conv; wT_bf16 from dgrad_weight()."""
     t, ci, co = wT_bf16.shape

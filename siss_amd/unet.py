@@ -157,6 +157,7 @@ class UNetEngine:
     epi_stats = True       # GroupNorm statistics from the producing conv's epilogue (no statistics pass at the large sites)
     d2s_epilogue = True    # downsample dgrad: depth-to-space in the plane GEMMs' epilogue (no dz tensor, no scatter pass)
     direct_cat = True      # convs that feed a concat write into the concat buffer directly (False: copy both parts)
+    fold_shortcut = True   # a resnet's 1x1 conv_shortcut rides in its conv2's 3x3 product (False: own product + residual add)
     # Weight gradients of the LOW-RESOLUTION layers (at most group_rows reduction rows per set: the 8x8 .. 32x32 levels) are not
     # launched one by one -- each alone leaves most CUs idle and pays a launch's fixed ~10-40 us -- but queued and run as grouped
     # launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).  They only feed the flat gradient buffer, so
@@ -493,16 +494,21 @@ class UNetEngine:
         return y, bwd
 
     def conv(self, x: Act, pre, ksize=3, rowbias=None, residual: Act = None, out_name=None, ldrb=None, cat_with=None,
-             skip_head=None, want_stats=False):
+             skip_head=None, want_stats=False, shortcut=None, fprop=True):
         """stride-1 'same' conv (3x3 or 1x1) with fused bias / time-embedding row bias / residual.  cat_with: the skip
         activation the result is about to be concatenated with -- the result is then written straight into the head
-        columns of that concat buffer (epilogue with ldc = C + C_skip) and concat() only copies the skip."""
+        columns of that concat buffer (epilogue with ldc = C + C_skip) and concat() only copies the skip.
+        shortcut = (x2, pre2): also add the 1x1 convolution `pre2` of x2 (a resnet's conv_shortcut) -- folded into the 3x3
+        product when its kernel takes it (ops.conv_fprop_sc), otherwise as a product of its own whose result is the residual.
+        fprop=False: no forward launch, only the backward closure (the folded shortcut's own dgrad / wgrad)."""
         ps = self.ps
         w = ps.sh(pre + ".weight")
         if ksize == 1:
             w = w.view(1, *w.shape)
         co = w.shape[1]
-        if cat_with is not None and self.direct_cat:
+        if not fprop:
+            y = None
+        elif cat_with is not None and self.direct_cat:
             assert (cat_with.n, cat_with.h, cat_with.w) == (x.n, x.h, x.w)
             if isinstance(cat_with, ActView):       # the skip already lives in the tail columns of its concat buffer
                 assert cat_with.c0 == co and cat_with.base.c == co + cat_with.c
@@ -517,13 +523,28 @@ class UNetEngine:
             y = self._act(self._name(out_name or pre), x.n, x.h, x.w, co)
         # want_stats: the result feeds a GroupNorm -- at the sites where that GroupNorm would make a statistics pass of its
         # own (more than 32 x 32 pixels) the conv's epilogue leaves the statistics (y.qstats) when its kernel can
-        y.qstats = None
-        if want_stats and self.epi_stats and ksize == 3 and x.h * x.w > 1024 and co % 128 == 0:
-            qs = self._buf(self._name(pre) + ".qs", (lib.query("siss_conv_qstats_words", x.rows, co),))
-            if ops.conv_fprop_qstats(x, w, y, qs, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ldrb=ldrb):
-                y.qstats = qs
-        else:
-            ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
+        if fprop:
+            y.qstats = None
+            stats = want_stats and self.epi_stats and ksize == 3 and x.h * x.w > 1024 and co % 128 == 0
+            qs = self._buf(self._name(pre) + ".qs", (lib.query("siss_conv_qstats_words", x.rows, co),)) if stats else None
+            folded = False
+            if shortcut is not None:
+                x2, pre2 = shortcut
+                assert residual is None and ksize == 3
+                if self.fold_shortcut and ops.conv3x3_sc_takes(x, co, y, x2):
+                    if ops.conv_fprop_sc(x, w, y, x2, ps.sh(pre2 + ".weight"), bias=ps.p(pre + ".bias"), bias2=ps.p(pre2 + ".bias"),
+                                         rowbias=rowbias, ldrb=ldrb, qstats=qs):
+                        y.qstats = qs
+                    folded = True
+                else:
+                    residual, _ = self.conv(x2, pre2, ksize=1)
+            if folded:
+                pass
+            elif stats:
+                if ops.conv_fprop_qstats(x, w, y, qs, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ldrb=ldrb):
+                    y.qstats = qs
+            else:
+                ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
 
         def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None):
             dW = ps.grads[self.gbase:, ps.specs[pre + ".weight"].off:]
@@ -620,11 +641,13 @@ class UNetEngine:
         a2, gn2_b = self.gn(h, pre + ".norm2", True)
         has_sc = cin != cout
         if has_sc:
-            sc, sc_b = self.conv(x, pre + ".conv_shortcut", ksize=1)
-            res = sc
+            # conv_shortcut(x) + conv2(a2) as one accumulation where the 3x3 kernel takes it (else: a 1x1 product + residual);
+            # the shortcut's backward (dgrad into x's cotangent, wgrad) stays a product of its own
+            _, sc_b = self.conv(x, pre + ".conv_shortcut", ksize=1, fprop=False)
+            out, c2_b = self.conv(a2, pre + ".conv2", cat_with=cat_with, skip_head=skip_head, want_stats=True,
+                                  shortcut=(x, pre + ".conv_shortcut"))
         else:
-            res = x
-        out, c2_b = self.conv(a2, pre + ".conv2", residual=res, cat_with=cat_with, skip_head=skip_head, want_stats=True)
+            out, c2_b = self.conv(a2, pre + ".conv2", residual=x, cat_with=cat_with, skip_head=skip_head, want_stats=True)
 
         def bwd():
             nb = self.nb

@@ -120,6 +120,78 @@ def test_conv3x3_on_the_persistent_and_fused_wgrad_kernels(dev, n, h, w, ci, co,
         _close(dB[s].cpu(), dy[s * n:(s + 1) * n].sum(dim=(0, 2, 3)), 2e-3, f"bias grad set {s}")
 
 
+# (n, h, w, cin of the 3x3, cout, channels of the shortcut's input, row stride of that input [0 = its channel count], statistics)
+SC_CASES = [
+    (2, 128, 128, 128, 128, 256, 0, False),      # up-block shape: 256-channel concat -> 128; one tile crosses the image seam
+    (1, 256, 256, 128, 128, 256, 0, True),       # two tile rounds; GroupNorm statistics of the sum from the store path
+    (4, 64, 64, 256, 256, 128, 0, False),        # down-block shape 128 -> 256: two column tiles, K2 < Kp
+    (3, 96, 96, 128, 128, 192, 320, True),       # K2 = 192 (three shortcut groups), the input is a column view of a wider buffer
+    (8, 64, 64, 64, 128, 64, 0, False),          # ONE k-chunk per filter row and ONE shortcut group: four groups per tile
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,c2,ld2,stats", SC_CASES)
+def test_conv3x3_with_the_1x1_shortcut_folded_in(dev, n, h, w, ci, co, c2, ld2, stats):
+    """siss_conv3x3_sc: conv3x3(a; W) + conv1x1(x; W_sc) + both biases + the per-image row bias as ONE product on the
+    persistent kernel (ResnetBlock2D: conv2 + conv_shortcut, diffusers resnet.py -> losses/ddpm_deletion_loss.py:24)
+    against torch fp32 on the same bf16-rounded operands; the statistics variant against the stored tensor."""
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act, ActView
+    g = torch.Generator().manual_seed(n * 100 + h + c2)
+    a = _bf(torch.randn(n, ci, h, w, generator=g))
+    x = _bf(torch.randn(n, c2, h, w, generator=g))
+    wt = _bf(torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3 * ci ** 0.5)))
+    ws = _bf(torch.randn(co, c2, 1, 1, generator=g) * (1.0 / c2 ** 0.5))
+    b1, b2 = torch.randn(co, generator=g), torch.randn(co, generator=g)
+    temb = torch.randn(n, co, generator=g)
+    ref = F.conv2d(a, wt, b1, padding=1) + F.conv2d(x, ws, b2) + temb[:, :, None, None]
+
+    aa = Act.from_nchw(a, dev)
+    if ld2:
+        wide = Act(n, h, w, ld2, dev)
+        xa = ActView(wide, ld2 - c2, c2)                    # the shortcut input lives in the TAIL columns of a wider buffer
+        wide.buf.normal_()                                  # ... whose other columns hold garbage
+        xa.data.copy_(Act.from_nchw(x, dev).data)
+    else:
+        xa = Act.from_nchw(x, dev)
+    out = Act(n, h, w, co, dev)
+    out.buf.fill_(7.0)
+    out.buf[: out.guard * co] = 0
+    out.buf[-out.guard * co:] = 0
+    assert ops.conv3x3_sc_takes(aa, co, out, xa)
+    qs = torch.full((lib.query("siss_conv_qstats_words", aa.rows, co),), float("nan"), device=dev) if stats else None
+    lib.dispatch_counts(reset=True)
+    wrote = ops.conv_fprop_sc(aa, ops.conv_w_to_native(wt).to(dev).to(torch.bfloat16), out, xa, ws.view(co, c2).to(dev).to(torch.bfloat16),
+                              bias=b1.to(dev), bias2=b2.to(dev), rowbias=temb.to(dev), qstats=qs)
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    assert cnt["gemm_nt_c3p_kernel"] == 1 and cnt["gemm_nt_kernel"] == 0, cnt
+    assert out.halo_is_zero()
+    _close(out.to_nchw().cpu(), ref, 1e-2, "conv3x3 + 1x1 shortcut")
+    if stats:
+        assert wrote and bool(torch.isfinite(qs).all())
+        # fold the entries the way the consumer does: per (sample, 4-channel quad) sum / sum of squares of the STORED values
+        G = 32
+        part = torch.zeros(lib.query("siss_gn_partial_words", n, h, w, co, G), device=dev)
+        y2, mean, rstd = Act(n, h, w, co, dev), torch.zeros(n, G, device=dev), torch.zeros(n, G, device=dev)
+        gamma, beta = torch.ones(co, device=dev), torch.zeros(co, device=dev)
+        lib.call("siss_groupnorm_fwd_qs", out.data, gamma, beta, y2.data, mean, rstd, part, qs, co, None, n, h, w, co, G, 1e-6, 0, 0, 0)
+        torch.cuda.synchronize()
+        st = out.to_nchw().view(n, G, -1)
+        torch.testing.assert_close(mean.cpu(), st.mean(-1).cpu(), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(rstd.cpu(), (st.var(-1, unbiased=False) + 1e-6).rsqrt().cpu(), rtol=1e-3, atol=1e-5)
+
+
+def test_conv3x3_sc_is_refused_where_the_persistent_kernel_is_not_taken(dev):
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act
+    a, x, out = Act(2, 16, 16, 128, dev), Act(2, 16, 16, 256, dev), Act(2, 16, 16, 128, dev)
+    assert not ops.conv3x3_sc_takes(a, 128, out, x)         # 16 x 16: the split-K kernels' territory
+    with pytest.raises(RuntimeError, match="bad argument"):
+        ops.conv_fprop_sc(a, torch.zeros(9, 128, 128, dtype=torch.bfloat16, device=dev), out, x,
+                          torch.zeros(128, 256, dtype=torch.bfloat16, device=dev))
+
+
 def _wgrad_sets(ops, lib, dya, xa, dW, dB, nsets):
     """conv_wgrad with a bias-gradient buffer per set (set stride = co floats)."""
     from siss_amd.layout import conv3x3_panels

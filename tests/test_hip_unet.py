@@ -513,3 +513,46 @@ def test_subscore_stats_row_selection_and_zero_size_guards(setup, u):
         ref_block = batch_stats(items, {"lambd": 0.5})
     st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
     _check_block(ref_block, st.stats(), f"subscore u={u}")
+
+
+def test_folded_shortcut_equals_the_separate_1x1_product():
+    """A resnet whose input and output widths differ adds conv_shortcut(x) to conv2(h) (diffusers ResnetBlock2D; reached from
+    losses/ddpm_deletion_loss.py:24).  Where the persistent 3x3 kernel takes the conv2 product, the 1x1 shortcut rides in it
+    as extra K-groups (siss_conv3x3_sc) instead of a product of its own + a residual read.  Same math, one bf16 rounding
+    less (the shortcut's output is no longer rounded before the add): prediction within 1e-2 of scale, gradients cosine
+    >= 0.999 per set against the two-launch form on a 128 x 128 network whose up path folds."""
+    from siss_amd import lib
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.unet import UNetEngine
+    kw = dict(sample_size=128, in_channels=3, out_channels=3, block_out_channels=(128, 128, 256),
+              down_block_types=("DownBlock2D", "DownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "UpBlock2D", "UpBlock2D"),
+              layers_per_block=1, attention_head_dim=None, norm_num_groups=32, norm_eps=1e-6,
+              downsample_padding=0, flip_sin_to_cos=False, freq_shift=1)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, 128, 128, generator=g).cuda()
+    t = torch.tensor([999, 400]).cuda()
+    cot = (torch.randn(4, 3, 128, 128, generator=g) * 1e-2).cuda()
+    outs = {}
+    for fold in (True, False):
+        eng = UNetEngine(UNet2DConfig(**kw), "cuda:0")
+        eng.init_random(seed=4)
+        eng.fold_shortcut = fold
+        calls = []
+        orig = lib.call
+        lib.call = lambda name, *a, _o=orig, _c=calls: (_c.append(name), _o(name, *a))[1]
+        try:
+            pred = eng.forward(x, t).clone()
+            eng.zero_grad()
+            eng.backward(cot, nsets=2)
+            torch.cuda.synchronize()
+        finally:
+            lib.call = orig
+        outs[fold] = (pred, eng.ps.grads.clone(), calls)
+    # the two 128 x 128 up resnets (256 -> 128 channels) fold; the 64 x 64 / 32 x 32 ones are below the persistent kernel's grid size
+    assert outs[True][2].count("siss_conv3x3_sc") == 2 and outs[False][2].count("siss_conv3x3_sc") == 0
+    pa, pb = outs[True][0], outs[False][0]
+    assert float((pa - pb).abs().max()) <= 1e-2 * float(pb.abs().max())
+    for s in range(2):
+        ga, gb = outs[True][1][s].double(), outs[False][1][s].double()
+        assert float((ga * gb).sum() / (ga.norm() * gb.norm())) >= 0.999, s
+        assert abs(float(ga.norm() / gb.norm()) - 1) < 1e-2, s
