@@ -303,39 +303,53 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
         for (int k = 0; k < SETS; ++k)
             dbase[k] = dy + (dy_compact ? (long)(k * nx + n) * s.H * s.W : (long)(k * nx + n) * rpi) * s.ld;
         const unsigned xb = s.ldx * 2, db = s.ld * 2, lb = cc * 16;
-        // Software pipeline: the loads of pixel i+1 (x + one dy per set) are issued BEFORE pixel i is consumed, so
-        // the memory pipe never drains while the SiLU' arithmetic runs (4-5 waves per SIMD only).
+        // Software pipeline, TWO pixels deep: the loads of pixels i+1 and i+2 (x + one dy per set each) are in flight while
+        // pixel i is consumed.  A launch is 512 blocks = 8 waves per CU; with one pixel ahead that was ~24 KB in flight per CU,
+        // below what a 6 TB/s read stream needs at this latency (tools/probes/hbm_bw.hip: 6.1-6.4 TB/s for three read streams
+        // with two loads in flight per lane, 4.0 TB/s measured for this kernel before).
         PixelWalk w(s, chunk, slot);
-        u32x4_t nx_x = u32x4_t{0u, 0u, 0u, 0u}, nx_d[SETS];
+        u32x4_t bx[2], bd[2][SETS];
+        bool have[2];
         auto issue = [&](const PixelWalk& q, u32x4_t& ox, u32x4_t (&od)[SETS]) {
             ox = ld16(xbase, boff(q.row(), xb, lb));
             const unsigned doff = boff(dy_compact ? q.pi : q.row(), db, lb);
 #pragma unroll
             for (int k = 0; k < SETS; ++k) od[k] = ld16(dbase[k], doff);
         };
-        if (w.ok()) issue(w, nx_x, nx_d);
-        while (w.ok()) {
-            const u32x4_t rx = nx_x;
-            u32x4_t rd[SETS];
 #pragma unroll
-            for (int k = 0; k < SETS; ++k) rd[k] = nx_d[k];
-            w.next();
-            if (w.ok()) issue(w, nx_x, nx_d);
-            float v[8], xh[8], dsl[8];
-            unpack8(rx, v);
+        for (int b2 = 0; b2 < 2; ++b2) {
+            bx[b2] = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xh[e] = v[e] * rs[e] - mr[e];
-                dsl[e] = SILU ? dsilu_f(xh[e] * ga[e] + be[e]) : 1.f;
-            }
+            for (int k = 0; k < SETS; ++k) bd[b2][k] = u32x4_t{0u, 0u, 0u, 0u};
+            have[b2] = w.ok();
+            if (have[b2]) { issue(w, bx[b2], bd[b2]); w.next(); }
+        }
+        while (have[0]) {
 #pragma unroll
-            for (int k = 0; k < SETS; ++k) {
-                float d[8];
-                unpack8(rd[k], d);
+            for (int b2 = 0; b2 < 2; ++b2) {
+                if (!have[b2]) break;
+                const u32x4_t rx = bx[b2];
+                u32x4_t rd[SETS];
+#pragma unroll
+                for (int k = 0; k < SETS; ++k) rd[k] = bd[b2][k];
+                have[b2] = w.ok();
+                if (have[b2]) { issue(w, bx[b2], bd[b2]); w.next(); }
+                float v[8], xh[8], dsl[8];
+                unpack8(rx, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float dz = d[e] * dsl[e];
-                    a1[k][e] += dz; a2[k][e] += dz * xh[e];
+                    xh[e] = v[e] * rs[e] - mr[e];
+                    dsl[e] = SILU ? dsilu_f(xh[e] * ga[e] + be[e]) : 1.f;
+                }
+#pragma unroll
+                for (int k = 0; k < SETS; ++k) {
+                    float d[8];
+                    unpack8(rd[k], d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float dz = d[e] * dsl[e];
+                        a1[k][e] += dz; a2[k][e] += dz * xh[e];
+                    }
                 }
             }
         }
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
     const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ partial, GNShape s, int nx, int dy_compact, const bf16_t* __restrict__ accum,
     const bf16_t* __restrict__ accum2, bf16_t* __restrict__ dx, bf16_t* __restrict__ dx2, int split_c,
-    int accumulate2, float* __restrict__ colsum, long colsum_ld) {
+    int accumulate2, float* __restrict__ colsum, long colsum_ld, int pchunks) {
     __shared__ float sh_s1[SETS][kMaxG], sh_s2[SETS][kMaxG];
     __shared__ __attribute__((aligned(16))) float red[2048];
     __shared__ float chs[kMaxC];
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
         const double cnt = (double)s.H * s.W * s.cpg;
         for (int k = 0; k < SETS; ++k) {
             const int n2 = k * nx + n;
-            fold_slab(partial + ((long)n2 * s.nslices + blockIdx.z) * s.nchunks * 2 * s.G, s.nchunks, s.G, fr);
+            fold_slab(partial + ((long)n2 * s.nslices + blockIdx.z) * pchunks * 2 * s.G, pchunks, s.G, fr);   // pchunks: the STATISTICS launch's blocks per sample
             if (tid < s.G) {
                 sh_s1[k][tid] = (float)(((double)fr[0][2 * tid] + fr[1][2 * tid] + fr[2][2 * tid] + fr[3][2 * tid]) / cnt);
                 sh_s2[k][tid] = (float)(((double)fr[0][2 * tid + 1] + fr[1][2 * tid + 1] + fr[2][2 * tid + 1] + fr[3][2 * tid + 1]) / cnt);
@@ -498,7 +512,13 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_apply_kernel(
     }
 }
 
-bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16) {
+// Target block count of a launch.  Forward kernels (34-60 VGPRs, many blocks resident per CU): ~3 per CU.  Backward kernels
+// (118-190 VGPRs: two 256-thread blocks resident per CU): 512 = exactly one resident round -- 768 was a round and a half, and the
+// half-empty second round cost 3-12 % of every site (profiles/r03_gn_block_count_sweep.txt: 256^2 x 128 548 -> 520 us,
+// 128^2 x 128 150 -> 135 us, 64^2 x 512 164 -> 144 us; round-robin pixel groups instead of contiguous runs: 0-4 % slower).
+constexpr int kBlocksFwd = 768, kBlocksBwd = 512, kBlocksBwdStats = 767;
+
+bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16, int blocks = kBlocksFwd) {
     if (H <= 0 || W <= 0 || C <= 0 || G <= 0 || G > kMaxG || C % G || C % 8) return false;
     s.H = H; s.W = W; s.ld = C; s.ldx = C; s.Gf = G; s.cpg = C / G;
     int gs = G;                                         // groups per slice
@@ -525,9 +545,14 @@ bool make_shape(int H, int W, int C, int G, GNShape& s, int N = 16) {
     const int px = H * W;
     // ~3 blocks per CU, and >= 16 pixel iterations per thread so that the per-block prologue (slab fold)
     // and epilogue (LDS + global atomics) are amortised
-    int nch = (768 + N * s.nslices - 1) / (N * s.nslices);
+    int nch = (blocks + N * s.nslices - 1) / (N * s.nslices);
     const int max_by_work = (px + 16 * s.ppi - 1) / (16 * s.ppi);
     if (nch > max_by_work) nch = max_by_work;
+    if (blocks == kBlocksBwd || blocks == kBlocksBwdStats) {
+        // backward: 32 iterations per thread where that still leaves a block per CU (64^2 x 256: 80 -> 68 us with 256 blocks)
+        const int by_work32 = (px + 32 * s.ppi - 1) / (32 * s.ppi);
+        if (nch > by_work32 && (long)by_work32 * N * s.nslices >= 256) nch = by_work32;
+    }
     if (nch > 256) nch = 256;
     if (nch < 1) nch = 1;
     s.chunk_px = (px + nch - 1) / nch;
@@ -577,7 +602,7 @@ int siss_groupnorm_fwd_qs(const void* x, const float* gamma, const float* beta, 
     SISS_CHECK_ARG(!qsA || (ca > 0 && ca <= C && ca % 4 == 0 && (ca == C) == (qsB == nullptr)));
     SISS_CHECK_ARG(((uintptr_t)qsA | (uintptr_t)qsB) % 8 == 0);
     SISS_CHECK_ARG(x && gamma && beta && y && mean && rstd && partial && N > 0);
-    SISS_CHECK_ARG(make_shape(H, W, C, G, s, N));
+    SISS_CHECK_ARG(make_shape(H, W, C, G, s, N, kBlocksFwd));
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
     if (ldx) s.ldx = ldx;
     SISS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y | (uintptr_t)partial) % 16 == 0);
@@ -631,7 +656,7 @@ int siss_groupnorm_bwd_ld(const void* dy, const void* x, const float* gamma, con
     SISS_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && partial);
     SISS_CHECK_ARG(n2 > 0 && nx > 0 && set_images > 0 && n2 % set_images == 0);
     SISS_CHECK_ARG(n2 == nx || n2 == 2 * nx);     // cotangent sets per saved sample: 1 or 2
-    SISS_CHECK_ARG(make_shape(H, W, C, G, s, nx));
+    SISS_CHECK_ARG(make_shape(H, W, C, G, s, nx, kBlocksBwd));
     SISS_CHECK_ARG(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)accum | (uintptr_t)accum2 | (uintptr_t)dx2) % 16 == 0);
     SISS_CHECK_ARG(!dx2 || (split_c > 0 && split_c < C && split_c % 8 == 0));
     SISS_CHECK_ARG(ldx == 0 || (ldx >= C && ldx % 8 == 0));
@@ -643,14 +668,18 @@ int siss_groupnorm_bwd_ld(const void* dy, const void* x, const float* gamma, con
         if (rc >= 0) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(s.nchunks, nx, s.nslices);
+    // the statistics kernel (142 VGPRs: three blocks resident per CU) and the apply kernel (190: two) each get ONE resident round
+    GNShape ss;
+    SISS_CHECK_ARG(make_shape(H, W, C, G, ss, nx, kBlocksBwdStats));
+    ss.ldx = s.ldx;
+    dim3 grid(s.nchunks, nx, s.nslices), grid_s(ss.nchunks, nx, ss.nslices);
     const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* xp = (const bf16_t*)x;
 #define GN_BWD(SILU, SETS)                                                                                          \
-    gn_bwd_stats_kernel<SILU, SETS><<<grid, kThreads, 0, st>>>(dyp, xp, gamma, beta, mean, rstd, s, nx, dy_compact, \
+    gn_bwd_stats_kernel<SILU, SETS><<<grid_s, kThreads, 0, st>>>(dyp, xp, gamma, beta, mean, rstd, ss, nx, dy_compact, \
                                                                set_images, set_stride, partial, dgamma, dbeta);    \
     gn_bwd_apply_kernel<SILU, SETS><<<grid, kThreads, 0, st>>>(dyp, xp, gamma, beta, mean, rstd, partial, s, nx,    \
                                                                dy_compact, (const bf16_t*)accum, (const bf16_t*)accum2, (bf16_t*)dx, (bf16_t*)dx2, split_c,  \
-                                                               accumulate2, colsum, colsum_ld)
+                                                               accumulate2, colsum, colsum_ld, ss.nchunks)
     if (n2 == nx) { if (silu) { GN_BWD(true, 1); } else { GN_BWD(false, 1); } }
     else          { if (silu) { GN_BWD(true, 2); } else { GN_BWD(false, 2); } }
 #undef GN_BWD

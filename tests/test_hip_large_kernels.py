@@ -125,7 +125,7 @@ SC_CASES = [
     (2, 128, 128, 128, 128, 256, 0, False),      # up-block shape: 256-channel concat -> 128; one tile crosses the image seam
     (1, 256, 256, 128, 128, 256, 0, True),       # two tile rounds; GroupNorm statistics of the sum from the store path
     (4, 64, 64, 256, 256, 128, 0, False),        # down-block shape 128 -> 256: two column tiles, K2 < Kp
-    (3, 96, 96, 128, 128, 192, 320, True),       # K2 = 192 (three shortcut groups), the input is a column view of a wider buffer
+    (4, 96, 96, 128, 128, 192, 320, True),       # K2 = 192 (three shortcut groups), the input is a column view of a wider buffer
     (8, 64, 64, 64, 128, 64, 0, False),          # ONE k-chunk per filter row and ONE shortcut group: four groups per tile
 ]
 
