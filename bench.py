@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("SISS_GRAPH", "1")),
                     help="replay the step from a captured hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--engine-attr", action="append", default=[], help="name=int: set a schedule switch of the engine (A/B runs)")
+    ap.add_argument("--lib-set", action="append", default=[], help="name=int: call a process-wide setter of the library (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -184,6 +185,9 @@ def main():
                            up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D"))
     B, hw, cin = a.batch, cfg.sample_size, cfg.in_channels
     eng = UNetCondEngine(cfg, dev) if sd else UNetEngine(cfg, dev)
+    for kv in filter(None, a.lib_set):
+        k, v = kv.split("=")
+        lib.query(k, int(v))
     for kv in filter(None, a.engine_attr):                   # A/B of a schedule switch on one box, e.g. --engine-attr fold_shortcut=0
         k, v = kv.split("=")
         assert hasattr(eng, k), k

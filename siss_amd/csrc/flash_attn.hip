@@ -148,23 +148,28 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
             for (int ks = 0; ks < F::KS; ++ks)
                 st[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm<DP>(ks_, sub, ks, lane), qf[ks], st[sub], 0, 0, 0);
         }
-        float mx = -INFINITY;
+        // The running maximum is kept on the RAW scores (scale > 0: the maximum commutes with the scaling), so that an element
+        // costs one fma + one exp2 (p = exp2(s * c - m * c)) instead of a multiply, a subtract and the exp2; the key mask (two more
+        // instructions per element) only exists in tiles that contain padded keys (cross attention's last tile) -- a wave-uniform
+        // branch.  These loops are VALU-bound at head dims <= 64 (2.4 vector issue slots per MFMA slot before this diet).
+        if (k0 + kTQ > valid_k) {
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
+            for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + sub * 16 + (lane >> 4) * 4 + r;
-                const float s = key < valid_k ? st[sub][r] * scale_log2 : -INFINITY;
-                st[sub][r] = s;
-                mx = fmaxf(mx, s);
-            }
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + sub * 16 + (lane >> 4) * 4 + r >= valid_k) st[sub][r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+        for (int sub = 1; sub < 4; ++sub) mx = fmaxf(mx, fmaxf(fmaxf(st[sub][0], st[sub][1]), fmaxf(st[sub][2], st[sub][3])));
         const float m_new = fmaxf(m, group_max(mx));            // finite: every 64-key tile up to valid_k has a valid key... see launcher
-        const float alpha = fast_exp2(m - m_new);                   // m = -inf on the first tile: alpha = 0
+        const float alpha = fast_exp2((m - m_new) * scale_log2);    // m = -inf on the first tile: alpha = 0
+        const float mc = m_new * scale_log2;
         float ps = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float p = fast_exp2(st[sub][r] - m_new); st[sub][r] = p; ps += p; }
+            for (int r = 0; r < 4; ++r) { const float p = fast_exp2(fmaf(st[sub][r], scale_log2, -mc)); st[sub][r] = p; ps += p; }
         l = l * alpha + group_sum(ps);
         m = m_new;
 #pragma unroll
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt)
         *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(ot[dt][0] * inv, ot[dt][1] * inv), pack_bf2(ot[dt][2] * inv, ot[dt][3] * inv)};
-    if ((lane >> 4) == 0) LSE2[bh * Sqp + q0 + lane] = m + log2f(l);
+    if ((lane >> 4) == 0) LSE2[bh * Sqp + q0 + lane] = m * scale_log2 + log2f(l);
 }
 
 // ====================================================================================================================
@@ -239,14 +244,18 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
                 dp[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm<DP>(vs_, sub, ks, lane), dof[ks], dp[sub], 0, 0, 0);
             }
         }
+        // dS without its factor `scale` (applied once to the finished dQ tile); the key mask only in tiles with padded keys
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + sub * 16 + (lane >> 4) * 4 + r;
-                const float p = key < valid_k ? fast_exp2(st[sub][r] * scale_log2 - lse) : 0.f;
-                st[sub][r] = p * (dp[sub][r] - dl) * scale;
-            }
+            for (int r = 0; r < 4; ++r) st[sub][r] = fast_exp2(fmaf(st[sub][r], scale_log2, -lse)) * (dp[sub][r] - dl);
+        if (k0 + kTQ > valid_k) {
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + sub * 16 + (lane >> 4) * 4 + r >= valid_k) st[sub][r] = 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bf16x8_t dsf = pack_pair(st[2 * j], st[2 * j + 1]);
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
     bf16_t* og = dQ + (z * Sqp + qrow) * DP + (lane >> 4) * 4;
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt)
-        *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(dqt[dt][0], dqt[dt][1]), pack_bf2(dqt[dt][2], dqt[dt][3])};
+        *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(dqt[dt][0] * scale, dqt[dt][1] * scale), pack_bf2(dqt[dt][2] * scale, dqt[dt][3] * scale)};
 }
 
 // ====================================================================================================================
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     const long z = blockIdx.y, zf = z % BH;
     const int k0 = blockIdx.x * kTQ + w * 16;
     const long krow = k0 + (lane & 15);
-    const bool key_ok = krow < valid_k;
+    const float key_lse_off = krow < valid_k ? 0.f : -INFINITY;     // a lane keeps ONE key: its mask is one additive constant
     bf16x8_t kf[F::KS], vf[F::KS];
 #pragma unroll
     for (int ks = 0; ks < F::KS; ++ks) {
@@ -323,9 +332,9 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
             const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(dlg + qb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = key_ok ? fast_exp2(s[sub][r] * scale_log2 - lse[r]) : 0.f;
+                const float p = fast_exp2(fmaf(s[sub][r], scale_log2, key_lse_off - lse[r]));     // padded key: exp2(-inf) = 0
                 s[sub][r] = p;
-                ds[sub][r] = p * (dp[sub][r] - dl[r]) * scale;
+                ds[sub][r] = p * (dp[sub][r] - dl[r]);                                              // (scale: once, on the finished dK tile)
             }
         }
 #pragma unroll
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     bf16_t* ovg = dV + (z * Skp + krow) * DP + (lane >> 4) * 4;
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt) {
-        *reinterpret_cast<u32x2_t*>(okg + dt * 16) = u32x2_t{pack_bf2(dkt[dt][0], dkt[dt][1]), pack_bf2(dkt[dt][2], dkt[dt][3])};
+        *reinterpret_cast<u32x2_t*>(okg + dt * 16) = u32x2_t{pack_bf2(dkt[dt][0] * scale, dkt[dt][1] * scale), pack_bf2(dkt[dt][2] * scale, dkt[dt][3] * scale)};
         *reinterpret_cast<u32x2_t*>(ovg + dt * 16) = u32x2_t{pack_bf2(dvt[dt][0], dvt[dt][1]), pack_bf2(dvt[dt][2], dvt[dt][3])};
     }
 }

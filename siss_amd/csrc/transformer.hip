@@ -90,40 +90,64 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* _
             const int c = lane + i * 64;
             ga[i][e] = c < nch ? gamma[c * 8 + e] : 0.f;
         }
-    for (long r = r0 + w; r < r1; r += kThreads / 64) {
-        const long rx = r % rows_x;
-        const float mu = mean[rx], rs = rstd[rx];
-        float d[NCH][8], xh[NCH][8];
-        float s1 = 0.f, s2 = 0.f;
+    // TWO rows per wave and trip: both rows' loads (dy, x, accum) are issued before either row's reductions -- the loop is a chain
+    // load -> two wave reductions -> store per row, and with one row in flight per wave it ran at a quarter of the HBM rate
+    constexpr int NW = kThreads / 64;
+    for (long rr = r0 + w; rr < r1; rr += 2 * NW) {
+        const bool two = rr + NW < r1;
+        const long rrow[2] = {rr, two ? rr + NW : rr};
+        u32x4_t vd[2][NCH], vx[2][NCH], va[2][NCH];
+        float mu[2], rs[2];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane + i * 64;
-            if (c < nch) {
-                float xv[8];
-                unpack8f(*reinterpret_cast<const u32x4_t*>(dy + r * C + c * 8), d[i]);
-                unpack8f(*reinterpret_cast<const u32x4_t*>(x + rx * C + c * 8), xv);
+        for (int q = 0; q < 2; ++q) {
+            const long r = rrow[q], rx = r % rows_x;
+            mu[q] = mean[rx]; rs[q] = rstd[rx];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    xh[i][e] = (xv[e] - mu) * rs;
-                    dg[i][e] += d[i][e] * xh[i][e];
-                    db[i][e] += d[i][e];
-                    d[i][e] *= ga[i][e];
-                    s1 += d[i][e];
-                    s2 += d[i][e] * xh[i][e];
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + i * 64;
+                if (c < nch) {
+                    vd[q][i] = *reinterpret_cast<const u32x4_t*>(dy + r * C + c * 8);
+                    vx[q][i] = *reinterpret_cast<const u32x4_t*>(x + rx * C + c * 8);
+                    if (accum) va[q][i] = *reinterpret_cast<const u32x4_t*>(accum + r * C + c * 8);
                 }
             }
         }
-        s1 = wave_sum(s1) / (float)C;
-        s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane + i * 64;
-            if (c < nch) {
-                float o[8], a[8];
-                if (accum) unpack8f(*reinterpret_cast<const u32x4_t*>(accum + r * C + c * 8), a);
+        for (int q = 0; q < 2; ++q) {
+            if (q == 1 && !two) break;
+            const long r = rrow[q];
+            float d[NCH][8], xh[NCH][8];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rs * (d[i][e] - s1 - xh[i][e] * s2) + (accum ? a[e] : 0.f);
-                *reinterpret_cast<u32x4_t*>(dx + r * C + c * 8) = pack8f(o);
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + i * 64;
+                if (c < nch) {
+                    float xv[8];
+                    unpack8f(vd[q][i], d[i]);
+                    unpack8f(vx[q][i], xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        xh[i][e] = (xv[e] - mu[q]) * rs[q];
+                        dg[i][e] += d[i][e] * xh[i][e];
+                        db[i][e] += d[i][e];
+                        d[i][e] *= ga[i][e];
+                        s1 += d[i][e];
+                        s2 += d[i][e] * xh[i][e];
+                    }
+                }
+            }
+            s1 = wave_sum(s1) / (float)C;
+            s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = lane + i * 64;
+                if (c < nch) {
+                    float o[8], av[8];
+                    if (accum) unpack8f(va[q][i], av);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = rs[q] * (d[i][e] - s1 - xh[i][e] * s2) + (accum ? av[e] : 0.f);
+                    *reinterpret_cast<u32x4_t*>(dx + r * C + c * 8) = pack8f(o);
+                }
             }
         }
     }
@@ -162,22 +186,27 @@ __global__ __launch_bounds__(kThreads) void quick_gelu_kernel(const bf16_t* __re
     *reinterpret_cast<u32x4_t*>(y + idx * 8) = pack8f(v);
 }
 
-// out[r] = sum_d a[r][d] * b[r % rows_b][d]   (delta = rowsum(dO o O) of the attention backward); one thread per row
+// out[r] = sum_d a[r][d] * b[r % rows_b][d]   (delta = rowsum(dO o O) of the attention backward).  EIGHT lanes per row, 16 B each:
+// a wave reads 8 whole 128-B rows per instruction (one thread per row had every lane on a line of its own: 2 TB/s).
 __global__ __launch_bounds__(kThreads) void rowdot_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                           float* __restrict__ out, long rows, long rows_b, int D) {
-    const long r = (long)blockIdx.x * kThreads + threadIdx.x;
-    if (r >= rows) return;
-    const bf16_t* pa = a + r * D;
-    const bf16_t* pb = b + (r % rows_b) * D;
+    const long t = (long)blockIdx.x * kThreads + threadIdx.x;
+    const long r = t >> 3;
+    const int sub = (int)(t & 7);
     float s = 0.f;
-    for (int c = 0; c < D; c += 8) {
-        float x[8], y[8];
-        unpack8f(*reinterpret_cast<const u32x4_t*>(pa + c), x);
-        unpack8f(*reinterpret_cast<const u32x4_t*>(pb + c), y);
+    if (r < rows) {
+        const bf16_t* pa = a + r * D;
+        const bf16_t* pb = b + (r % rows_b) * D;
+        for (int c = sub * 8; c < D; c += 64) {
+            float x[8], y[8];
+            unpack8f(*reinterpret_cast<const u32x4_t*>(pa + c), x);
+            unpack8f(*reinterpret_cast<const u32x4_t*>(pb + c), y);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += x[e] * y[e];
+            for (int e = 0; e < 8; ++e) s += x[e] * y[e];
+        }
     }
-    out[r] = s;
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (r < rows && sub == 0) out[r] = s;
 }
 
 // out[r][f] = h[r][f] * gelu(h[r][F + f])
@@ -391,7 +420,7 @@ int siss_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
     SISS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows2 > 0 && rows_x > 0 && set_rows > 0);
     SISS_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 64 * 8 * kMaxChunks && rows2 % set_rows == 0 && (!dgamma || dbeta));
     // rows per block: a divisor of set_rows near 16 (blocks must not straddle sets)
-    int rpb = 16;        // 4 rows per wave: 4x the blocks of the 64-row form (it left 2 waves per SIMD walking 16 rows each)
+    int rpb = 32;        // 8 rows per wave, two in flight; fewer blocks also means fewer same-address dgamma / dbeta atomics
     while (rpb > 1 && set_rows % rpb) --rpb;
     LN_DISPATCH(layernorm_bwd_kernel, cdiv(rows2, rpb), (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
                 (const bf16_t*)accum, (bf16_t*)dx, dgamma, dbeta, rows2, rows_x, set_rows, set_stride, C, rpb);
@@ -414,7 +443,7 @@ int siss_geglu_bwd(const void* dout, const void* h, void* dh, long rows2, long r
 // out[r] = <a[r], b[r % rows_b]> over D contiguous bf16 (D % 8 == 0), f32 result
 int siss_rowdot(const void* a, const void* b, float* out, long rows, long rows_b, int D, void* stream) {
     SISS_CHECK_ARG(a && b && out && rows > 0 && rows_b > 0 && D > 0 && D % 8 == 0);
-    rowdot_kernel<<<cdiv(rows, kThreads), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, out, rows, rows_b, D);
+    rowdot_kernel<<<cdiv(rows * 8, kThreads), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, out, rows, rows_b, D);
     SISS_LAUNCH_RET();
 }
 
