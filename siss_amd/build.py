@@ -17,6 +17,9 @@ LIB = os.path.join(HERE, "libsiss_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # bit-exact-vs-torch kernels (q_sample, AdamW) must not contract a*b+c into fma
 EXACT = {"siss_loss.hip", "optimizer.hip"}
+# per-file extras.  flash_attn.hip: MFMA results straight into VGPRs -- the softmax arithmetic consumes every accumulator of every
+# tile, and with the default (AGPR destinations) each one cost a v_accvgpr_read in loops that are VALU-bound (832 -> 10 in the file)
+EXTRA = {"flash_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():
@@ -32,7 +35,7 @@ def _stale(dst, srcs):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.abspath(__file__)]   # (flags live here)
     jobs = []
     objs = []
     for f in sources():
@@ -40,7 +43,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, f[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append(["hipcc", *FLAGS, *(["-ffp-contract=off"] if f in EXACT else []), "-c", src, "-o", obj])
+            jobs.append(["hipcc", *FLAGS, *(["-ffp-contract=off"] if f in EXACT else []), *EXTRA.get(f, []), "-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

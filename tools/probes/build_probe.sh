@@ -12,7 +12,7 @@ cd "$(dirname "$0")/../.."
 out=tools/probes/_probe_build; mkdir -p $out
 for f in siss_amd/csrc/*.hip; do
   b=$(basename $f .hip); extra=""
-  case $b in siss_loss|optimizer) extra="-ffp-contract=off";; esac
+  case $b in siss_loss|optimizer) extra="-ffp-contract=off";; flash_attn) extra="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSISS_PROBE $extra -c $f -o $out/$b.o &
   if (( $(jobs -r | wc -l) >= 4 )); then wait -n; fi
 done
