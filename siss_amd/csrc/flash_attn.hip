@@ -3,8 +3,12 @@
 // with LDS-staged tiles.  The S x S score / probability matrices never touch HBM (at 64 x 64 latents they are 1 GB per site
 // and pass in the GEMM + softmax form this replaces: 22 of the 77 ms of the SD-v1.5 step).
 //
-// Operands are the head-split tensors the transformer path already keeps: [B*heads][S_pad][D_pad] bf16, zero padded
-// (S_pad % 64 == 0, D_pad in {64, 128, 192}).  `valid_k` masks the padded keys (cross-attention: 77 of 128).
+// Operands are addressed as (base, row stride): the kernels read q / k / v / dO and write o / dq / dk / dv IN PLACE in the layout
+// the projections use -- "merged" [B][S][heads * D] rows with the head at column h * D (siss_flash_attn_*_merged) -- or in the
+// head-split, zero-padded [B*heads][S_pad][D_pad] form (siss_flash_attn_fwd / _bwd).  Rows past the tensor's end and head-dim
+// chunks past D read as zero and are not stored, so the merged form needs no head-split / head-merge copies and no padded
+// tensors (round 3: 256 launches and ~4 ms per SD step at B = 16 gone).  `valid_k` masks the padded keys (cross-attention: 77).
+// delta = rowsum(dO o O) is formed by the dQ kernel from the tiles it loads anyway (it runs first; the dK / dV kernel reads it).
 //
 // Everything is computed TRANSPOSED, so that no register shuffle is ever needed between the two products of a tile:
 //   v_mfma_f32_16x16x32_bf16(X, Y): out[x = (lane >> 4) * 4 + r][y = lane & 15], both operands "row, 8 consecutive k per lane".
@@ -49,14 +53,16 @@ template <int DP> struct FA {
 // A [64][DP] tile (global row stride DP; the tensors are padded, all 64 rows exist) travels global -> registers -> LDS in two
 // halves, so that the loads of tile t+1 are in flight while tile t is being multiplied (one LDS buffer, register prefetch).
 template <int DP> struct TileRegs { u32x4_t v[FA<DP>::CH * kTQ / kThreadsFA]; };
+// g: first row of the tile (already at the block's batch / head), ld: row stride in elements, rows: rows of the tile that exist
+// (<= 64), dch: 16-B chunks of a row that exist (D / 8); everything else reads as zero
 template <int DP>
-__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ g, TileRegs<DP>& r, int tid) {
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ g, long ld, int rows, int dch, TileRegs<DP>& r, int tid) {
     using F = FA<DP>;
 #pragma unroll
     for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i) {
         const int idx = i * kThreadsFA + tid;
         const int row = idx / F::CH, c = idx - row * F::CH;
-        r.v[i] = *reinterpret_cast<const u32x4_t*>(g + (long)row * DP + c * 8);
+        r.v[i] = (row < rows && c < dch) ? *reinterpret_cast<const u32x4_t*>(g + (long)row * ld + c * 8) : u32x4_t{0u, 0u, 0u, 0u};
     }
 }
 template <int DP>
@@ -102,43 +108,63 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// Operand addressing shared by the three kernels: tensor element (batch b, head h, row s, column d) lives at
+// base + (b * S_rows + s) * ld + h * hoff + d;  merged layout: hoff = D, ld = the projection's row length;  head-split padded
+// layout: the launcher passes H = 1, b = the (batch, head) index, ld = D_pad, hoff = 0.
+struct FAShape {
+    int H;                 // heads per batch entry (blockIdx.y = b * H + h)
+    int hoff;              // column offset between heads
+    int D;                 // valid head dim (a multiple of 8; chunks past it read as zero and are not stored)
+    int Sq, Sk;            // rows that exist per batch entry (queries, keys)
+    int Sqp, Skp;          // the same rounded up to 64 (loop bounds; LSE / delta rows per (batch, head))
+    int valid_k;           // keys >= valid_k are masked
+};
+__device__ __forceinline__ bf16x8_t load_frag_or_zero(const bf16_t* p, bool ok) {
+    return ok ? *reinterpret_cast<const bf16x8_t*>(p) : __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
+}
+
 // ====================================================================================================================
 // forward: O = softmax(scale Q K^T) V, LSE2[q] = log2 sum_k exp2(scale log2e (q.k))   (base-2 log-sum-exp)
 // grid (Sq_pad / 64, B*heads)
 // ====================================================================================================================
 template <int DP>
-__global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                               const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-                                                               float* __restrict__ LSE2, int Sqp, int Skp, int valid_k,
-                                                               float scale_log2) {
+__global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
+                                                               long ldk, const bf16_t* __restrict__ V, long ldv,
+                                                               bf16_t* __restrict__ O, long ldo, float* __restrict__ LSE2,
+                                                               FAShape sh, float scale_log2) {
     using F = FA<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks_ = smem;                       // K tile
     char* vs_ = smem + F::TILE;             // V tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const long bh = blockIdx.y;
+    const long b = bh / sh.H;
+    const int h = (int)(bh - b * sh.H);
+    const int dch = sh.D >> 3, valid_k = sh.valid_k, Skp = sh.Skp;
     const int q0 = blockIdx.x * kTQ + w * 16;
-    const bf16_t* qg = Q + (bh * Sqp + q0 + (lane & 15)) * DP + (lane >> 4) * 8;
+    const int qrow = q0 + (lane & 15);
+    const bool q_ok = qrow < sh.Sq;
+    const bf16_t* qg = Q + (b * sh.Sq + qrow) * ldq + h * sh.hoff + (lane >> 4) * 8;
     bf16x8_t qf[F::KS];
 #pragma unroll
-    for (int ks = 0; ks < F::KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qg + ks * 32);
+    for (int ks = 0; ks < F::KS; ++ks) qf[ks] = load_frag_or_zero(qg + ks * 32, q_ok && ks * 4 + (lane >> 4) < dch);
     f32x4_t ot[F::DT];
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
-    const bf16_t* kg = K + bh * Skp * DP;
-    const bf16_t* vg = V + bh * Skp * DP;
+    const bf16_t* kg = K + b * sh.Sk * ldk + h * sh.hoff;
+    const bf16_t* vg = V + b * sh.Sk * ldv + h * sh.hoff;
     TileRegs<DP> kr, vr;
-    tile_load<DP>(kg, kr, tid);
-    tile_load<DP>(vg, vr, tid);
+    tile_load<DP>(kg, ldk, sh.Sk, dch, kr, tid);
+    tile_load<DP>(vg, ldv, sh.Sk, dch, vr, tid);
     for (int k0 = 0; k0 < Skp; k0 += kTQ) {
         __syncthreads();                                        // the previous tile's readers are done
         tile_store<DP>(kr, ks_, tid);
         tile_store<DP>(vr, vs_, tid);
         __syncthreads();
         if (k0 + kTQ < Skp) {                                   // next tile: in flight under this tile's products
-            tile_load<DP>(kg + (long)(k0 + kTQ) * DP, kr, tid);
-            tile_load<DP>(vg + (long)(k0 + kTQ) * DP, vr, tid);
+            tile_load<DP>(kg + (long)(k0 + kTQ) * ldk, ldk, sh.Sk - k0 - kTQ, dch, kr, tid);
+            tile_load<DP>(vg + (long)(k0 + kTQ) * ldv, ldv, sh.Sk - k0 - kTQ, dch, vr, tid);
         }
         f32x4_t st[4];
 #pragma unroll
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
         float mx = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
 #pragma unroll
         for (int sub = 1; sub < 4; ++sub) mx = fmaxf(mx, fmaxf(fmaxf(st[sub][0], st[sub][1]), fmaxf(st[sub][2], st[sub][3])));
-        const float m_new = fmaxf(m, group_max(mx));            // finite: every 64-key tile up to valid_k has a valid key... see launcher
+        const float m_new = fmaxf(m, group_max(mx));            // finite: the first tile always holds a valid key (valid_k >= 1)
         const float alpha = fast_exp2((m - m_new) * scale_log2);    // m = -inf on the first tile: alpha = 0
         const float mc = m_new * scale_log2;
         float ps = 0.f;
@@ -185,54 +211,81 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
         }
     }
     const float inv = 1.f / l;
-    bf16_t* og = O + (bh * Sqp + q0 + (lane & 15)) * DP + (lane >> 4) * 4;
+    bf16_t* og = O + (b * sh.Sq + qrow) * ldo + h * sh.hoff + (lane >> 4) * 4;
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt)
-        *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(ot[dt][0] * inv, ot[dt][1] * inv), pack_bf2(ot[dt][2] * inv, ot[dt][3] * inv)};
-    if ((lane >> 4) == 0) LSE2[bh * Sqp + q0 + lane] = m * scale_log2 + log2f(l);
+        if (q_ok && dt * 16 + (lane >> 4) * 4 < sh.D)
+            *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(ot[dt][0] * inv, ot[dt][1] * inv), pack_bf2(ot[dt][2] * inv, ot[dt][3] * inv)};
+    if ((lane >> 4) == 0) LSE2[bh * sh.Sqp + q0 + lane] = m * scale_log2 + log2f(l);
 }
 
 // ====================================================================================================================
 // backward, dQ:  dQ = scale * dS K,  dS = P o (dO V^T - delta)        grid (Sq_pad / 64, nB*heads)
-// z = cotangent batch-head index; the forward tensors (Q, K, V, LSE2) are indexed z % BH (dual-cotangent backward).
+// z = cotangent (batch, head) index; the forward tensors (Q, K, V, O, LSE2) are indexed by (batch % Bf, head) (dual-cotangent
+// backward).  Og != null: delta[q] = <dO[q], O[q]> is formed here, from fragments laid out like Q's, and WRITTEN to `delta`
+// for the dK / dV kernel that follows; Og == null: `delta` is an input.
 // ====================================================================================================================
 template <int DP>
-__global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                  const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
-                                                                  const float* __restrict__ LSE2, const float* __restrict__ delta,
-                                                                  bf16_t* __restrict__ dQ, int BH, int Sqp, int Skp,
-                                                                  int valid_k, float scale, float scale_log2) {
+__global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
+                                                                  long ldk, const bf16_t* __restrict__ V, long ldv,
+                                                                  const bf16_t* __restrict__ Og, long ldo,
+                                                                  const bf16_t* __restrict__ dO, long lddo,
+                                                                  const float* __restrict__ LSE2, float* __restrict__ delta,
+                                                                  bf16_t* __restrict__ dQ, long lddq, int Bf, FAShape sh,
+                                                                  float scale, float scale_log2) {
     using F = FA<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks_ = smem;
     char* vs_ = smem + F::TILE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long z = blockIdx.y, zf = z % BH;
+    const long z = blockIdx.y;
+    const long bz = z / sh.H;
+    const int h = (int)(z - bz * sh.H);
+    const long bf = bz % Bf, zf = bf * sh.H + h;
+    const int dch = sh.D >> 3, valid_k = sh.valid_k, Skp = sh.Skp;
     const int q0 = blockIdx.x * kTQ + w * 16;
-    const long qrow = q0 + (lane & 15);
+    const int qrow = q0 + (lane & 15);
+    const bool q_ok = qrow < sh.Sq;
+    const long col = h * sh.hoff + (lane >> 4) * 8;
     bf16x8_t qf[F::KS], dof[F::KS];
+    float dl = 0.f;
 #pragma unroll
     for (int ks = 0; ks < F::KS; ++ks) {
-        qf[ks] = *reinterpret_cast<const bf16x8_t*>(Q + (zf * Sqp + qrow) * DP + (lane >> 4) * 8 + ks * 32);
-        dof[ks] = *reinterpret_cast<const bf16x8_t*>(dO + (z * Sqp + qrow) * DP + (lane >> 4) * 8 + ks * 32);
+        const bool ok = q_ok && ks * 4 + (lane >> 4) < dch;
+        qf[ks] = load_frag_or_zero(Q + (bf * sh.Sq + qrow) * ldq + col + ks * 32, ok);
+        dof[ks] = load_frag_or_zero(dO + (bz * sh.Sq + qrow) * lddo + col + ks * 32, ok);
+        if (Og) {
+            const bf16x8_t of = load_frag_or_zero(Og + (bf * sh.Sq + qrow) * ldo + col + ks * 32, ok);
+            const u32x4_t a = __builtin_bit_cast(u32x4_t, dof[ks]), c = __builtin_bit_cast(u32x4_t, of);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dl += __builtin_bit_cast(float, a[e] << 16) * __builtin_bit_cast(float, c[e] << 16) +
+                      __builtin_bit_cast(float, a[e] & 0xffff0000u) * __builtin_bit_cast(float, c[e] & 0xffff0000u);
+        }
     }
-    const float lse = LSE2[zf * Sqp + qrow], dl = delta[z * Sqp + qrow];
+    if (Og) {
+        dl = group_sum(dl);                                     // the four 16-lane groups hold the four k-chunks of a row
+        if ((lane >> 4) == 0) delta[z * sh.Sqp + q0 + lane] = dl;
+    } else {
+        dl = delta[z * sh.Sqp + qrow];
+    }
+    const float lse = LSE2[zf * sh.Sqp + qrow];
     f32x4_t dqt[F::DT];
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt) dqt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* kg = K + zf * Skp * DP;
-    const bf16_t* vg = V + zf * Skp * DP;
+    const bf16_t* kg = K + bf * sh.Sk * ldk + h * sh.hoff;
+    const bf16_t* vg = V + bf * sh.Sk * ldv + h * sh.hoff;
     TileRegs<DP> kr, vr;
-    tile_load<DP>(kg, kr, tid);
-    tile_load<DP>(vg, vr, tid);
+    tile_load<DP>(kg, ldk, sh.Sk, dch, kr, tid);
+    tile_load<DP>(vg, ldv, sh.Sk, dch, vr, tid);
     for (int k0 = 0; k0 < Skp; k0 += kTQ) {
         __syncthreads();
         tile_store<DP>(kr, ks_, tid);
         tile_store<DP>(vr, vs_, tid);
         __syncthreads();
         if (k0 + kTQ < Skp) {
-            tile_load<DP>(kg + (long)(k0 + kTQ) * DP, kr, tid);
-            tile_load<DP>(vg + (long)(k0 + kTQ) * DP, vr, tid);
+            tile_load<DP>(kg + (long)(k0 + kTQ) * ldk, ldk, sh.Sk - k0 - kTQ, dch, kr, tid);
+            tile_load<DP>(vg + (long)(k0 + kTQ) * ldv, ldv, sh.Sk - k0 - kTQ, dch, vr, tid);
         }
         f32x4_t st[4], dp[4];
 #pragma unroll
@@ -264,10 +317,11 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
                 dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DP>(ks_, j, dt, lane), dsf, dqt[dt], 0, 0, 0);
         }
     }
-    bf16_t* og = dQ + (z * Sqp + qrow) * DP + (lane >> 4) * 4;
+    bf16_t* og = dQ + (bz * sh.Sq + qrow) * lddq + h * sh.hoff + (lane >> 4) * 4;
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt)
-        *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(dqt[dt][0] * scale, dqt[dt][1] * scale), pack_bf2(dqt[dt][2] * scale, dqt[dt][3] * scale)};
+        if (q_ok && dt * 16 + (lane >> 4) * 4 < sh.D)
+            *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(dqt[dt][0] * scale, dqt[dt][1] * scale), pack_bf2(dqt[dt][2] * scale, dqt[dt][3] * scale)};
 }
 
 // ====================================================================================================================
@@ -275,44 +329,52 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
 // S[q][key] = mfma(Q rows, K rows): a lane keeps ONE key and 4 consecutive queries of each 16-query sub-tile.
 // ====================================================================================================================
 template <int DP>
-__global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                    const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
+                                                                    long ldk, const bf16_t* __restrict__ V, long ldv,
+                                                                    const bf16_t* __restrict__ dO, long lddo,
                                                                     const float* __restrict__ LSE2, const float* __restrict__ delta,
-                                                                    bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int BH,
-                                                                    int Sqp, int Skp, int valid_k, float scale, float scale_log2) {
+                                                                    bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV,
+                                                                    long lddv, int Bf, FAShape sh, float scale, float scale_log2) {
     using F = FA<DP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* qs_ = smem;
     char* dos_ = smem + F::TILE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long z = blockIdx.y, zf = z % BH;
+    const long z = blockIdx.y;
+    const long bz = z / sh.H;
+    const int h = (int)(z - bz * sh.H);
+    const long bf = bz % Bf, zf = bf * sh.H + h;
+    const int dch = sh.D >> 3, Sqp = sh.Sqp;
     const int k0 = blockIdx.x * kTQ + w * 16;
-    const long krow = k0 + (lane & 15);
-    const float key_lse_off = krow < valid_k ? 0.f : -INFINITY;     // a lane keeps ONE key: its mask is one additive constant
+    const int krow = k0 + (lane & 15);
+    const bool k_ok = krow < sh.Sk;
+    const float key_lse_off = krow < sh.valid_k ? 0.f : -INFINITY;     // a lane keeps ONE key: its mask is one additive constant
+    const long col = h * sh.hoff + (lane >> 4) * 8;
     bf16x8_t kf[F::KS], vf[F::KS];
 #pragma unroll
     for (int ks = 0; ks < F::KS; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8_t*>(K + (zf * Skp + krow) * DP + (lane >> 4) * 8 + ks * 32);
-        vf[ks] = *reinterpret_cast<const bf16x8_t*>(V + (zf * Skp + krow) * DP + (lane >> 4) * 8 + ks * 32);
+        const bool ok = k_ok && ks * 4 + (lane >> 4) < dch;
+        kf[ks] = load_frag_or_zero(K + (bf * sh.Sk + krow) * ldk + col + ks * 32, ok);
+        vf[ks] = load_frag_or_zero(V + (bf * sh.Sk + krow) * ldv + col + ks * 32, ok);
     }
     f32x4_t dkt[F::DT], dvt[F::DT];
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt) { dkt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    const bf16_t* qg = Q + zf * Sqp * DP;
-    const bf16_t* dog = dO + z * Sqp * DP;
+    const bf16_t* qg = Q + bf * sh.Sq * ldq + h * sh.hoff;
+    const bf16_t* dog = dO + bz * sh.Sq * lddo + h * sh.hoff;
     const float* lseg = LSE2 + zf * Sqp;
     const float* dlg = delta + z * Sqp;
     TileRegs<DP> qr, dor;
-    tile_load<DP>(qg, qr, tid);
-    tile_load<DP>(dog, dor, tid);
+    tile_load<DP>(qg, ldq, sh.Sq, dch, qr, tid);
+    tile_load<DP>(dog, lddo, sh.Sq, dch, dor, tid);
     for (int q0 = 0; q0 < Sqp; q0 += kTQ) {
         __syncthreads();
         tile_store<DP>(qr, qs_, tid);
         tile_store<DP>(dor, dos_, tid);
         __syncthreads();
         if (q0 + kTQ < Sqp) {
-            tile_load<DP>(qg + (long)(q0 + kTQ) * DP, qr, tid);
-            tile_load<DP>(dog + (long)(q0 + kTQ) * DP, dor, tid);
+            tile_load<DP>(qg + (long)(q0 + kTQ) * ldq, ldq, sh.Sq - q0 - kTQ, dch, qr, tid);
+            tile_load<DP>(dog + (long)(q0 + kTQ) * lddo, lddo, sh.Sq - q0 - kTQ, dch, dor, tid);
         }
         f32x4_t s[4], dp[4];
 #pragma unroll
@@ -332,7 +394,9 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
             const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(dlg + qb);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(fmaf(s[sub][r], scale_log2, key_lse_off - lse[r]));     // padded key: exp2(-inf) = 0
+                // padded key: exp2(-inf) = 0.  A padded QUERY row (past Sq) has q = dO = 0 in LDS: its P is finite garbage, but
+                // it only ever multiplies those zero rows in the dV / dK products
+                const float p = fast_exp2(fmaf(s[sub][r], scale_log2, key_lse_off - lse[r]));
                 s[sub][r] = p;
                 ds[sub][r] = p * (dp[sub][r] - dl[r]);                                              // (scale: once, on the finished dK tile)
             }
@@ -348,19 +412,65 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
             }
         }
     }
-    bf16_t* okg = dK + (z * Skp + krow) * DP + (lane >> 4) * 4;
-    bf16_t* ovg = dV + (z * Skp + krow) * DP + (lane >> 4) * 4;
+    bf16_t* okg = dK + (bz * sh.Sk + krow) * lddk + h * sh.hoff + (lane >> 4) * 4;
+    bf16_t* ovg = dV + (bz * sh.Sk + krow) * lddv + h * sh.hoff + (lane >> 4) * 4;
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt) {
+        if (!(k_ok && dt * 16 + (lane >> 4) * 4 < sh.D)) continue;
         *reinterpret_cast<u32x2_t*>(okg + dt * 16) = u32x2_t{pack_bf2(dkt[dt][0] * scale, dkt[dt][1] * scale), pack_bf2(dkt[dt][2] * scale, dkt[dt][3] * scale)};
         *reinterpret_cast<u32x2_t*>(ovg + dt * 16) = u32x2_t{pack_bf2(dvt[dt][0], dvt[dt][1]), pack_bf2(dvt[dt][2], dvt[dt][3])};
     }
+}
+
+inline int fa_dpad(int D) { return D <= 64 ? 64 : (D <= 128 ? 128 : (D <= 192 ? 192 : 0)); }
+
+struct FwdArgs { const void *q, *k, *v; void* o; long ldq, ldk, ldv, ldo; float* lse2; };
+int fa_launch_fwd(const FwdArgs& a, int nbh, const FAShape& sh, float scale, void* stream) {
+    const dim3 grid(sh.Sqp / kTQ, nbh);
+    const float sl2 = scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+#define FA_FWD(DP)                                                                                                       \
+    do {                                                                                                                  \
+        static unsigned char att[kMaxDevices];                                                                            \
+        if (siss_ensure_smem((const void*)flash_fwd_kernel<DP>, 2 * FA<DP>::TILE, att) != SISS_OK) return SISS_ERR_LAUNCH; \
+        flash_fwd_kernel<DP><<<grid, kThreadsFA, 2 * FA<DP>::TILE, st>>>((const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, \
+            (const bf16_t*)a.v, a.ldv, (bf16_t*)a.o, a.ldo, a.lse2, sh, sl2);                                              \
+    } while (0)
+    const int dp = fa_dpad(sh.D);
+    if (dp == 64) FA_FWD(64); else if (dp == 128) FA_FWD(128); else FA_FWD(192);
+#undef FA_FWD
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+}
+
+struct BwdArgs { const void *q, *k, *v, *o, *d_o; void *dq, *dk, *dv; long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+                 const float* lse2; float* delta; };
+int fa_launch_bwd(const BwdArgs& a, int nbh, int Bf, const FAShape& sh, float scale, void* stream) {
+    const float sl2 = scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+    // dQ first: it forms delta = rowsum(dO o O) for its 64 queries (when O is given) and leaves it for the dK / dV kernel
+#define FA_BWD(DP)                                                                                                          \
+    do {                                                                                                                     \
+        static unsigned char a1[kMaxDevices], a2[kMaxDevices];                                                               \
+        if (siss_ensure_smem((const void*)flash_bwd_dq_kernel<DP>, 2 * FA<DP>::TILE, a1) != SISS_OK) return SISS_ERR_LAUNCH; \
+        if (siss_ensure_smem((const void*)flash_bwd_dkdv_kernel<DP>, 2 * FA<DP>::TILE, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
+        flash_bwd_dq_kernel<DP><<<dim3(sh.Sqp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                            \
+            (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.o, a.ldo,     \
+            (const bf16_t*)a.d_o, a.lddo, a.lse2, a.delta, (bf16_t*)a.dq, a.lddq, Bf, sh, scale, sl2);                      \
+        flash_bwd_dkdv_kernel<DP><<<dim3(sh.Skp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                          \
+            (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.d_o, a.lddo,  \
+            a.lse2, a.delta, (bf16_t*)a.dk, a.lddk, (bf16_t*)a.dv, a.lddv, Bf, sh, scale, sl2);                             \
+    } while (0)
+    const int dp = fa_dpad(sh.D);
+    if (dp == 64) FA_BWD(64); else if (dp == 128) FA_BWD(128); else FA_BWD(192);
+#undef FA_BWD
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
 
 bool fa_shape_ok(int Sqp, int Skp, int Dp, int valid_k) {
     return Sqp > 0 && Skp > 0 && Sqp % kTQ == 0 && Skp % kTQ == 0 && (Dp == 64 || Dp == 128 || Dp == 192) && valid_k > 0 &&
            valid_k <= Skp;
 }
+inline int up64(int v) { return (v + 63) / 64 * 64; }
 
 }  // namespace
 
@@ -374,19 +484,22 @@ int siss_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, fl
     SISS_CHECK_ARG(q && k && v && o && lse2 && BH > 0 && fa_shape_ok(Sq_pad, Sk_pad, D_pad, valid_k));
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0);
     siss_count_dispatch(SISS_K_FLASH_FWD);
-    const dim3 grid(Sq_pad / kTQ, BH);
-    const float sl2 = scale * 1.4426950408889634f;
-    hipStream_t st = (hipStream_t)stream;
-#define FA_FWD(DP)                                                                                                       \
-    do {                                                                                                                  \
-        static unsigned char att[kMaxDevices];                                                                            \
-        if (siss_ensure_smem((const void*)flash_fwd_kernel<DP>, 2 * FA<DP>::TILE, att) != SISS_OK) return SISS_ERR_LAUNCH; \
-        flash_fwd_kernel<DP><<<grid, kThreadsFA, 2 * FA<DP>::TILE, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, \
-                                                                        (bf16_t*)o, lse2, Sq_pad, Sk_pad, valid_k, sl2);  \
-    } while (0)
-    if (D_pad == 64) FA_FWD(64); else if (D_pad == 128) FA_FWD(128); else FA_FWD(192);
-#undef FA_FWD
-    SISS_LAUNCH_RET();
+    const FAShape sh{1, 0, D_pad, Sq_pad, Sk_pad, Sq_pad, Sk_pad, valid_k};
+    return fa_launch_fwd(FwdArgs{q, k, v, o, D_pad, D_pad, D_pad, D_pad, lse2}, BH, sh, scale, stream);
+}
+
+// The same on the projections' own layout: q / o rows [B * Sq][ld >= H * D], k / v rows [B * Sk][ld], head h at columns
+// [h * D, (h + 1) * D) -- no head-split / head-merge copies and no padded tensors.  D % 8 == 0, D <= 192; every ld % 8 == 0;
+// lse2 [B * H][ceil64(Sq)] f32.  Keys: all Sk rows are valid.
+int siss_flash_attn_fwd_merged(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
+                               float* lse2, int B, int H, int Sq, int Sk, int D, float scale, void* stream) {
+    SISS_CHECK_ARG(q && k && v && o && lse2 && B > 0 && H > 0 && Sq > 0 && Sk > 0 && D > 0 && D % 8 == 0 && fa_dpad(D));
+    SISS_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && ldq >= (long)H * D && ldk >= (long)H * D &&
+                   ldv >= (long)H * D && ldo >= (long)H * D);
+    SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0);
+    siss_count_dispatch(SISS_K_FLASH_FWD);
+    const FAShape sh{H, D, D, Sq, Sk, up64(Sq), up64(Sk), Sk};
+    return fa_launch_fwd(FwdArgs{q, k, v, o, ldq, ldk, ldv, ldo, lse2}, B * H, sh, scale, stream);
 }
 
 // dQ, dK, dV for nBH cotangent (batch, head) entries against BH forward entries (entry z uses forward entry z % BH: the
@@ -400,23 +513,31 @@ int siss_flash_attn_bwd(const void* q, const void* k, const void* v, const void*
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 16 == 0);
     SISS_CHECK_ARG(((uintptr_t)lse2 | (uintptr_t)delta) % 16 == 0);
     siss_count_dispatch(SISS_K_FLASH_BWD);
-    const float sl2 = scale * 1.4426950408889634f;
-    hipStream_t st = (hipStream_t)stream;
-#define FA_BWD(DP)                                                                                                          \
-    do {                                                                                                                     \
-        static unsigned char a1[kMaxDevices], a2[kMaxDevices];                                                               \
-        if (siss_ensure_smem((const void*)flash_bwd_dq_kernel<DP>, 2 * FA<DP>::TILE, a1) != SISS_OK) return SISS_ERR_LAUNCH; \
-        if (siss_ensure_smem((const void*)flash_bwd_dkdv_kernel<DP>, 2 * FA<DP>::TILE, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
-        flash_bwd_dkdv_kernel<DP><<<dim3(Sk_pad / kTQ, nBH), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                          \
-            (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dk, (bf16_t*)dv, \
-            BH, Sq_pad, Sk_pad, valid_k, scale, sl2);                                                                        \
-        flash_bwd_dq_kernel<DP><<<dim3(Sq_pad / kTQ, nBH), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                            \
-            (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)d_o, lse2, delta, (bf16_t*)dq, BH, Sq_pad,  \
-            Sk_pad, valid_k, scale, sl2);                                                                                    \
-    } while (0)
-    if (D_pad == 64) FA_BWD(64); else if (D_pad == 128) FA_BWD(128); else FA_BWD(192);
-#undef FA_BWD
-    SISS_LAUNCH_RET();
+    const FAShape sh{1, 0, D_pad, Sq_pad, Sk_pad, Sq_pad, Sk_pad, valid_k};
+    const long d = D_pad;
+    return fa_launch_bwd(BwdArgs{q, k, v, nullptr, d_o, dq, dk, dv, d, d, d, d, d, d, d, d, lse2, const_cast<float*>(delta)},
+                         nBH, BH, sh, scale, stream);
+}
+
+// The same on the projections' own layout (see siss_flash_attn_fwd_merged): nB cotangent batch entries against B forward ones
+// (entry b uses forward entry b % B).  o: the forward's output (delta = rowsum(dO o O) is formed by the dQ kernel and parked in
+// `delta`, scratch of nB * H * ceil64(Sq) floats, 16-B aligned).  d_o / dq rows [nB * Sq], dk / dv rows [nB * Sk].
+int siss_flash_attn_bwd_merged(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo,
+                               const void* d_o, long lddo, const float* lse2, float* delta, void* dq, long lddq, void* dk,
+                               long lddk, void* dv, long lddv, int nB, int B, int H, int Sq, int Sk, int D, float scale,
+                               void* stream) {
+    SISS_CHECK_ARG(q && k && v && o && d_o && lse2 && delta && dq && dk && dv && B > 0 && nB >= B && nB % B == 0 && H > 0);
+    SISS_CHECK_ARG(Sq > 0 && Sk > 0 && D > 0 && D % 8 == 0 && fa_dpad(D));
+    const long need = (long)H * D;
+    SISS_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 &&
+                   lddv % 8 == 0 && ldq >= need && ldk >= need && ldv >= need && ldo >= need && lddo >= need && lddq >= need &&
+                   lddk >= need && lddv >= need);
+    SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 16 == 0);
+    SISS_CHECK_ARG(((uintptr_t)lse2 | (uintptr_t)delta) % 16 == 0);
+    siss_count_dispatch(SISS_K_FLASH_BWD);
+    const FAShape sh{H, D, D, Sq, Sk, up64(Sq), up64(Sk), Sk};
+    return fa_launch_bwd(BwdArgs{q, k, v, o, d_o, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, lse2, delta},
+                         nB * H, B, sh, scale, stream);
 }
 
 }  // extern "C"

@@ -82,6 +82,8 @@ SIGNATURES = {
     "siss_head_merge": [P, P, I, I, I, I, I, I, P],
     "siss_flash_attn_fwd": [P, P, P, P, P, I, I, I, I, I, F],
     "siss_flash_attn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F],
+    "siss_flash_attn_fwd_merged": [P, L, P, L, P, L, P, L, P, I, I, I, I, I, F],
+    "siss_flash_attn_bwd_merged": [P, L, P, L, P, L, P, L, P, L, P, P, P, L, P, L, P, L, I, I, I, I, I, I, F],
     "siss_softmax_rows_fwd": [P, P, L, I, I, I, P],
     "siss_quick_gelu": [P, P, L, P],
     "siss_softmax_rows_bwd": [P, P, P, L, L, I, I, F, P],
@@ -211,6 +213,10 @@ def _work(name, a):
         return 2.0 * 2 * a[5] * a[6] * a[9] * a[8]
     if name == "siss_flash_attn_bwd":   # algorithmic: S, dP, dQ, dK, dV (the two-kernel form recomputes S and dP: 7 products run)
         return 2.0 * 5 * a[9] * a[11] * a[14] * a[13]
+    if name == "siss_flash_attn_fwd_merged":   # true head dim, true rows: 2 products over B * H heads
+        return 2.0 * 2 * a[9] * a[10] * a[11] * a[12] * a[13]
+    if name == "siss_flash_attn_bwd_merged":
+        return 2.0 * 5 * a[18] * a[20] * a[21] * a[22] * a[23]
     return 0.0
 
 
@@ -249,6 +255,10 @@ def _shape_key(name, a):
         return ("BH", a[5], "Sq", a[6], "Sk", a[9], "D", a[8])
     if name == "siss_flash_attn_bwd":
         return ("BH", a[9], "Sq", a[11], "Sk", a[14], "D", a[13])
+    if name == "siss_flash_attn_fwd_merged":
+        return ("BH", a[9] * a[10], "Sq", a[11], "Sk", a[12], "D", a[13])
+    if name == "siss_flash_attn_bwd_merged":
+        return ("BH", a[18] * a[20], "Sq", a[21], "Sk", a[22], "D", a[23])
     return ()
 
 
@@ -299,6 +309,8 @@ def call(name, *args):
         elif name == "siss_groupnorm_fwd_qs":
             name, args = "siss_groupnorm_fwd_ld", list(args[:7]) + list(args[10:])
         base = name[:-3] if name.endswith("_ld") else name          # row-stride variants count as their plain form
+        if base.endswith("_merged"):
+            base = base[:-7]
         if base == "siss_conv3x3_sc":
             base = "siss_gemm_nt"
         PROF.append((base, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args), hbm_bytes(name, args)))

@@ -179,22 +179,26 @@ class UNetCondEngine(UNetEngine):
         tb = lambda s, shape, dt=torch.bfloat16: self._buf((nm if self.group_attn and self.group_rows else "tfm") + ".scr" + s, shape, dt)
         sb = lambda s, shape, dt=torch.bfloat16: self._buf("tfm" + s, shape, dt)   # always shared: the S x S matrices of the materialised path
         rq, rk = B * Sq, B * Sk
-        q, k, v = tb(".q", (rq, C)), tb(".k", (rk, C)), tb(".v", (rk, C))
+        flash = self.flash and Dp in (64, 128, 192)
+        # fused path: the kernels address q / k / v / o in the projections' own [rows, C] layout (head h at columns h * D): the
+        # projection outputs are what the backward keeps -- no head-split / head-merge copies, no padded tensors
+        keep = bb if flash else tb
+        q, k, v = keep(".q", (rq, C)), keep(".k", (rk, C)), keep(".v", (rk, C))
         self._linear(xq, pre + ".to_q", q, rq, C, C, bias=False)
         self._linear(xkv, pre + ".to_k", k, rk, C, Ckv, bias=False)
         self._linear(xkv, pre + ".to_v", v, rk, C, Ckv, bias=False)
-        qh, kh, vh = bb(".qh", (BH, Sqp, Dp)), bb(".kh", (BH, Skp, Dp)), bb(".vh", (BH, Skp, Dp))
-        lib.call("siss_head_split", q, qh, B, Sq, Hh, D, Sqp, Dp)
-        lib.call("siss_head_split", k, kh, B, Sk, Hh, D, Skp, Dp)
-        lib.call("siss_head_split", v, vh, B, Sk, Hh, D, Skp, Dp)
-        oh = bb(".oh", (BH, Sqp, Dp))                # kept: delta = rowsum(dO o O) in the backward
-        flash = self.flash and Dp in (64, 128, 192)
+        o = bb(".o", (rq, C))
         if flash:
             # QK^T -> softmax -> .V in ONE kernel (csrc/flash_attn.hip): the S x S matrices never reach HBM; the base-2
             # log-sum-exp is all the backward needs besides q, k, v, o
             lse = bb(".lse", (BH, Sqp), torch.float32)
-            lib.call("siss_flash_attn_fwd", qh, kh, vh, oh, lse, BH, Sqp, Skp, Dp, Sk, float(scale))
+            lib.call("siss_flash_attn_fwd_merged", q, C, k, C, v, C, o, C, lse, B, Hh, Sq, Sk, D, float(scale))
         else:
+            qh, kh, vh = bb(".qh", (BH, Sqp, Dp)), bb(".kh", (BH, Skp, Dp)), bb(".vh", (BH, Skp, Dp))
+            lib.call("siss_head_split", q, qh, B, Sq, Hh, D, Sqp, Dp)
+            lib.call("siss_head_split", k, kh, B, Sk, Hh, D, Skp, Dp)
+            lib.call("siss_head_split", v, vh, B, Sk, Hh, D, Skp, Dp)
+            oh = bb(".oh", (BH, Sqp, Dp))                # kept: delta = rowsum(dO o O) in the backward
             vT = sb(".vT", (BH, Dp, Skp))
             lib.call("siss_transpose_bf16", vh, vT, BH, Skp, Dp)
             sc, p = sb(".sc", (BH, Sqp, Skp)), bb(".p", (BH, Sqp, Skp))
@@ -203,8 +207,7 @@ class UNetCondEngine(UNetEngine):
             lib.call("siss_softmax_rows_fwd", sc, p, BH * Sqp, Sk, Skp, 0)
             ops.gemm_nt(lib.ptr(p), Skp, vT, lib.ptr(oh), Dp, Sqp, Dp, Skp, [0], [0], batch=BH,
                         stride_a=Sqp * Skp, stride_w=Dp * Skp, stride_c=Sqp * Dp)
-        o = bb(".o", (rq, C))
-        lib.call("siss_head_merge", oh, o, B, Sq, Hh, D, Sqp, Dp)
+            lib.call("siss_head_merge", oh, o, B, Sq, Hh, D, Sqp, Dp)
         out = bb(".out", (rq, C))
         self._linear(o, pre + ".to_out.0", out, rq, C, C, residual=residual)
 
@@ -217,19 +220,21 @@ class UNetCondEngine(UNetEngine):
             zp = ops.zero_page(self.device)
             do = tb(".do", (rows2, C))
             self._linear_bwd(dout, o, pre + ".to_out.0", rows2, rq, C, C, dx_out=do)
-            doh = tb(".doh", (nBH, Sqp, Dp))
-            lib.call("siss_head_split", do, doh, nb, Sq, Hh, D, Sqp, Dp)
+            dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (nb * Sk, C)), tb(".dv", (nb * Sk, C))
             delta = tb(".delta", (nBH * Sqp,), torch.float32)
-            dqh = tb(".dqh", (nBH, Sqp, Dp))
-            dkh, dvh = tb(".dkh", (nBH, Skp, Dp)), tb(".dvh", (nBH, Skp, Dp))
-            # delta[q] = sum_k P[q][k] dP[q][k] = <dO[q], O[q]> : no pass over the S x S matrices needed for it
-            lib.call("siss_rowdot", doh, oh, delta, nBH * Sqp, BH * Sqp, Dp)
             if flash:
                 # FlashAttention-2 style: P is recomputed per tile from q, k and the saved log-sum-exp; all cotangent
-                # (batch, head) entries in one launch pair, entry z against forward entry z % BH
-                lib.call("siss_flash_attn_bwd", qh, kh, vh, doh, lse, delta, dqh, dkh, dvh, nBH, BH, Sqp, Skp, Dp, Sk,
-                         float(scale))
+                # (batch, head) entries in one launch pair, cotangent batch b against forward batch b % B; delta[q] =
+                # sum_k P[q][k] dP[q][k] = <dO[q], O[q]> is formed by the dQ kernel from tiles it loads anyway
+                lib.call("siss_flash_attn_bwd_merged", q, C, k, C, v, C, o, C, do, C, lse, delta, dq, C, dk, C, dv, C,
+                         nb, B, Hh, Sq, Sk, D, float(scale))
             else:
+                doh = tb(".doh", (nBH, Sqp, Dp))
+                lib.call("siss_head_split", do, doh, nb, Sq, Hh, D, Sqp, Dp)
+                dqh = tb(".dqh", (nBH, Sqp, Dp))
+                dkh, dvh = tb(".dkh", (nBH, Skp, Dp)), tb(".dvh", (nBH, Skp, Dp))
+                # delta[q] = sum_k P[q][k] dP[q][k] = <dO[q], O[q]> : no pass over the S x S matrices needed for it
+                lib.call("siss_rowdot", doh, oh, delta, nBH * Sqp, BH * Sqp, Dp)
                 ds = sb(".ds", (nBH, Sqp, Skp))
                 dkf, dvf = sb(".dkf", (nBH, Skp, Dp), torch.float32), sb(".dvf", (nBH, Skp, Dp), torch.float32)
                 khT = sb(".khT", (BH, Dp, Skp))
@@ -253,10 +258,9 @@ class UNetCondEngine(UNetEngine):
                              0, Sqp, -1, zp, None, None)     # -1: one split, dW overwritten (no zero fill)
                 lib.call("siss_cast_f32_bf16", dkf, dkh, dkf.numel())
                 lib.call("siss_cast_f32_bf16", dvf, dvh, dvf.numel())
-            dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (nb * Sk, C)), tb(".dv", (nb * Sk, C))
-            lib.call("siss_head_merge", dqh, dq, nb, Sq, Hh, D, Sqp, Dp)
-            lib.call("siss_head_merge", dkh, dk, nb, Sk, Hh, D, Skp, Dp)
-            lib.call("siss_head_merge", dvh, dv, nb, Sk, Hh, D, Skp, Dp)
+                lib.call("siss_head_merge", dqh, dq, nb, Sq, Hh, D, Sqp, Dp)
+                lib.call("siss_head_merge", dkh, dk, nb, Sk, Hh, D, Skp, Dp)
+                lib.call("siss_head_merge", dvh, dv, nb, Sk, Hh, D, Skp, Dp)
             self._linear_bwd(dq, xq, pre + ".to_q", rows2, rq, C, C, dx_out=dxq, bias=False)
             self._linear_bwd(dk, xkv, pre + ".to_k", nb * Sk, rk, C, Ckv, dx_out=dxkv, accumulate=True, bias=False)
             self._linear_bwd(dv, xkv, pre + ".to_v", nb * Sk, rk, C, Ckv, dx_out=dxkv, accumulate=True, bias=False)

@@ -107,3 +107,64 @@ def test_flash_attention_rejects_unsupported_shapes(dev):
         lib.call("siss_flash_attn_fwd", t, t, t, t, lse, 1, 64, 64, 256, 64, 1.0)      # D_pad 256: not covered
     with pytest.raises(RuntimeError, match="bad argument"):
         lib.call("siss_flash_attn_fwd", t, t, t, t, lse, 1, 60, 64, 64, 64, 1.0)       # Sq_pad not a multiple of 64
+
+
+MERGED_CASES = [  # B, H, Sq, Sk, D, extra row-stride columns
+    (2, 8, 256, 256, 40, 0),      # SD 64-channel-per-... level shape: 8 heads of 40 in 320-wide rows
+    (2, 8, 128, 77, 40, 0),       # cross attention: 77 keys, second key tile mostly padding that does not exist in memory
+    (1, 4, 100, 100, 80, 64),     # ragged rows (100 of 128), head dim 80, rows wider than heads * D
+    (2, 2, 64, 200, 160, 0),      # head dim 160 (three 64-wide k-steps), ragged keys
+]
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,D,extra", MERGED_CASES)
+def test_flash_attention_on_the_projection_layout(dev, B, H, Sq, Sk, D, extra):
+    """siss_flash_attn_fwd_merged / _bwd_merged: the same kernels reading q / k / v / dO and writing o / dq / dk / dv in the
+    projections' own [B * S, heads * D] layout (head h at columns h * D) -- no head-split / head-merge copies, no padding in
+    memory; delta = rowsum(dO o O) formed inside the dQ kernel.  Against torch fp32 attention + autograd, two cotangent sets."""
+    from siss_amd import lib
+    g = torch.Generator().manual_seed(B * 100 + H + Sq + Sk + D)
+    C, ld = H * D, H * D + extra
+    sets = 2
+
+    def rows(n, S):                                             # [n * S, ld] bf16 on the device, garbage in the extra columns
+        t = torch.randn(n * S, ld, generator=g)
+        return t.to(torch.bfloat16).to(dev)
+    q, k, v, do = rows(B, Sq), rows(B, Sk), rows(B, Sk), rows(sets * B, Sq)
+    heads = lambda t, n, S: t[:, :C].float().cpu().view(n, S, H, D).permute(0, 2, 1, 3)        # [n, H, S, D]
+    scale = D ** -0.5
+    qr, kr, vr = (heads(t, B, S).clone().requires_grad_(True) for t, S in ((q, Sq), (k, Sk), (v, Sk)))
+    s = (qr @ kr.transpose(2, 3)) * scale
+    o_ref = torch.softmax(s, dim=-1) @ vr
+    dor = heads(do, sets * B, Sq)
+    grads = [torch.autograd.grad(o_ref, (qr, kr, vr), dor[i * B:(i + 1) * B], retain_graph=True) for i in range(sets)]
+
+    Sqp = _up(Sq, 64)
+    o = torch.full((B * Sq, ld), 7.0, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(B * H, Sqp, device=dev)
+    lib.dispatch_counts(reset=True)
+    lib.call("siss_flash_attn_fwd_merged", q, ld, k, ld, v, ld, o, ld, lse, B, H, Sq, Sk, D, float(scale))
+    torch.cuda.synchronize()
+    _close(heads(o, B, Sq), o_ref.detach(), 1e-2, "O")
+    if extra:
+        assert float((o[:, C:].float() - 7.0).abs().max()) == 0.0, "columns past heads * D are not the kernel's to write"
+    lse_ref = torch.logsumexp(s, dim=-1) / math.log(2.0)
+    assert (lse.view(B, H, Sqp)[:, :, :Sq].cpu() - lse_ref.detach()).abs().max() < 2e-3
+
+    dq = torch.full((sets * B * Sq, ld), 3.0, dtype=torch.bfloat16, device=dev)
+    dk, dv = (torch.full((sets * B * Sk, ld), 3.0, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    delta = torch.zeros(sets * B * H * Sqp, device=dev)
+    lib.call("siss_flash_attn_bwd_merged", q, ld, k, ld, v, ld, o, ld, do, ld, lse, delta, dq, ld, dk, ld, dv, ld,
+             sets * B, B, H, Sq, Sk, D, float(scale))
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    assert cnt["flash_attn_fwd"] == 1 and cnt["flash_attn_bwd"] == 1
+    d_ref = (dor * heads(o, B, Sq).repeat(sets, 1, 1, 1)).sum(-1)                       # <dO, O> with the bf16 O the kernel read
+    _close(delta.view(sets * B, H, Sqp)[:, :, :Sq].cpu(), d_ref, 1e-2, "delta")
+    for i in range(sets):
+        _close(heads(dq, sets * B, Sq)[i * B:(i + 1) * B], grads[i][0], 2e-2, f"dQ set {i}")
+        _close(heads(dk, sets * B, Sk)[i * B:(i + 1) * B], grads[i][1], 2e-2, f"dK set {i}")
+        _close(heads(dv, sets * B, Sk)[i * B:(i + 1) * B], grads[i][2], 2e-2, f"dV set {i}")
+    if extra:
+        for t in (dq, dk, dv):
+            assert float((t[:, C:].float() - 3.0).abs().max()) == 0.0
