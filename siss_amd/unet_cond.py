@@ -183,16 +183,28 @@ class UNetCondEngine(UNetEngine):
         # fused path: the kernels address q / k / v / o in the projections' own [rows, C] layout (head h at columns h * D): the
         # projection outputs are what the backward keeps -- no head-split / head-merge copies, no padded tensors
         keep = bb if flash else tb
-        q, k, v = keep(".q", (rq, C)), keep(".k", (rk, C)), keep(".v", (rk, C))
-        self._linear(xq, pre + ".to_q", q, rq, C, C, bias=False)
-        self._linear(xkv, pre + ".to_k", k, rk, C, Ckv, bias=False)
-        self._linear(xkv, pre + ".to_v", v, rk, C, Ckv, bias=False)
+        ps = self.ps
+        wq, wk, wv = (ps.sh(pre + n + ".weight") for n in (".to_q", ".to_k", ".to_v"))
+        # self-attention on the fused path: q, k and v are ONE projection (the three weights lie back to back in the flat
+        # buffer: a [3C][C] matrix) into one [rows, 3C] tensor -- the normalised input is read once, and the attention kernels
+        # take the three column blocks by pointer + row stride
+        fused_qkv = (flash and xq is xkv and Ckv == C and wk.data_ptr() == wq.data_ptr() + 2 * C * C
+                     and wv.data_ptr() == wk.data_ptr() + 2 * C * C)
+        if fused_qkv:
+            qkv = bb(".qkv", (rq, 3 * C))
+            ops.gemm_nt(lib.ptr(xq), C, wq, lib.ptr(qkv), 3 * C, rq, 3 * C, C, [0], [0])
+            q, k, v, ldqkv = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], 3 * C
+        else:
+            q, k, v, ldqkv = keep(".q", (rq, C)), keep(".k", (rk, C)), keep(".v", (rk, C)), C
+            self._linear(xq, pre + ".to_q", q, rq, C, C, bias=False)
+            self._linear(xkv, pre + ".to_k", k, rk, C, Ckv, bias=False)
+            self._linear(xkv, pre + ".to_v", v, rk, C, Ckv, bias=False)
         o = bb(".o", (rq, C))
         if flash:
             # QK^T -> softmax -> .V in ONE kernel (csrc/flash_attn.hip): the S x S matrices never reach HBM; the base-2
             # log-sum-exp is all the backward needs besides q, k, v, o
             lse = bb(".lse", (BH, Sqp), torch.float32)
-            lib.call("siss_flash_attn_fwd_merged", q, C, k, C, v, C, o, C, lse, B, Hh, Sq, Sk, D, float(scale))
+            lib.call("siss_flash_attn_fwd_merged", q, ldqkv, k, ldqkv, v, ldqkv, o, C, lse, B, Hh, Sq, Sk, D, float(scale))
         else:
             qh, kh, vh = bb(".qh", (BH, Sqp, Dp)), bb(".kh", (BH, Skp, Dp)), bb(".vh", (BH, Skp, Dp))
             lib.call("siss_head_split", q, qh, B, Sq, Hh, D, Sqp, Dp)
@@ -220,14 +232,18 @@ class UNetCondEngine(UNetEngine):
             zp = ops.zero_page(self.device)
             do = tb(".do", (rows2, C))
             self._linear_bwd(dout, o, pre + ".to_out.0", rows2, rq, C, C, dx_out=do)
-            dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (nb * Sk, C)), tb(".dv", (nb * Sk, C))
+            if fused_qkv:
+                dqkv = tb(".dqkv", (rows2, 3 * C))
+                dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
+            else:
+                dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (nb * Sk, C)), tb(".dv", (nb * Sk, C))
             delta = tb(".delta", (nBH * Sqp,), torch.float32)
             if flash:
                 # FlashAttention-2 style: P is recomputed per tile from q, k and the saved log-sum-exp; all cotangent
                 # (batch, head) entries in one launch pair, cotangent batch b against forward batch b % B; delta[q] =
                 # sum_k P[q][k] dP[q][k] = <dO[q], O[q]> is formed by the dQ kernel from tiles it loads anyway
-                lib.call("siss_flash_attn_bwd_merged", q, C, k, C, v, C, o, C, do, C, lse, delta, dq, C, dk, C, dv, C,
-                         nb, B, Hh, Sq, Sk, D, float(scale))
+                lib.call("siss_flash_attn_bwd_merged", q, ldqkv, k, ldqkv, v, ldqkv, o, C, do, C, lse, delta, dq, ldqkv, dk, ldqkv,
+                         dv, ldqkv, nb, B, Hh, Sq, Sk, D, float(scale))
             else:
                 doh = tb(".doh", (nBH, Sqp, Dp))
                 lib.call("siss_head_split", do, doh, nb, Sq, Hh, D, Sqp, Dp)
@@ -261,9 +277,17 @@ class UNetCondEngine(UNetEngine):
                 lib.call("siss_head_merge", dqh, dq, nb, Sq, Hh, D, Sqp, Dp)
                 lib.call("siss_head_merge", dkh, dk, nb, Sk, Hh, D, Skp, Dp)
                 lib.call("siss_head_merge", dvh, dv, nb, Sk, Hh, D, Skp, Dp)
-            self._linear_bwd(dq, xq, pre + ".to_q", rows2, rq, C, C, dx_out=dxq, bias=False)
-            self._linear_bwd(dk, xkv, pre + ".to_k", nb * Sk, rk, C, Ckv, dx_out=dxkv, accumulate=True, bias=False)
-            self._linear_bwd(dv, xkv, pre + ".to_v", nb * Sk, rk, C, Ckv, dx_out=dxkv, accumulate=True, bias=False)
+            if fused_qkv:
+                # one weight-gradient product for the [3C][C] matrix (cotangent rows [rows2, 3C]) and one three-panel product
+                # dx = dq W_q + dk W_k + dv W_v (panel p: cotangent columns [pC, (p+1)C) against the p-th transposed copy)
+                self._linear_bwd(dqkv, xq, pre + ".to_q", rows2, rq, 3 * C, C, dx_out=None, bias=False)
+                wts = [self.wT[pre + n + ".weight"] for n in (".to_q", ".to_k", ".to_v")]
+                assert wts[1].data_ptr() == wts[0].data_ptr() + 2 * C * C and wts[2].data_ptr() == wts[1].data_ptr() + 2 * C * C
+                ops.gemm_nt(lib.ptr(dqkv), 3 * C, wts[0], lib.ptr(dxq), C, rows2, C, C, [0, 0, 0], [0, C, 2 * C])
+            else:
+                self._linear_bwd(dq, xq, pre + ".to_q", rows2, rq, C, C, dx_out=dxq, bias=False)
+                self._linear_bwd(dk, xkv, pre + ".to_k", nb * Sk, rk, C, Ckv, dx_out=dxkv, accumulate=True, bias=False)
+                self._linear_bwd(dv, xkv, pre + ".to_v", nb * Sk, rk, C, Ckv, dx_out=dxkv, accumulate=True, bias=False)
         return out, bwd
 
     def transformer(self, x: Act, pre):
