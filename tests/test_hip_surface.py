@@ -227,3 +227,26 @@ def test_checkpoint_crosses_between_hip_and_the_oracle_network(tmp_path):
     json.dump({**full, "resnet_time_scale_shift": "scale_shift"}, open(d / "config.json", "w"))
     with pytest.raises(ValueError, match="resnet_time_scale_shift"):
         UNet2DModel.from_pretrained(str(tmp_path / "b"), subfolder="unet", device="cuda:0")
+
+
+def test_check_checkpoint_tool_on_a_saved_checkpoint(tmp_path):
+    """tools/check_checkpoint.py -- the one-command check INTEGRATION.md gives for a REAL diffusers checkpoint
+    (google/ddpm-celebahq-256 loads at delete_celeb.py:181-186; none is available here: no network) -- run on a checkpoint
+    that `save_pretrained` wrote in the diffusers layout: strict load, forward and dual backward against the fp32 network."""
+    import subprocess
+    import sys
+    import os
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.model import UNet2DModel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = UNet2DConfig(sample_size=32, in_channels=3, out_channels=3, block_out_channels=(64, 128),
+                       down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"),
+                       layers_per_block=1, attention_head_dim=None, norm_num_groups=32, norm_eps=1e-6,
+                       downsample_padding=0, flip_sin_to_cos=False, freq_shift=1)
+    m = UNet2DModel(cfg, device="cuda:0")
+    m.engine.init_random(seed=9)
+    m.save_pretrained(str(tmp_path / "ckpt" / "unet"))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_checkpoint.py"), str(tmp_path / "ckpt"), "--subfolder", "unet"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "checkpoint OK" in r.stdout, r.stdout
