@@ -73,7 +73,8 @@ def main():
     names = [n for n, _ in net.named_parameters()]
     params = [p for _, p in net.named_parameters()]
     grads = [torch.autograd.grad(ref, params, c_, retain_graph=(i == 0)) for i, c_ in enumerate((cx, ca))]
-    worst = assert_grads_match(eng, names, grads, dev)
+    # (a mathematically zero gradient -- attention key biases -- must be negligible: 1e-5 of the total; bf16 noise on small nets is ~2e-6)
+    worst = assert_grads_match(eng, names, grads, dev, zero_tol=1e-5)
     print(f"dual backward: worst per-tensor gradient cosine {worst[0]:.5f} at {worst[1]} (bar 0.99) -- checkpoint OK")
 
 
