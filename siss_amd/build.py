@@ -51,6 +51,9 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
         return cmd[-1]
 
+    for f in os.listdir(OBJ):                                  # objects of sources that no longer exist (moved to tools/probes/)
+        if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
+            os.remove(os.path.join(OBJ, f))
     if jobs:
         with ThreadPoolExecutor(max_workers=4) as ex:
             for done in ex.map(run, jobs):
