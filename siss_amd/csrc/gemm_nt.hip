@@ -349,7 +349,8 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
                      const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
                      int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream,
                      float* qstats = nullptr, int* qstats_written = nullptr, int d2s = 0, const void* A2 = nullptr, long lda2 = 0,
-                     const void* W2 = nullptr, int K2 = 0, const float* bias2 = nullptr) {
+                     const void* W2 = nullptr, int K2 = 0, const float* bias2 = nullptr, const void* Wx = nullptr, void* Cx = nullptr,
+                     long ldcx = 0, int Nx = 0) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
     if (qstats_written) *qstats_written = 0;
     SISS_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % BK == 0 && npanels >= 1 && npanels <= kMaxPanels);
@@ -367,6 +368,9 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     p.ksplit = 1; p.slab = nullptr; p.qstats = nullptr; p.d2s = d2s;
     p.A2 = (const bf16_t*)A2; p.W2 = (const bf16_t*)W2; p.bias2 = A2 ? bias2 : nullptr; p.lda2 = lda2; p.K2 = A2 ? K2 : 0;
+    p.Wx = (const bf16_t*)Wx; p.Cx = (bf16_t*)Cx; p.ldcx = ldcx; p.Nx = Cx ? Nx : 0;
+    SISS_CHECK_ARG(!Cx || (Wx && Nx > 0 && Nx % BN == 0 && ldcx % 8 == 0 && ldcx >= Nx && npanels == 9 && !qstats && !A2 &&
+                           ((uintptr_t)Wx | (uintptr_t)Cx) % 16 == 0));
     SISS_CHECK_ARG(!A2 || (W2 && K2 > 0 && K2 % BK == 0 && lda2 % 8 == 0 && lda2 >= K2 && !R && npanels == 9 &&
                            ((uintptr_t)A2 | (uintptr_t)W2) % 16 == 0 && (!bias2 || (uintptr_t)bias2 % 16 == 0)));
 #ifdef SISS_PROBE
@@ -394,7 +398,8 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
         constexpr long kC3pMinTiles = 256;
         const long tiles = (long)cdiv(M, 128) * cdiv(N, BN);
         const bool fits32 = (long)M * ldc * 2 < (1L << 32) && (!R || (long)M * ldr * 2 < (1L << 32)) && (long)(M + 2) * lda * 2 < (1L << 32) &&
-                            (long)N * Kp * 2 < (1L << 32) && (!A2 || ((long)(M + 2) * lda2 * 2 < (1L << 32) && (long)N * K2 * 2 < (1L << 32)));
+                            (long)N * Kp * 2 < (1L << 32) && (!A2 || ((long)(M + 2) * lda2 * 2 < (1L << 32) && (long)N * K2 * 2 < (1L << 32))) &&
+                            (!Cx || ((long)M * ldcx * 2 < (1L << 32) && (long)Nx * Kp * 2 < (1L << 32) && Kp >= 2 * BK));
         if (conv3 && N % BN == 0 && rows_per_image >= 256 && (Wp == 0 || Wp >= 8) && tiles >= kC3pMinTiles && fits32) {
             if (qstats && Hp > 0 && ((uintptr_t)qstats % 16) == 0) {
                 p.qstats = qstats;                          // only the persistent kernel forms them; the caller is told
@@ -403,7 +408,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
             return siss_launch_gemm_nt_c3p(&p, stream);
         }
     }
-    SISS_CHECK_ARG(!A2);                                       // only the persistent kernel folds a shortcut in (callers ask siss_conv3x3_sc_takes first)
+    SISS_CHECK_ARG(!A2 && !Cx);                                // only the persistent kernel folds a shortcut in (callers ask siss_conv3x3_*_takes first)
     // Large grids: single-buffered blocks at 4 per CU (latency hidden by the other three) measured 10-15 %
     // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;
@@ -479,6 +484,25 @@ int siss_conv3x3_sc(const void* A, long lda, const void* W, void* C, long ldc, c
     SISS_CHECK_ARG(A2 && W2 && siss_conv3x3_sc_takes(M, N, Kp, K2, rows_per_image, Wp, lda, ldc, lda2));
     return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, nullptr, 0, M, N, Kp, 9, shifts, coffs, rows_per_image, Hp, Wp,
                             1.0f, 1, 0, 0, 0, nullptr, 0, stream, qstats, written, 0, A2, lda2, W2, K2, bias2);
+}
+
+// The backward of that block tail in ONE product: conv2's dgrad  C = sum_taps A(shifted) . W  (nine panels, W = the transposed tap copies)
+// AND the shortcut's dgrad  Cx[r, n] = sum_k A[r, k] . Wx[n][k]  (Wx [Nx][Kp] bf16 = the transposed 1x1 weight, Nx % 128 == 0, Cx rows of
+// ldcx elements, halo rows zeroed) -- both read the same cotangent A.  On its own the 1x1 product is HBM-bound (it writes Nx / N times
+// the 3x3 product's output); here it runs as extra column tiles of the persistent kernel.  R (optional) is added to C only.
+// siss_conv3x3_dgrad_sc_takes: whether a product of this shape lands on that kernel (else: two siss_gemm_nt calls).
+int siss_conv3x3_dgrad_sc_takes(int M, int N, int Kp, int Nx, int rows_per_image, int Wp, long lda, long ldc, long ldcx) {
+    if (M <= 0 || N <= 0 || Kp < 2 * BK || Kp % BK || Nx <= 0 || Nx % BN || N % BN || rows_per_image < 256 || (Wp != 0 && Wp < 8)) return 0;
+    if ((long)cdiv(M, 128) * cdiv(N, BN) < 256) return 0;
+    return (long)M * ldc * 2 < (1L << 32) && (long)(M + 2) * lda * 2 < (1L << 32) && (long)N * Kp * 2 < (1L << 32) &&
+           (long)M * ldcx * 2 < (1L << 32) && (long)Nx * Kp * 2 < (1L << 32);
+}
+int siss_conv3x3_dgrad_sc(const void* A, long lda, const void* W, void* C, long ldc, const void* R, long ldr, const void* Wx, void* Cx,
+                          long ldcx, int Nx, int M, int N, int Kp, const int* shifts, const int* coffs, int rows_per_image, int Hp,
+                          int Wp, void* stream) {
+    SISS_CHECK_ARG(Wx && Cx && siss_conv3x3_dgrad_sc_takes(M, N, Kp, Nx, rows_per_image, Wp, lda, ldc, ldcx));
+    return gemm_nt_dispatch(A, lda, W, C, ldc, nullptr, nullptr, N, R, ldr, M, N, Kp, 9, shifts, coffs, rows_per_image, Hp, Wp,
+                            1.0f, 1, 0, 0, 0, nullptr, 0, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, Wx, Cx, ldcx, Nx);
 }
 
 // siss_gemm_nt whose rows are the pixels of ONE space-to-depth plane (plane = 2 py + px) of a stride-2 convolution's input: the

@@ -28,6 +28,12 @@
 // tile in the centre tap's slot; the consumers run the 4 centre-tap blocks of 16 MFMAs.  The 1x1 product's own launch (an
 // HBM-bound GEMM: 173 us at 256 x 256, 256 -> 128 channels), its output tensor and the residual read of the 3x3 launch's store
 // path (+ 50 us) disappear for K2 / (9 Kp) more MFMA work.
+//
+// Second product over the same A (NTParams::Cx): the backward of that shortcut.  conv2's dgrad and conv_shortcut's dgrad both read
+// the block's output cotangent; the 1x1 one is HBM-bound on its own (it writes a 256-channel tensor for 1/9 of the MFMAs per
+// column: 396 us at 256 x 256).  Here it rides as Nx / 128 more column tiles per row tile ("x tiles": Kp / 64 centre-tap groups,
+// weights Wx, output Cx with its own row stride) between the 3x3 tiles of the same rows -- its stores drain while the neighbours' MFMAs
+// run, and A is fetched from HBM once for both.
 #include "nt_common.h"
 #include <type_traits>
 
@@ -68,15 +74,21 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     TileMap tm;
     tm.nb = gridDim.x; tm.per = tm.nb >> 3; tm.b_lo = blockIdx.x & 7; tm.b_hi = blockIdx.x >> 3;
-    tm.tiles_n = p.N / BN;
+    const int tiles_nm = p.N / BN;                         // column tiles of the 3x3 product ...
+    const int tiles_nx = p.Cx ? p.Nx / BN : 0;             // ... and of the optional second (1x1, centre-tap) product over the same A
+    tm.tiles_n = tiles_nm + tiles_nx;
     tm.ntiles = ((p.M + P_VALID - 1) / P_VALID) * tm.tiles_n;
     int count = 0;
     while (tm.tile(count) < tm.ntiles) ++count;
     const int kchunks = p.Kp / BK;
     const int k2chunks = p.A2 ? p.K2 / BK : 0;             // folded 1x1 shortcut: more K-groups per tile, centre tap only
     const int g3 = 3 * kchunks;                            // groups of the 3x3 filter per tile
-    const int gpt = g3 + k2chunks;                         // groups per tile
-    const int G = count * gpt;
+    const int gpt = g3 + k2chunks;                         // groups per tile of the 3x3 product (an x tile has kchunks groups)
+    // class of a tile: x = it belongs to the second product; groups it runs
+    auto tile_is_x = [&](int k) { return tm.tile(k) % tm.tiles_n >= tiles_nm; };
+    auto tile_groups = [&](int k) { return tile_is_x(k) ? kchunks : gpt; };
+    int G = 0;
+    for (int k = 0; k < count; ++k) G += tile_groups(k);
     if (G == 0) return;
     const long wtap = (long)p.N * p.Kp;
     constexpr int SROW = 144;                              // parked tile: 128 B of channels + 16 B pad per row
@@ -95,9 +107,12 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         // pointer form cost a v_lshl_add_u64 and an m0 save / restore per piece, on a SIMD they share with an MFMA wave.
         // (m0 is a reserved register the compiler sets itself before each of its own uses; nothing here relies on its value.)
         unsigned aoffs[8], woffs[4], aoffs2[8], woffs2[4];
+        bool issue_x = false;                              // the tile whose groups are being ISSUED belongs to the second product
         auto set_tile = [&](int k) {
             const int t = tm.tile(k);
-            const int m0 = (t / tm.tiles_n) * P_VALID, n0 = (t % tm.tiles_n) * BN;
+            const int tn = t % tm.tiles_n;
+            issue_x = tn >= tiles_nm;
+            const int m0 = (t / tm.tiles_n) * P_VALID, n0 = (issue_x ? tn - tiles_nm : tn) * BN;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = (pw * 8 + j) * 8 + prow;
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                 const int row = (pw * 4 + j) * 8 + prow;
                 woffs[j] = (unsigned)(((long)(n0 + row) * p.Kp + ((pc ^ swz3p(row)) << 3)) * 2);
             }
-            if (k2chunks) {                                // (uniform) the shortcut operand: other row strides
+            if (k2chunks && !issue_x) {                    // (uniform) the shortcut operand: other row strides
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int row = (pw * 8 + j) * 8 + prow;
@@ -128,6 +143,19 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         };
         auto issue_group = [&]() {
             const unsigned dst = smem_a + (issued & 1) * P_SLOT;
+            if (issue_x) {
+                // tile of the second product: A at the centre row's shift (the centre tap reads tile row + 1 = the pixel itself),
+                // ONE weight tile of Wx in the centre tap's slot; kchunks groups per tile
+                const bf16_t* abase = p.A + (long)p.shift[3] * p.lda + p.coff[3] + gkc * BK;
+                const bf16_t* wbase = p.Wx + gkc * BK;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dma(aoffs[j], abase, dst + (pw * 8 + j) * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dma(woffs[j], wbase, dst + P_ABYTES + P_WBYTES + (pw * 4 + j) * 1024);
+                ++issued;
+                if (++gkc == kchunks) { gkc = 0; gky = 0; ++gk; if (gk < count) set_tile(gk); }
+                return;
+            }
             if (gky < 3) {
                 const long aoff = (long)p.shift[3 * gky] * p.lda + p.coff[3 * gky] + gkc * BK;
                 const long woff = 3L * gky * wtap + gkc * BK;
@@ -202,7 +230,11 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         auto store_tile = [&](auto has_r, int half) __attribute__((always_inline)) -> int {
             constexpr bool HAS_R = decltype(has_r)::value;
             const int tl = tm.tile(pend);
-            const int m0 = (tl / tm.tiles_n) * P_VALID, n0 = (tl % tm.tiles_n) * BN;
+            const int tn = tl % tm.tiles_n;
+            const bool xt = tn >= tiles_nm;                // (uniform) a tile of the second product: its own output tensor
+            const int m0 = (tl / tm.tiles_n) * P_VALID, n0 = (xt ? tn - tiles_nm : tn) * BN;
+            char* const cbase = reinterpret_cast<char*>(xt ? p.Cx : p.C);
+            const unsigned ldc = (unsigned)(xt ? p.ldcx : p.ldc);
             const int img0 = m0 / rpi;                     // a 256-row tile spans at most two images (rpi >= 256)
             const int split = (img0 + 1) * rpi;            // first row of the second image
             const bool straddle = m0 + P_BM > split;       // (uniform) the tile's last rows belong to the next image
@@ -211,7 +243,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             // scalar stride per row -- the 64-bit form cost two quarter-rate v_mul_lo_u32 + a v_mad_u64_u32 per stored row in
             // waves that share their SIMD with an MFMA wave.  (siss_launch_gemm_nt_c3p checks that C and R span < 4 GiB.)
             const unsigned row0 = (unsigned)(m0 + wm * 128 + half * 64 + prow);
-            const unsigned coff0 = (row0 * (unsigned)p.ldc + (unsigned)ccol) * 2u, cstep = (unsigned)p.ldc * 16u;
+            const unsigned coff0 = (row0 * ldc + (unsigned)ccol) * 2u, cstep = ldc * 16u;
             u32x4_t res[HAS_R ? 8 : 1];
             if constexpr (HAS_R) {
                 // all residual loads, then ONE wait, before the first store: vmcnt counts loads and stores in one
@@ -255,7 +287,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                 if (px >= wrap) { px -= wrap; ++py; }
                 if (py > ylast) py = 0;
                 if (row >= P_VALID || r >= p.M) continue;
-                *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(p.C) + (coff0 + i8 * cstep)) = o;
+                *reinterpret_cast<u32x4_t*>(cbase + (coff0 + i8 * cstep)) = o;
                 if constexpr (QS) {
                     // statistics of the STORED values (halo rows are zero and add nothing) straight from the packed bf16 pairs:
                     // v_dot2c_f32_bf16 (acc += a.lo * b.lo + a.hi * b.hi) against (1, 1) gives the sum, against itself the
@@ -294,43 +326,45 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             return exact ? 8 : 0;
         };
 
-        int gin = 0;
+        int gin = 0, ck = 0, cgpt = tile_groups(0);        // consumption cursor: group within tile ck, which has cgpt groups
         set_tile(0);
         issue_group();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        auto store_half = [&]() __attribute__((always_inline)) -> int {
+            int counted = 0;
+            if (!C3P_ABLATE(1)) {
+                if (p.R && !tile_is_x(pend)) store_tile(std::true_type{}, phalf);      // its wait retired the DMA above as well
+                else counted = store_tile(std::false_type{}, phalf);
+            }
+            if (++phalf == 2) { phalf = 0; pend = -1; }
+            return counted;
+        };
         for (int g = 0; g < G; ++g) {
             c3p_barrier();                                 // #g: group g has landed; consumers are done with group g-1
             if (g + 1 < G) issue_group();                  // -> slot (g+1)&1: last read by group g-1 / parked tile already in `ov`
             int counted = 0;
-            if (pend >= 0) {
-                if (!C3P_ABLATE(1)) {
-                    if (p.R) store_tile(std::true_type{}, phalf);      // its wait retired the DMA above as well
-                    else counted = store_tile(std::false_type{}, phalf);
-                }
-                if (++phalf == 2) { phalf = 0; pend = -1; }
-            }
+            if (pend >= 0) counted = store_half();
             // the DMA of group g+1 must have landed before barrier #g+1; the younger stores may stay in flight
             if (counted == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (counted == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (++gin == gpt) {                            // g was the last group of its tile
+            if (++gin == cgpt) {                           // g was the last group of its tile
                 gin = 0;
                 c3p_barrier();                             // E : every consumer has finished reading slot g&1
                 c3p_barrier();                             // E2: the consumers have parked the tile there
+                // (a tile of fewer than two groups would arrive here with a half of the previous tile still in `ov`)
+                while (pend >= 0) store_half();
                 const char* st = smem + (g & 1) * P_SLOT + pw * (128 * SROW);
 #pragma unroll
                 for (int it = 0; it < 16; ++it)
                     ov[it] = *reinterpret_cast<const u32x4_t*>(st + (it * 8 + prow) * SROW + pc * 16);
 #pragma unroll
                 for (int it = 0; it < 16; ++it) asm volatile("" : "+v"(ov[it]));      // in registers before barrier #g+1
-                pend = g / gpt;
+                pend = ck;
+                if (++ck < count) cgpt = tile_groups(ck);
             }
         }
-        if (pend >= 0 && !C3P_ABLATE(1)) {
-            for (; phalf < 2; ++phalf) {
-                if (p.R) store_tile(std::true_type{}, phalf); else store_tile(std::false_type{}, phalf);
-            }
-        }
+        while (pend >= 0 && !C3P_ABLATE(1)) store_half();
         return;
     }
 
@@ -393,9 +427,12 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
                 }
             }
         };
-        // (two loops, not one loop with a branch: the accumulators must not meet at a merge point of two code paths)
-        for (int g = 0; g < g3; ++g, ++gg) run_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
-        for (int g = g3; g < gpt; ++g, ++gg) run_group(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});   // shortcut: centre tap
+        // (separate loops, not one loop with a branch: the accumulators must not meet at a merge point of two code paths; a tile
+        // of the second product runs the last loop only: its kchunks centre-tap groups)
+        const bool xtile = tile_is_x(k);
+        const int n3 = xtile ? 0 : g3, nc = xtile ? kchunks : k2chunks;
+        for (int g = 0; g < n3; ++g, ++gg) run_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
+        for (int g = 0; g < nc; ++g, ++gg) run_group(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});   // centre tap
         C3P_TICK(0);
 
         // ---- consumer half of the epilogue: alpha, bias and the per-image row bias in f32, ONE rounding to bf16
@@ -403,7 +440,8 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         // the tile's last group as four wave-private 128 x 64 images.
         // acc[i][j][r] = channel n0 + wn*64 + i*16 + fq*4 + r of row m0 + wm*128 + j*16 + frow.
         const int tl = tm.tile(k);
-        const int m0 = (tl / tm.tiles_n) * P_VALID, n0 = (tl % tm.tiles_n) * BN;
+        const int tnk = tl % tm.tiles_n;
+        const int m0 = (tl / tm.tiles_n) * P_VALID, n0 = (xtile ? tnk - tiles_nm : tnk) * BN;
         const int img0 = m0 / rpi;
         const int img1 = img0 + 1 < last_img ? img0 + 1 : last_img;
         const int split = (img0 + 1) * rpi;
@@ -412,15 +450,15 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
         f32x4_t b0[4], b1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            b0[i] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + ncol + i * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (p.bias2) {
+            b0[i] = (p.bias && !xtile) ? *reinterpret_cast<const f32x4_t*>(p.bias + ncol + i * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (p.bias2 && !xtile) {
                 const f32x4_t s2 = *reinterpret_cast<const f32x4_t*>(p.bias2 + ncol + i * 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b0[i][e] += s2[e];
             }
             b1[i] = b0[i];
         }
-        if (p.rowbias) {
+        if (p.rowbias && !xtile) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4_t r0 = *reinterpret_cast<const f32x4_t*>(p.rowbias + (long)img0 * p.ldrb + ncol + i * 16);
@@ -448,7 +486,7 @@ __global__ __launch_bounds__(P_THREADS, 1) void gemm_nt_c3p_kernel(const NTParam
             };
             // almost every tile lies inside one image: no per-row select between the two images' row biases; a product without
             // bias, row bias and scale (every dgrad launch) only rounds its accumulators
-            if (!p.bias && !p.bias2 && !p.rowbias && p.alpha == 1.f) {
+            if (xtile || (!p.bias && !p.bias2 && !p.rowbias && p.alpha == 1.f)) {          // (the second product: plain accumulators)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -478,6 +516,7 @@ int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     const bool qs = p.qstats != nullptr;
     // 32-bit byte offsets in the store path (gemm_nt_dispatch sends larger tensors to the one-tile-per-block kernels)
     if ((long)p.M * p.ldc * 2 >= (1L << 32) || (p.R && (long)p.M * p.ldr * 2 >= (1L << 32))) return SISS_ERR_ARG;
+    if (p.Cx && ((long)p.M * p.ldcx * 2 >= (1L << 32) || p.Nx % BN || p.Kp < 2 * BK || (long)p.Nx * p.Kp * 2 >= (1L << 32))) return SISS_ERR_ARG;
     using kern_t = void (*)(const NTParams);
     const kern_t kern = qs ? gemm_nt_c3p_kernel<true> : gemm_nt_c3p_kernel<false>;
     if (siss_ensure_smem((const void*)kern, P_SMEM, attr_set[qs ? 1 : 0]) != SISS_OK) return SISS_ERR_LAUNCH;
@@ -486,7 +525,7 @@ int siss_launch_gemm_nt_c3p(const void* params, void* stream) {
     // chip: 550 tiles are 3 rounds on 256 CUs (38 CUs with three tiles, 218 with two) and exactly 3 on 184 -- the idle
     // CUs' power goes to the busy ones (measured: the mid-size grids run 4 % faster on 208 CUs than on 256).
     const int maxb = nt_c3p_blocks();
-    const long ntiles = (long)((p.M + P_VALID - 1) / P_VALID) * (p.N / BN);
+    const long ntiles = (long)((p.M + P_VALID - 1) / P_VALID) * (p.N / BN + (p.Cx ? p.Nx / BN : 0));
     const long rounds = (ntiles + maxb - 1) / maxb;
     int nb = (int)((ntiles + rounds - 1) / rounds);
     nb = (nb + 7) & ~7;

@@ -34,6 +34,13 @@ struct NTParams {
     const bf16_t* A2; const bf16_t* W2; const float* bias2;
     long lda2;
     int K2;
+    // Optional SECOND product over the same A (persistent 3x3 kernel only; a resnet's conv_shortcut dgrad beside conv2's dgrad -- both
+    // read the block's output cotangent):  Cx[r, n] = sum_k A[r, k] . Wx[n][k]  (Nx % 128 == 0 columns, row stride ldcx, halo rows
+    // zeroed like C's).  It runs as Nx / 128 more column tiles per row tile, centre tap only: an HBM-bound product (it writes
+    // Nx / N times the 3x3 product's output for 1/9 of its MFMAs per column) hidden inside an MFMA-bound kernel.
+    const bf16_t* Wx; bf16_t* Cx;
+    long ldcx;
+    int Nx;
     int shift[kMaxPanels];
     int coff[kMaxPanels];
 };

@@ -35,6 +35,8 @@ SIGNATURES = {
     "siss_gemm_nt_qstats": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, P, IP, P],
     "siss_conv3x3_sc": [P, L, P, P, L, P, P, L, P, L, P, I, P, I, I, I, IP, IP, I, I, I, P, IP, P],
     "siss_conv3x3_sc_takes": [I, I, I, I, I, I, L, L, L],
+    "siss_conv3x3_dgrad_sc": [P, L, P, P, L, P, L, P, P, L, I, I, I, I, IP, IP, I, I, I, P],
+    "siss_conv3x3_dgrad_sc_takes": [I, I, I, I, I, I, L, L, L],
     "siss_conv_qstats_words": [L, I],
     "siss_gemm_nt_d2s": [P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, I, P],
     "siss_gemm_nt_set_workspace": [P, L],
@@ -198,6 +200,11 @@ def _work(name, a):
         if hp > 2 and wp > 2 and M % rpi == 0:
             M = (M // rpi) * (hp - 2) * (wp - 2)
         return 2.0 * M * a[14] * (9 * a[15] + a[11])
+    if name == "siss_conv3x3_dgrad_sc":   # 2 * M * Kp * (9 N + Nx): the 3x3 dgrad and the 1x1 shortcut dgrad over the same cotangent
+        M, rpi, hp, wp = a[11], a[16], a[17], a[18]
+        if hp > 2 and wp > 2 and M % rpi == 0:
+            M = (M // rpi) * (hp - 2) * (wp - 2)
+        return 2.0 * M * a[13] * (9 * a[12] + a[10])
     if name == "siss_gemm_tn":      # 2 * N * C * npanels * nsets * rows
         rows, rps, rb = a[15] - a[14], a[12], a[14]
         wp = rb - 1                 # padded layouts reduce over rows [wp + 1, rows_per_set - (wp + 1)); images are square
@@ -245,6 +252,8 @@ def _shape_key(name, a):
         return ("M", a[10], "N", a[11], "K", a[12], "panels", a[13], "batch", a[20])
     if name == "siss_conv3x3_sc":
         return ("M", a[13], "N", a[14], "K", a[15], "panels", 9, "+1x1 K", a[11])
+    if name == "siss_conv3x3_dgrad_sc":
+        return ("M", a[11], "N", a[12], "K", a[13], "panels", 9, "+1x1 N", a[10])
     if name == "siss_gemm_tn":
         return ("N", a[6], "C", a[7], "panels", a[8], "sets", a[11], "rows", a[15] - a[14], "splits", a[16])
     if name in ("siss_groupnorm_fwd", "siss_groupnorm_fwd_ld"):
@@ -276,7 +285,7 @@ def kernel_symbol(name, a):
                 and triples(a[14], a[15], 9)):
             return "gemm_nt_c3p_kernel"
         return "gemm_nt_kernel"
-    if name == "siss_conv3x3_sc":
+    if name in ("siss_conv3x3_sc", "siss_conv3x3_dgrad_sc"):
         return "gemm_nt_c3p_kernel"
     if name == "siss_gemm_nt_mulsub":
         return "gemm_nt_kernel"
@@ -311,7 +320,7 @@ def call(name, *args):
         base = name[:-3] if name.endswith("_ld") else name          # row-stride variants count as their plain form
         if base.endswith("_merged"):
             base = base[:-7]
-        if base == "siss_conv3x3_sc":
+        if base in ("siss_conv3x3_sc", "siss_conv3x3_dgrad_sc"):
             base = "siss_gemm_nt"
         PROF.append((base, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args), hbm_bytes(name, args)))
     else:

@@ -125,6 +125,25 @@ def conv_dgrad(dy: Act, wT_bf16, out: Act, residual: Act = None, ksize=3):
     return out
 
 
+def conv3x3_dgrad_sc_takes(dy: Act, ci, out: Act, out_x: Act):
+    """Whether conv_dgrad_sc can run the 1x1 shortcut's dgrad (-> out_x) inside the 3x3 dgrad (-> out) over the same cotangent."""
+    return bool(lib.query("siss_conv3x3_dgrad_sc_takes", dy.rows, ci, dy.c, out_x.c, dy.rows_per_image, dy.wp, dy.c,
+                          getattr(out, "ld", out.c), getattr(out_x, "ld", out_x.c)))
+
+
+def conv_dgrad_sc(dy: Act, wT_bf16, out: Act, wT_sc_bf16, out_x: Act, residual: Act = None):
+    """out = conv3x3^T(dy) (+ residual)  AND  out_x = conv1x1^T(dy)  in ONE product (siss_conv3x3_dgrad_sc): the backward of a
+    resnet's conv2 + conv_shortcut tail; wT_sc_bf16 [Cin_x][Cout] = the transposed shortcut weight."""
+    t, ci, co = wT_bf16.shape
+    assert t == 9 and co == dy.c and ci == out.c and tuple(wT_sc_bf16.shape[-2:]) == (out_x.c, co)
+    shifts, coffs = conv3x3_panels(dy.wp, co)
+    lib.call("siss_conv3x3_dgrad_sc", dy.data, dy.c, wT_bf16, out.data, getattr(out, "ld", out.c),
+             residual.data if residual is not None else None, residual.c if residual is not None else 0, wT_sc_bf16, out_x.data,
+             getattr(out_x, "ld", out_x.c), out_x.c, dy.rows, ci, co, lib.int_array(shifts), lib.int_array(coffs),
+             dy.rows_per_image, dy.hp, dy.wp)
+    return out, out_x
+
+
 def _nsplits(tiles, npanels, nsets, rows, fused3):
     """Split-K factor of the wgrad GEMM: 0 = let siss_gemm_tn choose (kernel variant + split count from its cost
     model: K-steps per block vs the float-atomic traffic every extra split adds; gemm_tn.hip)."""

@@ -546,7 +546,9 @@ class UNetEngine:
             else:
                 ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
 
-        def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None):
+        def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None, sc_dgrad=None):
+            """sc_dgrad = (pre2, out2): also form the dgrad of the 1x1 convolution `pre2` over the SAME cotangent into out2 -- inside
+            this 3x3 dgrad when its kernel takes it (returns (dx, True)), else not at all (returns (dx, False): the caller runs it)."""
             dW = ps.grads[self.gbase:, ps.specs[pre + ".weight"].off:]
             # the bias gradient (column sums of dy) rides along in the wgrad GEMM as one more product
             self._wgrad(dy, x, dW, co, x.c, ksize, dbias=ps.g(pre + ".bias", self.gbase) if bias_grad else None,
@@ -556,6 +558,15 @@ class UNetEngine:
             if accum is not None:
                 self._wsync(accum)
             dx = accum if accum is not None else self._get(dy.n, x.h, x.w, x.c)
+            if sc_dgrad is not None:
+                pre2, out2 = sc_dgrad
+                # (not with more than twice the 3x3 product's columns: every x tile pays a tile's fixed epilogue for a third of its
+                # MFMAs -- measured at 128 x 128, 128 -> 128 with a 384-channel shortcut: 424 us folded against 129 + 149 us apart)
+                if self.fold_shortcut and ksize == 3 and out2.c <= 2 * x.c and ops.conv3x3_dgrad_sc_takes(dy, x.c, dx, out2):
+                    ops.conv_dgrad_sc(dy, self.wT[pre + ".weight"], dx, self.wT[pre2 + ".weight"][0], out2, residual=accum)
+                    return dx, True
+                ops.conv_dgrad(dy, self.wT[pre + ".weight"], dx, residual=accum, ksize=ksize)
+                return dx, False
             ops.conv_dgrad(dy, self.wT[pre + ".weight"], dx, residual=accum, ksize=ksize)
             return dx
         return y, bwd
@@ -653,8 +664,15 @@ class UNetEngine:
             nb = self.nb
             dout = self._take(out)
             gb = self.gbase
-            # conv2 (its bias gradient equals the shortcut conv's bias gradient: same pre-activation)
-            da2 = c2_b(dout, bias_grad2=ps.g(pre + ".conv_shortcut.bias", gb) if has_sc else None)
+            # conv2 (its bias gradient equals the shortcut conv's bias gradient: same pre-activation).  With a shortcut, its dgrad
+            # (dout . W_sc, HBM-bound on its own) rides in conv2's 3x3 dgrad over the same cotangent where that kernel takes it
+            sc_folded = False
+            if has_sc:
+                acc_sc = self._get(nb, x.h, x.w, x.c)
+                da2, sc_folded = c2_b(dout, bias_grad2=ps.g(pre + ".conv_shortcut.bias", gb),
+                                      sc_dgrad=(pre + ".conv_shortcut", acc_sc))
+            else:
+                da2 = c2_b(dout)
             # column sums of dh = cotangent of time_emb_proj's output (and of conv1's bias); the weight
             # gradients of ALL time_emb_proj layers are formed in one batched launch at the end
             dh = gn2_b(da2, colsum=self.dtp_all[:, col0:], accum=None, colsum_ld=self.temb_ntot)
@@ -663,7 +681,12 @@ class UNetEngine:
             self._put(dh)
             prior = self.gmap.pop(id(x), None)          # cotangent x already received from another consumer
             if has_sc:
-                acc = sc_b(dout, bias_grad=False)
+                if sc_folded:
+                    sc_b(dout, bias_grad=False, need_dx=False)      # the shortcut's weight gradient only
+                    acc = acc_sc
+                else:
+                    self._put(acc_sc)
+                    acc = sc_b(dout, bias_grad=False)
                 self._put(dout)
             else:
                 acc = dout

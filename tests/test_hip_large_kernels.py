@@ -182,6 +182,51 @@ def test_conv3x3_with_the_1x1_shortcut_folded_in(dev, n, h, w, ci, co, c2, ld2, 
         torch.testing.assert_close(rstd.cpu(), (st.var(-1, unbiased=False) + 1e-6).rsqrt().cpu(), rtol=1e-3, atol=1e-5)
 
 
+# (n [cotangent images], h, w, cout of both convs = channels of the cotangent, cin of the 3x3, cin of the 1x1, residual on the 3x3 output)
+SC_DGRAD_CASES = [
+    (2, 128, 128, 128, 128, 256, False),     # up-block shape: conv2 128 -> 128, shortcut 256 -> 128; a tile crosses the image seam
+    (2, 256, 256, 128, 128, 256, True),      # batch-2 cotangent at 256 x 256: several rounds of mixed tiles; running cotangent added to dx
+    (4, 64, 64, 256, 256, 128, False),       # down-block shape: K = 256 (four centre-tap groups per x tile), two + one column tiles
+    (8, 64, 64, 128, 128, 384, True),        # Nx = 384: three x tiles per row tile
+]
+
+
+@pytest.mark.parametrize("n,h,w,co,ci,cx,res", SC_DGRAD_CASES)
+def test_conv3x3_dgrad_with_the_shortcut_dgrad_folded_in(dev, n, h, w, co, ci, cx, res):
+    """siss_conv3x3_dgrad_sc: dx = conv3x3^T(dy; W) (+ r) and dx_sc = conv1x1^T(dy; W_sc) from ONE launch of the persistent kernel
+    (the backward of ResnetBlock2D's conv2 + conv_shortcut tail, differentiated at delete_celeb.py:691,:702) against torch
+    autograd on the same bf16-rounded operands; both outputs' halo must be written as zero."""
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act
+    g = torch.Generator().manual_seed(n * 10 + h + cx)
+    dy = _bf(torch.randn(n, co, h, w, generator=g))
+    wt = _bf(torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3 * ci ** 0.5)))
+    ws = _bf(torch.randn(co, cx, 1, 1, generator=g) * (1.0 / cx ** 0.5))
+    r = _bf(torch.randn(n, ci, h, w, generator=g))
+    x3 = torch.zeros(n, ci, h, w, requires_grad=True)
+    x1 = torch.zeros(n, cx, h, w, requires_grad=True)
+    dx_ref = torch.autograd.grad(F.conv2d(x3, wt, padding=1), x3, dy)[0] + (r if res else 0)
+    dxs_ref = torch.autograd.grad(F.conv2d(x1, ws), x1, dy)[0]
+
+    dya = Act.from_nchw(dy, dev)
+    wn = ops.conv_w_to_native(wt).to(dev)
+    wsn = ws.view(1, co, cx).to(dev)
+    wT, wsT = ops.dgrad_weight(wn), ops.dgrad_weight(wsn)[0]                # [9][ci][co], [cx][co]
+    dx = Act.from_nchw(r, dev) if res else Act(n, h, w, ci, dev)
+    dxs = Act(n, h, w, cx, dev)
+    for a in ((dxs,) if res else (dx, dxs)):
+        a.buf.fill_(5.0); a.buf[: a.guard * a.c] = 0; a.buf[-a.guard * a.c:] = 0      # poison: the kernel writes the zero halo itself
+    assert ops.conv3x3_dgrad_sc_takes(dya, ci, dx, dxs)
+    lib.dispatch_counts(reset=True)
+    ops.conv_dgrad_sc(dya, wT, dx, wsT, dxs, residual=dx if res else None)
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    assert cnt["gemm_nt_c3p_kernel"] == 1 and cnt["gemm_nt_kernel"] == 0, cnt
+    assert dx.halo_is_zero() and dxs.halo_is_zero()
+    _close(dx.to_nchw().cpu(), dx_ref, 1e-2, "3x3 dgrad")
+    _close(dxs.to_nchw().cpu(), dxs_ref, 1e-2, "1x1 shortcut dgrad")
+
+
 def test_conv3x3_sc_is_refused_where_the_persistent_kernel_is_not_taken(dev):
     from siss_amd import lib, ops
     from siss_amd.layout import Act

@@ -550,6 +550,8 @@ def test_folded_shortcut_equals_the_separate_1x1_product():
         outs[fold] = (pred, eng.ps.grads.clone(), calls)
     # the two 128 x 128 up resnets (256 -> 128 channels) fold; the 64 x 64 / 32 x 32 ones are below the persistent kernel's grid size
     assert outs[True][2].count("siss_conv3x3_sc") == 2 and outs[False][2].count("siss_conv3x3_sc") == 0
+    # ... and so do their backward tails: the shortcut's dgrad rides in conv2's 3x3 dgrad over the same cotangent
+    assert outs[True][2].count("siss_conv3x3_dgrad_sc") == 2 and outs[False][2].count("siss_conv3x3_dgrad_sc") == 0
     pa, pb = outs[True][0], outs[False][0]
     assert float((pa - pb).abs().max()) <= 1e-2 * float(pb.abs().max())
     for s in range(2):
