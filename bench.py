@@ -349,12 +349,19 @@ def main():
         ksym = {}
         hbm = {}
         dom_split = {}
+        dom_kind = {}
         for name, s, e, work, shape, sym, nbytes in prof:
             dt_ms = s.elapsed_time(e)
             if sym == "gemm_nt_c3p_kernel":      # the same kernel on the large grids it was built for vs the mid-size layers
                 sh = dict(zip(shape[::2], shape[1::2]))
                 big = -(-sh["M"] // 128) * -(-sh["N"] // 128) >= 2048
                 b = dom_split.setdefault("grids >= 2048 tiles" if big else "grids < 2048 tiles", [0, 0.0, 0.0])
+                b[0] += 1; b[1] += dt_ms; b[2] += work
+                # ... and the launches that carry a resnet's 1x1 shortcut (forward: extra K-groups; dgrad: extra column tiles -- an
+                # HBM-bound product hidden in the launch) apart from the plain 3x3 ones
+                kind = ("3x3 + folded 1x1 shortcut dgrad (x tiles)" if "+1x1 N" in sh else
+                        "3x3 + folded 1x1 shortcut fprop (K-groups)" if "+1x1 K" in sh else "plain 3x3")
+                b = dom_kind.setdefault(kind, [0, 0.0, 0.0])
                 b[0] += 1; b[1] += dt_ms; b[2] += work
             if nbytes:
                 h = hbm.setdefault(name, [0, 0.0, 0.0])
@@ -380,6 +387,9 @@ def main():
                 **({"by_grid": {k: {"achieved": round(v[2] / (v[1] * 1e-3) / 1e12, 2), "launches_per_step": v[0] // ksteps,
                                     "avg_launch_us": round(v[1] / v[0] * 1e3, 2)} for k, v in sorted(dom_split.items())}}
                    if dom == "gemm_nt_c3p_kernel" and dom_split else {}),
+                **({"by_kind": {k: {"achieved": round(v[2] / (v[1] * 1e-3) / 1e12, 2), "launches_per_step": v[0] // ksteps,
+                                    "avg_launch_us": round(v[1] / v[0] * 1e3, 2)} for k, v in sorted(dom_kind.items())}}
+                   if dom == "gemm_nt_c3p_kernel" and len(dom_kind) > 1 else {}),
                 "share_of_step_kernel_time": round(tms / tot_ms, 3),
                 # the HBM-bound launchers of the step (K1, K5, K10-12), each against the HBM peak:
                 # ALGORITHMIC bytes (operands read once, results written once; lib.hbm_bytes) / summed launch time
