@@ -123,6 +123,60 @@ __device__ __forceinline__ bf16x8_t load_frag_or_zero(const bf16_t* p, bool ok) 
     return ok ? *reinterpret_cast<const bf16x8_t*>(p) : __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
 }
 
+// ---- augmented contraction (backward kernels, head dims with padding: D < D_pad) ----------------------------------------------
+// The per-element arithmetic of the backward is  p = exp2(s c - lse[q]),  dS = p (dP - delta[q]).  Both subtractions are rank-one
+// updates of a product, and the contraction dimension is padded anyway (40 -> 64): with three spare columns of the Q operand set to
+// a bf16 hi / mid / lo split of -lse[q] / c against ONES in the K operand, and two spare columns of the dO operand set to a split of
+// -delta[q] against ones in V, the MFMAs deliver  s - lse / c  and  dP - delta  directly -- two vector instructions per score
+// element gone from loops that are VALU-bound (and the per-tile lse / delta loads of the dK / dV kernel with them).  The products
+// that read the same tiles transposed (dQ, dK, dV) get garbage only in output columns >= D, which are never stored.
+__device__ __forceinline__ uint32_t bf16_bits(float v) { return pack_bf2(v, 0.f) & 0xffffu; }
+__device__ __forceinline__ float bf16_val(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+// v -> (hi, mid, lo) bf16 with hi + mid + lo = v to ~2^-24 relative; nparts = 2 drops lo
+__device__ __forceinline__ u32x4_t split_bf16(float v, int nparts) {
+    const uint32_t h = bf16_bits(v);
+    const float r1 = v - bf16_val(h);
+    const uint32_t m = bf16_bits(r1);
+    const uint32_t l = nparts > 2 ? bf16_bits(r1 - bf16_val(m)) : 0u;
+    return u32x4_t{h | (m << 16), l, 0u, 0u};
+}
+constexpr uint32_t kOne2 = 0x3F803F80u, kOne1 = 0x00003F80u;       // bf16 (1, 1) / (1, 0)
+
+// the tile's chunk `dch` of every row := `val` (the ones of an augmented K / V tile)
+template <int DP>
+__device__ __forceinline__ void tile_set_chunk(TileRegs<DP>& r, int dch, u32x4_t val, int tid) {
+    using F = FA<DP>;
+#pragma unroll
+    for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i) {
+        const int idx = i * kThreadsFA + tid;
+        if (idx - (idx / F::CH) * F::CH == dch) r.v[i] = val;
+    }
+}
+// the tile's chunk `dch` of row r := split(v[r] * mul) (the -lse / c or -delta columns of an augmented Q / dO tile), in two steps: the
+// row values are LOADED with the tile (rowvals_load: the loads join the prefetch in flight under the current tile's products) and
+// converted / placed only when the tile goes to LDS (rowvals_apply) -- converting at load time made every wave wait for its whole
+// prefetch before the current tile's MFMAs (vmcnt retires in order): 5.6 -> 5.8 ms instead of 4.8
+template <int DP> struct RowVals { float v[FA<DP>::CH * kTQ / kThreadsFA]; };
+template <int DP>
+__device__ __forceinline__ void rowvals_load(RowVals<DP>& rv, int dch, const float* __restrict__ vals, int tid) {
+    using F = FA<DP>;
+#pragma unroll
+    for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i) {
+        const int idx = i * kThreadsFA + tid;
+        const int row = idx / F::CH;
+        rv.v[i] = (idx - row * F::CH == dch) ? vals[row] : 0.f;
+    }
+}
+template <int DP>
+__device__ __forceinline__ void rowvals_apply(TileRegs<DP>& r, const RowVals<DP>& rv, int dch, float mul, int nparts, int tid) {
+    using F = FA<DP>;
+#pragma unroll
+    for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i) {
+        const int idx = i * kThreadsFA + tid;
+        if (idx - (idx / F::CH) * F::CH == dch) r.v[i] = split_bf16(rv.v[i] * mul, nparts);
+    }
+}
+
 // ====================================================================================================================
 // forward: O = softmax(scale Q K^T) V, LSE2[q] = log2 sum_k exp2(scale log2e (q.k))   (base-2 log-sum-exp)
 // grid (Sq_pad / 64, B*heads)
@@ -225,7 +279,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
 // backward).  Og != null: delta[q] = <dO[q], O[q]> is formed here, from fragments laid out like Q's, and WRITTEN to `delta`
 // for the dK / dV kernel that follows; Og == null: `delta` is an input.
 // ====================================================================================================================
-template <int DP>
+template <int DP, bool AUG>
 __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                                   long ldk, const bf16_t* __restrict__ V, long ldv,
                                                                   const bf16_t* __restrict__ Og, long ldo,
@@ -270,6 +324,13 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
         dl = delta[z * sh.Sqp + qrow];
     }
     const float lse = LSE2[zf * sh.Sqp + qrow];
+    if constexpr (AUG) {
+        // this lane's row of the Q / dO operands: the pad chunk (columns D .. D+7) carries -lse / c and -delta, split into bf16 parts
+        const u32x4_t lq = split_bf16(-lse / scale_log2, 3), ld = split_bf16(-dl, 2);
+#pragma unroll
+        for (int ks = 0; ks < F::KS; ++ks)
+            if (ks * 4 + (lane >> 4) == dch) { qf[ks] = __builtin_bit_cast(bf16x8_t, lq); dof[ks] = __builtin_bit_cast(bf16x8_t, ld); }
+    }
     f32x4_t dqt[F::DT];
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt) dqt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -280,6 +341,8 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
     tile_load<DP>(vg, ldv, sh.Sk, dch, vr, tid);
     for (int k0 = 0; k0 < Skp; k0 += kTQ) {
         __syncthreads();
+        // (the ones columns are placed when the tile goes to LDS: the prefetched registers are not touched while the loads fly)
+        if constexpr (AUG) { tile_set_chunk<DP>(kr, dch, u32x4_t{kOne2, kOne1, 0u, 0u}, tid); tile_set_chunk<DP>(vr, dch, u32x4_t{kOne2, 0u, 0u, 0u}, tid); }
         tile_store<DP>(kr, ks_, tid);
         tile_store<DP>(vr, vs_, tid);
         __syncthreads();
@@ -301,7 +364,10 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st[sub][r] = fast_exp2(fmaf(st[sub][r], scale_log2, -lse)) * (dp[sub][r] - dl);
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (AUG) st[sub][r] = fast_exp2(st[sub][r] * scale_log2) * dp[sub][r];        // (the MFMAs subtracted lse / c and delta)
+                else st[sub][r] = fast_exp2(fmaf(st[sub][r], scale_log2, -lse)) * (dp[sub][r] - dl);
+            }
         if (k0 + kTQ > valid_k) {
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
@@ -328,7 +394,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
 // backward, dK / dV:  dV = P^T dO,  dK = scale * dS^T Q             grid (Sk_pad / 64, nB*heads)
 // S[q][key] = mfma(Q rows, K rows): a lane keeps ONE key and 4 consecutive queries of each 16-query sub-tile.
 // ====================================================================================================================
-template <int DP>
+template <int DP, bool AUG>
 __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                                     long ldk, const bf16_t* __restrict__ V, long ldv,
                                                                     const bf16_t* __restrict__ dO, long lddo,
@@ -357,6 +423,17 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
         kf[ks] = load_frag_or_zero(K + (bf * sh.Sk + krow) * ldk + col + ks * 32, ok);
         vf[ks] = load_frag_or_zero(V + (bf * sh.Sk + krow) * ldv + col + ks * 32, ok);
     }
+    if constexpr (AUG) {
+        // this lane's key row: ones against the -lse / c (three) and -delta (two) columns of the augmented Q / dO tiles
+#pragma unroll
+        for (int ks = 0; ks < F::KS; ++ks)
+            if (ks * 4 + (lane >> 4) == dch) {
+                kf[ks] = __builtin_bit_cast(bf16x8_t, u32x4_t{kOne2, kOne1, 0u, 0u});
+                vf[ks] = __builtin_bit_cast(bf16x8_t, u32x4_t{kOne2, 0u, 0u, 0u});
+            }
+    }
+    const float key_mask = krow < sh.valid_k ? 1.f : 0.f;
+    const bool any_masked = blockIdx.x * kTQ + kTQ > sh.valid_k;       // (block-uniform) this block holds padded keys
     f32x4_t dkt[F::DT], dvt[F::DT];
 #pragma unroll
     for (int dt = 0; dt < F::DT; ++dt) { dkt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
@@ -364,17 +441,22 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     const bf16_t* dog = dO + bz * sh.Sq * lddo + h * sh.hoff;
     const float* lseg = LSE2 + zf * Sqp;
     const float* dlg = delta + z * Sqp;
+    const float lmul = -1.f / scale_log2;
     TileRegs<DP> qr, dor;
+    RowVals<DP> lrow, drow;
     tile_load<DP>(qg, ldq, sh.Sq, dch, qr, tid);
     tile_load<DP>(dog, lddo, sh.Sq, dch, dor, tid);
+    if constexpr (AUG) { rowvals_load<DP>(lrow, dch, lseg, tid); rowvals_load<DP>(drow, dch, dlg, tid); }
     for (int q0 = 0; q0 < Sqp; q0 += kTQ) {
         __syncthreads();
+        if constexpr (AUG) { rowvals_apply<DP>(qr, lrow, dch, lmul, 3, tid); rowvals_apply<DP>(dor, drow, dch, -1.f, 2, tid); }
         tile_store<DP>(qr, qs_, tid);
         tile_store<DP>(dor, dos_, tid);
         __syncthreads();
         if (q0 + kTQ < Sqp) {
             tile_load<DP>(qg + (long)(q0 + kTQ) * ldq, ldq, sh.Sq - q0 - kTQ, dch, qr, tid);
             tile_load<DP>(dog + (long)(q0 + kTQ) * lddo, lddo, sh.Sq - q0 - kTQ, dch, dor, tid);
+            if constexpr (AUG) { rowvals_load<DP>(lrow, dch, lseg + q0 + kTQ, tid); rowvals_load<DP>(drow, dch, dlg + q0 + kTQ, tid); }
         }
         f32x4_t s[4], dp[4];
 #pragma unroll
@@ -387,18 +469,38 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
             }
         }
         f32x4_t ds[4];
+        if constexpr (AUG) {
+            // s and dp arrive with lse / c and delta already subtracted (augmented contraction).  A padded QUERY row (past Sq) has
+            // q = dO = 0 in LDS but carries its lse / delta columns: its P is finite garbage that only ever multiplies those zero
+            // rows in the dV / dK products.  Padded KEYS (blocks past valid_k only): one more multiply by the lane's 0 / 1 mask.
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            const int qb = q0 + sub * 16 + (lane >> 4) * 4;
-            const f32x4_t lse = *reinterpret_cast<const f32x4_t*>(lseg + qb);
-            const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(dlg + qb);
+            for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // padded key: exp2(-inf) = 0.  A padded QUERY row (past Sq) has q = dO = 0 in LDS: its P is finite garbage, but
-                // it only ever multiplies those zero rows in the dV / dK products
-                const float p = fast_exp2(fmaf(s[sub][r], scale_log2, key_lse_off - lse[r]));
-                s[sub][r] = p;
-                ds[sub][r] = p * (dp[sub][r] - dl[r]);                                              // (scale: once, on the finished dK tile)
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(s[sub][r] * scale_log2);
+                    s[sub][r] = p;
+                    ds[sub][r] = p * dp[sub][r];                                                    // (scale: once, on the finished dK tile)
+                }
+            if (any_masked) {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[sub][r] *= key_mask; ds[sub][r] *= key_mask; }
+            }
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const int qb = q0 + sub * 16 + (lane >> 4) * 4;
+                const f32x4_t lse = *reinterpret_cast<const f32x4_t*>(lseg + qb);
+                const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(dlg + qb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // padded key: exp2(-inf) = 0.  A padded QUERY row (past Sq) has q = dO = 0 in LDS: its P is finite garbage, but
+                    // it only ever multiplies those zero rows in the dV / dK products
+                    const float p = fast_exp2(fmaf(s[sub][r], scale_log2, key_lse_off - lse[r]));
+                    s[sub][r] = p;
+                    ds[sub][r] = p * (dp[sub][r] - dl[r]);                                          // (scale: once, on the finished dK tile)
+                }
             }
         }
 #pragma unroll
@@ -448,20 +550,24 @@ int fa_launch_bwd(const BwdArgs& a, int nbh, int Bf, const FAShape& sh, float sc
     const float sl2 = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
     // dQ first: it forms delta = rowsum(dO o O) for its 64 queries (when O is given) and leaves it for the dK / dV kernel
-#define FA_BWD(DP)                                                                                                          \
+#define FA_BWD(DP, AUG)                                                                                                     \
     do {                                                                                                                     \
         static unsigned char a1[kMaxDevices], a2[kMaxDevices];                                                               \
-        if (siss_ensure_smem((const void*)flash_bwd_dq_kernel<DP>, 2 * FA<DP>::TILE, a1) != SISS_OK) return SISS_ERR_LAUNCH; \
-        if (siss_ensure_smem((const void*)flash_bwd_dkdv_kernel<DP>, 2 * FA<DP>::TILE, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
-        flash_bwd_dq_kernel<DP><<<dim3(sh.Sqp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                            \
+        if (siss_ensure_smem((const void*)flash_bwd_dq_kernel<DP, AUG>, 2 * FA<DP>::TILE, a1) != SISS_OK) return SISS_ERR_LAUNCH; \
+        if (siss_ensure_smem((const void*)flash_bwd_dkdv_kernel<DP, AUG>, 2 * FA<DP>::TILE, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
+        flash_bwd_dq_kernel<DP, AUG><<<dim3(sh.Sqp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                       \
             (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.o, a.ldo,     \
             (const bf16_t*)a.d_o, a.lddo, a.lse2, a.delta, (bf16_t*)a.dq, a.lddq, Bf, sh, scale, sl2);                      \
-        flash_bwd_dkdv_kernel<DP><<<dim3(sh.Skp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                          \
+        flash_bwd_dkdv_kernel<DP, AUG><<<dim3(sh.Skp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                     \
             (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.d_o, a.lddo,  \
             a.lse2, a.delta, (bf16_t*)a.dk, a.lddk, (bf16_t*)a.dv, a.lddv, Bf, sh, scale, sl2);                             \
     } while (0)
     const int dp = fa_dpad(sh.D);
-    if (dp == 64) FA_BWD(64); else if (dp == 128) FA_BWD(128); else FA_BWD(192);
+    // A head dim of at most 56 (one whole pad chunk in the 64-wide operands: SD's D = 40, the 4096-key sites) takes the
+    // augmented-contraction kernels: 5.58 -> 4.98 ms per launch at B = 16.  The wider tiles do NOT: there the loops are less
+    // VALU-bound and the extra registers cost a resident wave (dK / dV kernel at D_pad = 128: 232 -> 256 VGPRs, 772 -> 1069 us).
+    if (dp == 64 && sh.D + 8 <= dp) FA_BWD(64, true);
+    else if (dp == 64) FA_BWD(64, false); else if (dp == 128) FA_BWD(128, false); else FA_BWD(192, false);
 #undef FA_BWD
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
