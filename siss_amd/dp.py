@@ -30,13 +30,28 @@ def allreduce_pieces(tensors, group=None, async_op=False):
     Returns a handle with .wait() when async_op."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
         return None
-    from torch.distributed.distributed_c10d import _coalescing_manager
+    try:
+        from torch.distributed.distributed_c10d import _coalescing_manager
+    except ImportError:                                  # (a torch without the coalescing window: one all-reduce per piece)
+        _coalescing_manager = None
+    if _coalescing_manager is None:
+        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op) for t in tensors]
+        return _Works(works) if async_op else None
     # (no `device`: the fast path -- the window records the all-reduces and hands them to the backend's allreduce_coalesced,
     # which RCCL and gloo both implement)
     with _coalescing_manager(group=group, async_ops=async_op) as cm:
         for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return cm if async_op else None
+
+
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
 
 
 def can_shard(P, world, align=4):

@@ -127,9 +127,19 @@ class SISSStepper:
         # from what it was given, whichever candidate wins
         saved = [t.clone() for t in (self.opt.p, self.opt.m, self.opt.v, self.opt.scalars)]
         saved_state = (self.superfactor, self.last, self._micro)
+        errors = {}
         for name, (mode, exch) in candidates.items():
             self.set_overlap(mode, exch)
-            step_fn()                                            # settle (scratch buffers, communicator channels)
+            try:
+                step_fn()                                        # settle (scratch buffers, communicator channels)
+            except (RuntimeError, NotImplementedError) as exc:
+                # a collective this backend does not offer raises on EVERY rank at the call: the candidate is dropped everywhere
+                # (the sharded update's all-to-all is the likely one); the serial all-reduce must work or the run has no exchange
+                if name == "serial":
+                    raise
+                errors[name] = (str(exc) or type(exc).__name__)[:200]
+                self._pending, self._micro, self._state_shard = [], 0, None
+                continue
             dist.barrier(group=self.pg); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(iters):
@@ -147,6 +157,8 @@ class SISSStepper:
         self.e.refresh_weights(cast_shadow=True)
         self.set_overlap(best.startswith("overlap"), candidates[best][1])
         self.overlap_timings = {k + "_ms": v * 1e3 for k, v in results.items()}
+        if errors:
+            self.overlap_timings["errors"] = errors
         return self.overlap
 
     # ------------------------------------------------------------------ one micro-batch
