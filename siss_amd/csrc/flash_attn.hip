@@ -181,12 +181,16 @@ __device__ __forceinline__ void rowvals_apply(TileRegs<DP>& r, const RowVals<DP>
 // forward: O = softmax(scale Q K^T) V, LSE2[q] = log2 sum_k exp2(scale log2e (q.k))   (base-2 log-sum-exp)
 // grid (Sq_pad / 64, B*heads)
 // ====================================================================================================================
-template <int DP>
+// DL: the head dimension covers only the first DL 16-wide d tiles of the DP-wide operands (0: all of them) -- the output tiles and
+// the 32-deep contraction steps past it are all padding and are not computed (D = 40 in 64: 3 of 4 tiles; 80 in 128: 5 of 8 tiles
+// and 3 of 4 steps; 160 in 192: 10 of 12 and 5 of 6).
+template <int DP, int DL>
 __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                                long ldk, const bf16_t* __restrict__ V, long ldv,
                                                                bf16_t* __restrict__ O, long ldo, float* __restrict__ LSE2,
                                                                FAShape sh, float scale_log2) {
     using F = FA<DP>;
+    constexpr int DTL = DL ? DL : F::DT, KSL = DL ? (DL * 16 + 31) / 32 : F::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks_ = smem;                       // K tile
     char* vs_ = smem + F::TILE;             // V tile
@@ -199,12 +203,12 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
     const int qrow = q0 + (lane & 15);
     const bool q_ok = qrow < sh.Sq;
     const bf16_t* qg = Q + (b * sh.Sq + qrow) * ldq + h * sh.hoff + (lane >> 4) * 8;
-    bf16x8_t qf[F::KS];
+    bf16x8_t qf[KSL];
 #pragma unroll
-    for (int ks = 0; ks < F::KS; ++ks) qf[ks] = load_frag_or_zero(qg + ks * 32, q_ok && ks * 4 + (lane >> 4) < dch);
-    f32x4_t ot[F::DT];
+    for (int ks = 0; ks < KSL; ++ks) qf[ks] = load_frag_or_zero(qg + ks * 32, q_ok && ks * 4 + (lane >> 4) < dch);
+    f32x4_t ot[DTL];
 #pragma unroll
-    for (int dt = 0; dt < F::DT; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DTL; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
     const bf16_t* kg = K + b * sh.Sk * ldk + h * sh.hoff;
     const bf16_t* vg = V + b * sh.Sk * ldv + h * sh.hoff;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
         for (int sub = 0; sub < 4; ++sub) {
             st[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < F::KS; ++ks)
+            for (int ks = 0; ks < KSL; ++ks)
                 st[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm<DP>(ks_, sub, ks, lane), qf[ks], st[sub], 0, 0, 0);
         }
         // The running maximum is kept on the RAW scores (scale > 0: the maximum commutes with the scaling), so that an element
@@ -253,21 +257,21 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
         l = l * alpha + group_sum(ps);
         m = m_new;
 #pragma unroll
-        for (int dt = 0; dt < F::DT; ++dt)
+        for (int dt = 0; dt < DTL; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bf16x8_t pf = pack_pair(st[2 * j], st[2 * j + 1]);
 #pragma unroll
-            for (int dt = 0; dt < F::DT; ++dt)
+            for (int dt = 0; dt < DTL; ++dt)
                 ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DP>(vs_, j, dt, lane), pf, ot[dt], 0, 0, 0);
         }
     }
     const float inv = 1.f / l;
     bf16_t* og = O + (b * sh.Sq + qrow) * ldo + h * sh.hoff + (lane >> 4) * 4;
 #pragma unroll
-    for (int dt = 0; dt < F::DT; ++dt)
+    for (int dt = 0; dt < DTL; ++dt)
         if (q_ok && dt * 16 + (lane >> 4) * 4 < sh.D)
             *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(ot[dt][0] * inv, ot[dt][1] * inv), pack_bf2(ot[dt][2] * inv, ot[dt][3] * inv)};
     if ((lane >> 4) == 0) LSE2[bh * sh.Sqp + q0 + lane] = m * scale_log2 + log2f(l);
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
 // backward).  Og != null: delta[q] = <dO[q], O[q]> is formed here, from fragments laid out like Q's, and WRITTEN to `delta`
 // for the dK / dV kernel that follows; Og == null: `delta` is an input.
 // ====================================================================================================================
-template <int DP, bool AUG>
+template <int DP, bool AUG, int DL>
 __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                                   long ldk, const bf16_t* __restrict__ V, long ldv,
                                                                   const bf16_t* __restrict__ Og, long ldo,
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
                                                                   bf16_t* __restrict__ dQ, long lddq, int Bf, FAShape sh,
                                                                   float scale, float scale_log2) {
     using F = FA<DP>;
+    constexpr int DTL = DL ? DL : F::DT, KSL = DL ? (DL * 16 + (AUG ? 8 : 0) + 31) / 32 : F::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks_ = smem;
     char* vs_ = smem + F::TILE;
@@ -301,10 +306,10 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
     const int qrow = q0 + (lane & 15);
     const bool q_ok = qrow < sh.Sq;
     const long col = h * sh.hoff + (lane >> 4) * 8;
-    bf16x8_t qf[F::KS], dof[F::KS];
+    bf16x8_t qf[KSL], dof[KSL];
     float dl = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < F::KS; ++ks) {
+    for (int ks = 0; ks < KSL; ++ks) {
         const bool ok = q_ok && ks * 4 + (lane >> 4) < dch;
         qf[ks] = load_frag_or_zero(Q + (bf * sh.Sq + qrow) * ldq + col + ks * 32, ok);
         dof[ks] = load_frag_or_zero(dO + (bz * sh.Sq + qrow) * lddo + col + ks * 32, ok);
@@ -328,12 +333,12 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
         // this lane's row of the Q / dO operands: the pad chunk (columns D .. D+7) carries -lse / c and -delta, split into bf16 parts
         const u32x4_t lq = split_bf16(-lse / scale_log2, 3), ld = split_bf16(-dl, 2);
 #pragma unroll
-        for (int ks = 0; ks < F::KS; ++ks)
+        for (int ks = 0; ks < KSL; ++ks)
             if (ks * 4 + (lane >> 4) == dch) { qf[ks] = __builtin_bit_cast(bf16x8_t, lq); dof[ks] = __builtin_bit_cast(bf16x8_t, ld); }
     }
-    f32x4_t dqt[F::DT];
+    f32x4_t dqt[DTL];
 #pragma unroll
-    for (int dt = 0; dt < F::DT; ++dt) dqt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DTL; ++dt) dqt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bf16_t* kg = K + bf * sh.Sk * ldk + h * sh.hoff;
     const bf16_t* vg = V + bf * sh.Sk * ldv + h * sh.hoff;
     TileRegs<DP> kr, vr;
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
         for (int sub = 0; sub < 4; ++sub) {
             st[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < F::KS; ++ks) {
+            for (int ks = 0; ks < KSL; ++ks) {
                 st[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm<DP>(ks_, sub, ks, lane), qf[ks], st[sub], 0, 0, 0);
                 dp[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm<DP>(vs_, sub, ks, lane), dof[ks], dp[sub], 0, 0, 0);
             }
@@ -379,13 +384,13 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
         for (int j = 0; j < 2; ++j) {
             const bf16x8_t dsf = pack_pair(st[2 * j], st[2 * j + 1]);
 #pragma unroll
-            for (int dt = 0; dt < F::DT; ++dt)
+            for (int dt = 0; dt < DTL; ++dt)
                 dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DP>(ks_, j, dt, lane), dsf, dqt[dt], 0, 0, 0);
         }
     }
     bf16_t* og = dQ + (bz * sh.Sq + qrow) * lddq + h * sh.hoff + (lane >> 4) * 4;
 #pragma unroll
-    for (int dt = 0; dt < F::DT; ++dt)
+    for (int dt = 0; dt < DTL; ++dt)
         if (q_ok && dt * 16 + (lane >> 4) * 4 < sh.D)
             *reinterpret_cast<u32x2_t*>(og + dt * 16) = u32x2_t{pack_bf2(dqt[dt][0] * scale, dqt[dt][1] * scale), pack_bf2(dqt[dt][2] * scale, dqt[dt][3] * scale)};
 }
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
 // backward, dK / dV:  dV = P^T dO,  dK = scale * dS^T Q             grid (Sk_pad / 64, nB*heads)
 // S[q][key] = mfma(Q rows, K rows): a lane keeps ONE key and 4 consecutive queries of each 16-query sub-tile.
 // ====================================================================================================================
-template <int DP, bool AUG>
+template <int DP, bool AUG, int DL>
 __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                                     long ldk, const bf16_t* __restrict__ V, long ldv,
                                                                     const bf16_t* __restrict__ dO, long lddo,
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
                                                                     bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV,
                                                                     long lddv, int Bf, FAShape sh, float scale, float scale_log2) {
     using F = FA<DP>;
+    constexpr int DTL = DL ? DL : F::DT, KSL = DL ? (DL * 16 + (AUG ? 8 : 0) + 31) / 32 : F::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* qs_ = smem;
     char* dos_ = smem + F::TILE;
@@ -416,9 +422,9 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     const bool k_ok = krow < sh.Sk;
     const float key_lse_off = krow < sh.valid_k ? 0.f : -INFINITY;     // a lane keeps ONE key: its mask is one additive constant
     const long col = h * sh.hoff + (lane >> 4) * 8;
-    bf16x8_t kf[F::KS], vf[F::KS];
+    bf16x8_t kf[KSL], vf[KSL];
 #pragma unroll
-    for (int ks = 0; ks < F::KS; ++ks) {
+    for (int ks = 0; ks < KSL; ++ks) {
         const bool ok = k_ok && ks * 4 + (lane >> 4) < dch;
         kf[ks] = load_frag_or_zero(K + (bf * sh.Sk + krow) * ldk + col + ks * 32, ok);
         vf[ks] = load_frag_or_zero(V + (bf * sh.Sk + krow) * ldv + col + ks * 32, ok);
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     if constexpr (AUG) {
         // this lane's key row: ones against the -lse / c (three) and -delta (two) columns of the augmented Q / dO tiles
 #pragma unroll
-        for (int ks = 0; ks < F::KS; ++ks)
+        for (int ks = 0; ks < KSL; ++ks)
             if (ks * 4 + (lane >> 4) == dch) {
                 kf[ks] = __builtin_bit_cast(bf16x8_t, u32x4_t{kOne2, kOne1, 0u, 0u});
                 vf[ks] = __builtin_bit_cast(bf16x8_t, u32x4_t{kOne2, 0u, 0u, 0u});
@@ -434,9 +440,9 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     }
     const float key_mask = krow < sh.valid_k ? 1.f : 0.f;
     const bool any_masked = blockIdx.x * kTQ + kTQ > sh.valid_k;       // (block-uniform) this block holds padded keys
-    f32x4_t dkt[F::DT], dvt[F::DT];
+    f32x4_t dkt[DTL], dvt[DTL];
 #pragma unroll
-    for (int dt = 0; dt < F::DT; ++dt) { dkt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    for (int dt = 0; dt < DTL; ++dt) { dkt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     const bf16_t* qg = Q + bf * sh.Sq * ldq + h * sh.hoff;
     const bf16_t* dog = dO + bz * sh.Sq * lddo + h * sh.hoff;
     const float* lseg = LSE2 + zf * Sqp;
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
         for (int sub = 0; sub < 4; ++sub) {
             s[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < F::KS; ++ks) {
+            for (int ks = 0; ks < KSL; ++ks) {
                 s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm<DP>(qs_, sub, ks, lane), kf[ks], s[sub], 0, 0, 0);
                 dp[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm<DP>(dos_, sub, ks, lane), vf[ks], dp[sub], 0, 0, 0);
             }
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
             const bf16x8_t pf = pack_pair(s[2 * j], s[2 * j + 1]);
             const bf16x8_t dsf = pack_pair(ds[2 * j], ds[2 * j + 1]);
 #pragma unroll
-            for (int dt = 0; dt < F::DT; ++dt) {
+            for (int dt = 0; dt < DTL; ++dt) {
                 dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DP>(dos_, j, dt, lane), pf, dvt[dt], 0, 0, 0);
                 dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DP>(qs_, j, dt, lane), dsf, dkt[dt], 0, 0, 0);
             }
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     bf16_t* okg = dK + (bz * sh.Sk + krow) * lddk + h * sh.hoff + (lane >> 4) * 4;
     bf16_t* ovg = dV + (bz * sh.Sk + krow) * lddv + h * sh.hoff + (lane >> 4) * 4;
 #pragma unroll
-    for (int dt = 0; dt < F::DT; ++dt) {
+    for (int dt = 0; dt < DTL; ++dt) {
         if (!(k_ok && dt * 16 + (lane >> 4) * 4 < sh.D)) continue;
         *reinterpret_cast<u32x2_t*>(okg + dt * 16) = u32x2_t{pack_bf2(dkt[dt][0] * scale, dkt[dt][1] * scale), pack_bf2(dkt[dt][2] * scale, dkt[dt][3] * scale)};
         *reinterpret_cast<u32x2_t*>(ovg + dt * 16) = u32x2_t{pack_bf2(dvt[dt][0], dvt[dt][1]), pack_bf2(dvt[dt][2], dvt[dt][3])};
@@ -531,15 +537,18 @@ int fa_launch_fwd(const FwdArgs& a, int nbh, const FAShape& sh, float scale, voi
     const dim3 grid(sh.Sqp / kTQ, nbh);
     const float sl2 = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
-#define FA_FWD(DP)                                                                                                       \
+#define FA_FWD(DP, DL)                                                                                                   \
     do {                                                                                                                  \
         static unsigned char att[kMaxDevices];                                                                            \
-        if (siss_ensure_smem((const void*)flash_fwd_kernel<DP>, 2 * FA<DP>::TILE, att) != SISS_OK) return SISS_ERR_LAUNCH; \
-        flash_fwd_kernel<DP><<<grid, kThreadsFA, 2 * FA<DP>::TILE, st>>>((const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, \
+        if (siss_ensure_smem((const void*)flash_fwd_kernel<DP, DL>, 2 * FA<DP>::TILE, att) != SISS_OK) return SISS_ERR_LAUNCH; \
+        flash_fwd_kernel<DP, DL><<<grid, kThreadsFA, 2 * FA<DP>::TILE, st>>>((const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, \
             (const bf16_t*)a.v, a.ldv, (bf16_t*)a.o, a.ldo, a.lse2, sh, sl2);                                              \
     } while (0)
     const int dp = fa_dpad(sh.D);
-    if (dp == 64) FA_FWD(64); else if (dp == 128) FA_FWD(128); else FA_FWD(192);
+    // (the live-tile counts instantiated: SD v1.5's head dims 40 / 80 / 160 and anything narrower; everything else runs all tiles)
+    if (dp == 64) { if (sh.D <= 48) FA_FWD(64, 3); else FA_FWD(64, 0); }
+    else if (dp == 128) { if (sh.D <= 80) FA_FWD(128, 5); else FA_FWD(128, 0); }
+    else { if (sh.D <= 160) FA_FWD(192, 10); else FA_FWD(192, 0); }
 #undef FA_FWD
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
@@ -550,15 +559,15 @@ int fa_launch_bwd(const BwdArgs& a, int nbh, int Bf, const FAShape& sh, float sc
     const float sl2 = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
     // dQ first: it forms delta = rowsum(dO o O) for its 64 queries (when O is given) and leaves it for the dK / dV kernel
-#define FA_BWD(DP, AUG)                                                                                                     \
+#define FA_BWD(DP, AUG, DL)                                                                                                   \
     do {                                                                                                                     \
         static unsigned char a1[kMaxDevices], a2[kMaxDevices];                                                               \
-        if (siss_ensure_smem((const void*)flash_bwd_dq_kernel<DP, AUG>, 2 * FA<DP>::TILE, a1) != SISS_OK) return SISS_ERR_LAUNCH; \
-        if (siss_ensure_smem((const void*)flash_bwd_dkdv_kernel<DP, AUG>, 2 * FA<DP>::TILE, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
-        flash_bwd_dq_kernel<DP, AUG><<<dim3(sh.Sqp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                       \
+        if (siss_ensure_smem((const void*)flash_bwd_dq_kernel<DP, AUG, DL>, 2 * FA<DP>::TILE, a1) != SISS_OK) return SISS_ERR_LAUNCH; \
+        if (siss_ensure_smem((const void*)flash_bwd_dkdv_kernel<DP, AUG, DL>, 2 * FA<DP>::TILE, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
+        flash_bwd_dq_kernel<DP, AUG, DL><<<dim3(sh.Sqp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                       \
             (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.o, a.ldo,     \
             (const bf16_t*)a.d_o, a.lddo, a.lse2, a.delta, (bf16_t*)a.dq, a.lddq, Bf, sh, scale, sl2);                      \
-        flash_bwd_dkdv_kernel<DP, AUG><<<dim3(sh.Skp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                     \
+        flash_bwd_dkdv_kernel<DP, AUG, DL><<<dim3(sh.Skp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                     \
             (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.d_o, a.lddo,  \
             a.lse2, a.delta, (bf16_t*)a.dk, a.lddk, (bf16_t*)a.dv, a.lddv, Bf, sh, scale, sl2);                             \
     } while (0)
@@ -566,8 +575,11 @@ int fa_launch_bwd(const BwdArgs& a, int nbh, int Bf, const FAShape& sh, float sc
     // A head dim of at most 56 (one whole pad chunk in the 64-wide operands: SD's D = 40, the 4096-key sites) takes the
     // augmented-contraction kernels: 5.58 -> 4.98 ms per launch at B = 16.  The wider tiles do NOT: there the loops are less
     // VALU-bound and the extra registers cost a resident wave (dK / dV kernel at D_pad = 128: 232 -> 256 VGPRs, 772 -> 1069 us).
-    if (dp == 64 && sh.D + 8 <= dp) FA_BWD(64, true);
-    else if (dp == 64) FA_BWD(64, false); else if (dp == 128) FA_BWD(128, false); else FA_BWD(192, false);
+    if (dp == 64 && sh.D <= 48) FA_BWD(64, true, 3);
+    else if (dp == 64 && sh.D + 8 <= dp) FA_BWD(64, true, 0);
+    else if (dp == 64) FA_BWD(64, false, 0);
+    else if (dp == 128) { if (sh.D <= 80) FA_BWD(128, false, 5); else FA_BWD(128, false, 0); }
+    else { if (sh.D <= 160) FA_BWD(192, false, 10); else FA_BWD(192, false, 0); }
 #undef FA_BWD
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }

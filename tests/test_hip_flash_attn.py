@@ -114,6 +114,13 @@ MERGED_CASES = [  # B, H, Sq, Sk, D, extra row-stride columns
     (2, 8, 128, 77, 40, 0),       # cross attention: 77 keys, second key tile mostly padding that does not exist in memory
     (1, 4, 100, 100, 80, 64),     # ragged rows (100 of 128), head dim 80, rows wider than heads * D
     (2, 2, 64, 200, 160, 0),      # head dim 160 (three 64-wide k-steps), ragged keys
+    # the live-tile variants (tiles and contraction steps that are all padding are not computed) and their boundaries
+    (1, 2, 128, 128, 48, 0),      # 3 of 4 d tiles, the augmented columns at 48..55 in the second contraction step
+    (1, 2, 128, 192, 56, 8),      # augmented, all 4 tiles
+    (1, 2, 64, 64, 64, 0),        # no pad chunk: plain form
+    (1, 2, 70, 130, 16, 0),       # one live tile of the 3 computed
+    (1, 3, 128, 128, 96, 0),      # 128-wide operands, all tiles (80 < D <= 128)
+    (1, 1, 64, 128, 192, 0),      # 192-wide operands, all tiles
 ]
 
 
