@@ -195,6 +195,59 @@ __global__ void conv_weight_dgrad_multi_kernel(const float* __restrict__ flat, b
     }
 }
 
+// The same from the bf16 operand shadow (bitwise the rounded master: the fused AdamW kernel / siss_cast_f32_bf16 keep it so): half
+// the bytes read, and 16-B accesses on both sides -- a lane reads 8 consecutive c of one o, scatters them into the transposed LDS
+// tile, and writes 8 consecutive o of one c.  Weights whose co or ci is not a multiple of 8 (conv_in) take the scalar walk.
+__global__ __launch_bounds__(256) void conv_weight_dgrad_multi_bf16_kernel(const bf16_t* __restrict__ shadow, bf16_t* __restrict__ wt_all,
+                                                                           const WtJob* __restrict__ jobs, int njobs) {
+    constexpr int TS = 64, LD = TS + 8;                   // 144-B rows: 16-B aligned vectors, rows 4 banks apart
+    __shared__ __attribute__((aligned(16))) bf16_t tile[TS][LD];   // [c][o]
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WtJob j = jobs[lo];
+    int t = blockIdx.x - j.tile0;
+    const int tc = (j.ci + TS - 1) / TS, to = (j.co + TS - 1) / TS;
+    const int tap = t / (tc * to); t -= tap * tc * to;
+    const int o0 = (t / tc) * TS, c0 = (t % tc) * TS;
+    const bf16_t* src = shadow + j.src + (long)tap * j.co * j.ci;
+    bf16_t* dst = wt_all + j.dst + (long)(j.taps - 1 - tap) * j.co * j.ci;
+    const int tid = threadIdx.x;
+    if ((j.ci | j.co) % 8 == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int id = tid + 256 * k, r = id >> 3, ch = id & 7;
+            const int o = o0 + r, c = c0 + ch * 8;
+            u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+            if (o < j.co && c < j.ci) v = *reinterpret_cast<const u32x4_t*>(src + (long)o * j.ci + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                tile[ch * 8 + 2 * e][r] = (bf16_t)(v[e] & 0xffffu);
+                tile[ch * 8 + 2 * e + 1][r] = (bf16_t)(v[e] >> 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int id = tid + 256 * k, r = id >> 3, ch = id & 7;
+            const int c = c0 + r, o = o0 + ch * 8;
+            if (c < j.ci && o < j.co) *reinterpret_cast<u32x4_t*>(dst + (long)c * j.co + o) = *reinterpret_cast<const u32x4_t*>(&tile[r][ch * 8]);
+        }
+    } else {
+        for (int id = tid; id < TS * TS; id += 256) {
+            const int r = id >> 6, cc = id & 63, o = o0 + r, c = c0 + cc;
+            tile[cc][r] = (o < j.co && c < j.ci) ? src[(long)o * j.ci + c] : (bf16_t)0;
+        }
+        __syncthreads();
+        for (int id = tid; id < TS * TS; id += 256) {
+            const int r = id >> 6, oo = id & 63, c = c0 + r, o = o0 + oo;
+            if (c < j.ci && o < j.co) dst[(long)c * j.co + o] = tile[r][oo];
+        }
+    }
+}
+
 inline int grid_for(long n) {
     long b = (n / 4 + kThreads - 1) / kThreads;
     if (b < 1) b = 1;
@@ -276,6 +329,17 @@ int siss_conv_weight_dgrad_multi(const float* flat, void* wt_all, const void* jo
     SISS_CHECK_ARG(flat && wt_all && jobs && njobs > 0 && total_tiles > 0);
     conv_weight_dgrad_multi_kernel<<<total_tiles, dim3(64, 4), 0, (hipStream_t)stream>>>(
         flat, reinterpret_cast<bf16_t*>(wt_all), reinterpret_cast<const WtJob*>(jobs), njobs);
+    SISS_LAUNCH_RET();
+}
+
+// The same from the bf16 operand shadow of the flat buffer (same element offsets; it must hold the rounded master: the fused
+// AdamW launch and siss_cast_f32_bf16 leave it so): half the bytes read, 16-B accesses.
+int siss_conv_weight_dgrad_multi_bf16(const void* shadow, void* wt_all, const void* jobs, int njobs, int total_tiles,
+                                      void* stream) {
+    SISS_CHECK_ARG(shadow && wt_all && jobs && njobs > 0 && total_tiles > 0);
+    SISS_CHECK_ARG(((uintptr_t)shadow | (uintptr_t)wt_all) % 16 == 0);
+    conv_weight_dgrad_multi_bf16_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const bf16_t*>(shadow), reinterpret_cast<bf16_t*>(wt_all), reinterpret_cast<const WtJob*>(jobs), njobs);
     SISS_LAUNCH_RET();
 }
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "siss_cast_f32_bf16": [P, P, L, P],
     "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],
     "siss_conv_weight_dgrad_multi": [P, P, P, I, I, P],
+    "siss_conv_weight_dgrad_multi_bf16": [P, P, P, I, I, P],
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_nt_qstats": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, P, IP, P],
     "siss_conv3x3_sc": [P, L, P, P, L, P, P, L, P, L, P, I, P, I, I, I, IP, IP, I, I, I, P, IP, P],

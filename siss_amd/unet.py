@@ -317,7 +317,8 @@ class UNetEngine:
             lib.call("siss_cast_f32_bf16", ps.flat, ps.shadow, ps.total)
         if not self.wT:
             self._build_wt_jobs()
-        lib.call("siss_conv_weight_dgrad_multi", ps.flat, self._wt_all, self._wt_jobs, self._wt_njobs,
+        # (from the bf16 shadow, which holds the rounded master at this point: cast above, or refreshed by the fused AdamW launch)
+        lib.call("siss_conv_weight_dgrad_multi_bf16", ps.shadow, self._wt_all, self._wt_jobs, self._wt_njobs,
                  self._wt_tiles)
         for pre, (buf, idx) in self._wds.items():
             torch.index_select(self.wT[pre + ".conv.weight"], 0, idx, out=buf)

@@ -558,3 +558,49 @@ def test_folded_shortcut_equals_the_separate_1x1_product():
         ga, gb = outs[True][1][s].double(), outs[False][1][s].double()
         assert float((ga * gb).sum() / (ga.norm() * gb.norm())) >= 0.999, s
         assert abs(float(ga.norm() / gb.norm()) - 1) < 1e-2, s
+
+
+def test_dgrad_weight_copies_from_the_shadow_equal_those_from_the_master(setup):
+    """refresh_weights() builds the transposed / tap-reversed dgrad operands from the bf16 shadow (siss_conv_weight_dgrad_multi_bf16,
+    16-B accesses; conv_in's 3 input channels take its scalar walk): bitwise what the f32-master form writes."""
+    from siss_amd import lib
+    eng, _, _ = setup
+    eng.refresh_weights(cast_shadow=True)
+    got = eng._wt_all.clone()
+    assert float(got.float().abs().max()) > 0
+    ref = torch.zeros_like(got)
+    lib.call("siss_conv_weight_dgrad_multi", eng.ps.flat, ref, eng._wt_jobs, eng._wt_njobs, eng._wt_tiles)
+    torch.cuda.synchronize()
+    # (the buffer's alignment gaps between weights are never written by either form)
+    for n, w in eng.wT.items():
+        off = w.data_ptr() - eng._wt_all.data_ptr()
+        assert off % 2 == 0
+        r = ref[off // 2: off // 2 + w.numel()].view_as(w)
+        assert torch.equal(w, r), n
+
+
+def test_dgrad_weight_copy_kernel_on_odd_shapes():
+    """The same kernel driven directly: a job table mixing vector-path weights (co, ci multiples of 8, partial 64 x 64 tiles) with
+    ones that take the scalar walk (co or ci not a multiple of 8), against torch's permute."""
+    import numpy as np
+    from siss_amd import lib
+    dev = torch.device("cuda:0")
+    shapes = [(9, 72, 136), (1, 320, 768), (9, 12, 20), (1, 5, 64), (9, 64, 3), (1, 128, 128)]
+    g = torch.Generator().manual_seed(5)
+    rec = np.zeros(len(shapes), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("co", "<i4"), ("ci", "<i4"), ("tile0", "<i4")]))
+    off = tiles = 0
+    for i, (t, co, ci) in enumerate(shapes):
+        rec[i] = (off, off, t, co, ci, tiles)
+        off += -(-t * co * ci // 64) * 64
+        tiles += t * (-(-co // 64)) * (-(-ci // 64))
+    master = torch.randn(off, generator=g).to(dev)
+    shadow = master.to(torch.bfloat16)
+    out = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+    jobs = torch.from_numpy(rec.view(np.uint8)).to(dev)
+    lib.call("siss_conv_weight_dgrad_multi_bf16", shadow, out, jobs, len(shapes), tiles)
+    torch.cuda.synchronize()
+    for (t, co, ci), r in zip(shapes, rec):
+        o = int(r["src"])
+        w = shadow[o:o + t * co * ci].view(t, co, ci)
+        want = w.flip(0).permute(0, 2, 1).contiguous()
+        assert torch.equal(out[o:o + t * co * ci].view(t, ci, co), want), (t, co, ci)
