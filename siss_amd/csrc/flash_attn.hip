@@ -405,7 +405,8 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
                                                                     const bf16_t* __restrict__ dO, long lddo,
                                                                     const float* __restrict__ LSE2, const float* __restrict__ delta,
                                                                     bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV,
-                                                                    long lddv, int Bf, FAShape sh, float scale, float scale_log2) {
+                                                                    long lddv, int Bf, FAShape sh, float scale, float scale_log2,
+                                                                    int qchunk, float* __restrict__ part) {
     using F = FA<DP>;
     constexpr int DTL = DL ? DL : F::DT, KSL = DL ? (DL * 16 + (AUG ? 8 : 0) + 31) / 32 : F::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -450,16 +451,20 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     const float lmul = -1.f / scale_log2;
     TileRegs<DP> qr, dor;
     RowVals<DP> lrow, drow;
-    tile_load<DP>(qg, ldq, sh.Sq, dch, qr, tid);
-    tile_load<DP>(dog, lddo, sh.Sq, dch, dor, tid);
-    if constexpr (AUG) { rowvals_load<DP>(lrow, dch, lseg, tid); rowvals_load<DP>(drow, dch, dlg, tid); }
-    for (int q0 = 0; q0 < Sqp; q0 += kTQ) {
+    // query range of this block: all of them, or (few keys: cross attention) the blockIdx.z-th chunk of `qchunk` rows, whose
+    // partial dK / dV go to `part` in f32 for flash_dkdv_reduce_kernel
+    const int qb0 = part ? blockIdx.z * qchunk : 0;
+    const int qb1 = part ? (qb0 + qchunk < Sqp ? qb0 + qchunk : Sqp) : Sqp;
+    tile_load<DP>(qg + (long)qb0 * ldq, ldq, sh.Sq - qb0, dch, qr, tid);
+    tile_load<DP>(dog + (long)qb0 * lddo, lddo, sh.Sq - qb0, dch, dor, tid);
+    if constexpr (AUG) { rowvals_load<DP>(lrow, dch, lseg + qb0, tid); rowvals_load<DP>(drow, dch, dlg + qb0, tid); }
+    for (int q0 = qb0; q0 < qb1; q0 += kTQ) {
         __syncthreads();
         if constexpr (AUG) { rowvals_apply<DP>(qr, lrow, dch, lmul, 3, tid); rowvals_apply<DP>(dor, drow, dch, -1.f, 2, tid); }
         tile_store<DP>(qr, qs_, tid);
         tile_store<DP>(dor, dos_, tid);
         __syncthreads();
-        if (q0 + kTQ < Sqp) {
+        if (q0 + kTQ < qb1) {
             tile_load<DP>(qg + (long)(q0 + kTQ) * ldq, ldq, sh.Sq - q0 - kTQ, dch, qr, tid);
             tile_load<DP>(dog + (long)(q0 + kTQ) * lddo, lddo, sh.Sq - q0 - kTQ, dch, dor, tid);
             if constexpr (AUG) { rowvals_load<DP>(lrow, dch, lseg + q0 + kTQ, tid); rowvals_load<DP>(drow, dch, dlg + q0 + kTQ, tid); }
@@ -520,6 +525,16 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
             }
         }
     }
+    if (part) {
+        // [z][chunk][key][dK: DTL * 16 | dV: DTL * 16] f32, unscaled
+        float* pg = part + (((long)z * gridDim.z + blockIdx.z) * sh.Skp + krow) * (2 * DTL * 16) + (lane >> 4) * 4;
+#pragma unroll
+        for (int dt = 0; dt < DTL; ++dt) {
+            *reinterpret_cast<f32x4_t*>(pg + dt * 16) = dkt[dt];
+            *reinterpret_cast<f32x4_t*>(pg + DTL * 16 + dt * 16) = dvt[dt];
+        }
+        return;
+    }
     bf16_t* okg = dK + (bz * sh.Sk + krow) * lddk + h * sh.hoff + (lane >> 4) * 4;
     bf16_t* ovg = dV + (bz * sh.Sk + krow) * lddv + h * sh.hoff + (lane >> 4) * 4;
 #pragma unroll
@@ -528,6 +543,31 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
         *reinterpret_cast<u32x2_t*>(okg + dt * 16) = u32x2_t{pack_bf2(dkt[dt][0] * scale, dkt[dt][1] * scale), pack_bf2(dkt[dt][2] * scale, dkt[dt][3] * scale)};
         *reinterpret_cast<u32x2_t*>(ovg + dt * 16) = u32x2_t{pack_bf2(dvt[dt][0], dvt[dt][1]), pack_bf2(dvt[dt][2], dvt[dt][3])};
     }
+}
+
+// Sum of the query chunks' partial dK / dV (flash_bwd_dkdv_kernel with `part`): one thread per (z, key, 4 head-dim columns).
+__global__ __launch_bounds__(256) void flash_dkdv_reduce_kernel(const float* __restrict__ part, int nchunks, int DW,
+                                                               bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV, long lddv,
+                                                               FAShape sh, float scale, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = sh.D >> 2;
+    const int col = (int)(i % c4) * 4;
+    const long r = i / c4;
+    const int key = (int)(r % sh.Sk);
+    const long z = r / sh.Sk;
+    const long bz = z / sh.H;
+    const int h = (int)(z - bz * sh.H);
+    f32x4_t k = f32x4_t{0.f, 0.f, 0.f, 0.f}, v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunks; ++c) {
+        const float* pg = part + ((z * nchunks + c) * sh.Skp + key) * (2 * DW) + col;
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(pg), b = *reinterpret_cast<const f32x4_t*>(pg + DW);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { k[e] += a[e]; v[e] += b[e]; }
+    }
+    const long o = (bz * sh.Sk + key);
+    *reinterpret_cast<u32x2_t*>(dK + o * lddk + h * sh.hoff + col) = u32x2_t{pack_bf2(k[0] * scale, k[1] * scale), pack_bf2(k[2] * scale, k[3] * scale)};
+    *reinterpret_cast<u32x2_t*>(dV + o * lddv + h * sh.hoff + col) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
 }
 
 inline int fa_dpad(int D) { return D <= 64 ? 64 : (D <= 128 ? 128 : (D <= 192 ? 192 : 0)); }
@@ -555,9 +595,30 @@ int fa_launch_fwd(const FwdArgs& a, int nbh, const FAShape& sh, float scale, voi
 
 struct BwdArgs { const void *q, *k, *v, *o, *d_o; void *dq, *dk, *dv; long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
                  const float* lse2; float* delta; };
+// Few key tiles (cross attention: 77 keys = 2 tiles) leave the dK / dV grid at a fraction of the chip -- 128 blocks of 64 query
+// tiles each at B = 4.  Then the queries are cut into chunks (grid z), every block leaves its partial tiles in the library
+// workspace (siss_gemm_nt_set_workspace; launches on one stream at a time share it) and a small kernel sums them: deterministic,
+// no atomics.  Chunks: as many as bring the grid to ~1024 blocks, at least 4 query tiles each, within the workspace.
+void fa_qsplit(const FAShape& sh, int nbh, int DW, int& nch, int& qchunk, float*& ws) {
+    long bytes = 0;
+    ws = (float*)siss_workspace(&bytes);
+    const long base = (long)(sh.Skp / kTQ) * nbh;
+    const int qtiles = sh.Sqp / kTQ;
+    if (!ws || base >= 512 || qtiles < 8 || sh.Sk != sh.valid_k || sh.D % 4) return;
+    long n = (1024 + base - 1) / base;
+    if (n > qtiles / 4) n = qtiles / 4;
+    const long per_chunk = (long)nbh * sh.Skp * 2 * DW * (long)sizeof(float);
+    if (n * per_chunk > bytes - 4096) n = (bytes - 4096) / per_chunk;
+    if (n < 2) return;
+    const int tiles_per = (int)((qtiles + n - 1) / n);
+    nch = (qtiles + tiles_per - 1) / tiles_per;
+    qchunk = tiles_per * kTQ;
+}
+
 int fa_launch_bwd(const BwdArgs& a, int nbh, int Bf, const FAShape& sh, float scale, void* stream) {
     const float sl2 = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
+    float* ws = nullptr;
     // dQ first: it forms delta = rowsum(dO o O) for its 64 queries (when O is given) and leaves it for the dK / dV kernel
 #define FA_BWD(DP, AUG, DL)                                                                                                   \
     do {                                                                                                                     \
@@ -567,9 +628,18 @@ int fa_launch_bwd(const BwdArgs& a, int nbh, int Bf, const FAShape& sh, float sc
         flash_bwd_dq_kernel<DP, AUG, DL><<<dim3(sh.Sqp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                       \
             (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.o, a.ldo,     \
             (const bf16_t*)a.d_o, a.lddo, a.lse2, a.delta, (bf16_t*)a.dq, a.lddq, Bf, sh, scale, sl2);                      \
-        flash_bwd_dkdv_kernel<DP, AUG, DL><<<dim3(sh.Skp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                     \
+        constexpr int DW = (DL ? DL : FA<DP>::DT) * 16;                                                                     \
+        int nch = 1, qchunk = sh.Sqp;                                                                                        \
+        fa_qsplit(sh, nbh, DW, nch, qchunk, ws);                                                                             \
+        flash_bwd_dkdv_kernel<DP, AUG, DL><<<dim3(sh.Skp / kTQ, nbh, nch), kThreadsFA, 2 * FA<DP>::TILE, st>>>(            \
             (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.d_o, a.lddo,  \
-            a.lse2, a.delta, (bf16_t*)a.dk, a.lddk, (bf16_t*)a.dv, a.lddv, Bf, sh, scale, sl2);                             \
+            a.lse2, a.delta, (bf16_t*)a.dk, a.lddk, (bf16_t*)a.dv, a.lddv, Bf, sh, scale, sl2, qchunk, nch > 1 ? ws : nullptr); \
+        if (nch > 1) {                                                                                                       \
+            siss_count_dispatch(SISS_K_FLASH_QSPLIT);                                                                        \
+            const long total = (long)nbh * sh.Sk * (sh.D >> 2);                                                              \
+            flash_dkdv_reduce_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(ws, nch, DW, (bf16_t*)a.dk, a.lddk, \
+                (bf16_t*)a.dv, a.lddv, sh, scale, total);                                                                    \
+        }                                                                                                                    \
     } while (0)
     const int dp = fa_dpad(sh.D);
     // A head dim of at most 56 (one whole pad chunk in the 64-wide operands: SD's D = 40, the 4096-key sites) takes the

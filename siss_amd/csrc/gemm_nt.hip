@@ -296,6 +296,13 @@ int nt_c3p_blocks() {
     return g_c3p_blocks[dev];
 }
 
+void* siss_workspace(long* bytes) {
+    const int dev = siss_current_device();
+    if (dev < 0 || !g_slab_dev[dev]) { *bytes = 0; return nullptr; }
+    *bytes = g_slab_bytes_dev[dev];
+    return g_slab_dev[dev];
+}
+
 static long g_dispatch[SISS_K_COUNT];
 void siss_count_dispatch(int k) { if (k >= 0 && k < SISS_K_COUNT) __atomic_fetch_add(&g_dispatch[k], 1L, __ATOMIC_RELAXED); }
 
@@ -317,7 +324,8 @@ int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
 // Diagnostics: number of launches dispatched to device kernel `kernel_id` since the last reset (process-wide):
 // 0 gemm_nt_kernel, 1 gemm_nt_c3p_kernel, 2 flash_fwd_kernel, 3 flash_bwd_dkdv_kernel + flash_bwd_dq_kernel (one count per siss_flash_attn_bwd), 4 gemm_nt_kernel split-K (+ reduce),
 // 5 gemm_tn_kernel<1>, 6 gemm_tn_kernel<3>, 7 GroupNorm slab kernels (forward or backward, small sites),
-// 8 GroupNorm forward on the statistics its producing convolution left (no statistics pass).
+// 8 GroupNorm forward on the statistics its producing convolution left (no statistics pass),
+// 9 attention dK / dV launches that cut the queries into chunks (few key tiles; partials in the workspace + reduce kernel).
 // -1 for an unknown id.  siss_dispatch_reset() zeroes them all.  (Tests use these to prove which kernel a case ran on.)
 long siss_dispatch_count(int kernel_id) {
     return kernel_id >= 0 && kernel_id < SISS_K_COUNT ? __atomic_load_n(&g_dispatch[kernel_id], __ATOMIC_RELAXED) : -1;

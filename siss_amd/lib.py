@@ -101,7 +101,7 @@ _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_sc
 
 # siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
 KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "flash_attn_fwd": 2, "flash_attn_bwd": 3,
-              "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8}
+              "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8, "flash_dkdv_qsplit": 9}
 
 
 def dispatch_counts(reset=False):
@@ -144,7 +144,7 @@ def load():
 
 
 _WORKSPACE = {}
-WORKSPACE_BYTES = 32 << 20      # 512 partial tiles of 128 x 128 f32: the most the split-K paths of siss_gemm_nt ask for
+WORKSPACE_BYTES = 64 << 20      # split-K partial tiles of siss_gemm_nt (at most 32 MiB) / query-chunk partials of the attention dK, dV kernel
 
 
 def ensure_workspace(device):

@@ -21,6 +21,7 @@ def dev():
     assert torch.cuda.is_available(), "GPU tests need a real MI355X"
     from siss_amd import lib
     lib.load()
+    lib.ensure_workspace("cuda:0")
     return torch.device("cuda:0")
 
 
@@ -121,6 +122,10 @@ MERGED_CASES = [  # B, H, Sq, Sk, D, extra row-stride columns
     (1, 2, 70, 130, 16, 0),       # one live tile of the 3 computed
     (1, 3, 128, 128, 96, 0),      # 128-wide operands, all tiles (80 < D <= 128)
     (1, 1, 64, 128, 192, 0),      # 192-wide operands, all tiles
+    # few key tiles, many query tiles: the dK / dV kernel cuts the queries into chunks (partials in the workspace + a reduce kernel)
+    (2, 8, 1024, 77, 40, 0),      # SD cross attention: 4 chunks of 4 query tiles
+    (1, 8, 640, 77, 80, 0),       # 2 chunks of 5
+    (1, 4, 570, 100, 160, 8),     # 9 query tiles (the last one ragged): chunks of 5 + 4
 ]
 
 
@@ -166,6 +171,7 @@ def test_flash_attention_on_the_projection_layout(dev, B, H, Sq, Sk, D, extra):
     torch.cuda.synchronize()
     cnt = lib.dispatch_counts(reset=True)
     assert cnt["flash_attn_fwd"] == 1 and cnt["flash_attn_bwd"] == 1
+    assert cnt["flash_dkdv_qsplit"] == (1 if Sk <= 128 and Sq >= 512 else 0), cnt
     d_ref = (dor * heads(o, B, Sq).repeat(sets, 1, 1, 1)).sum(-1)                       # <dO, O> with the bf16 O the kernel read
     _close(delta.view(sets * B, H, Sqp)[:, :, :Sq].cpu(), d_ref, 1e-2, "delta")
     for i in range(sets):
