@@ -210,6 +210,10 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
 #pragma unroll
     for (int dt = 0; dt < DTL; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
+    // Row sums on the matrix pipe: when the head dim ends in the middle of a d tile (D % 16 == 8: SD's 40) that tile has an all-padding
+    // column at index D; a ones column there in V makes O^T[D][q] accumulate sum_k p[q][k] -- with the same rescaling as O -- and the
+    // 16 adds + the cross-group sum per tile leave these VALU-bound loops.  (The sum is then over the bf16-rounded p the product uses.)
+    const bool lcol = (sh.D & 15) == 8 && sh.D < DTL * 16;
     const bf16_t* kg = K + b * sh.Sk * ldk + h * sh.hoff;
     const bf16_t* vg = V + b * sh.Sk * ldv + h * sh.hoff;
     TileRegs<DP> kr, vr;
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
     tile_load<DP>(vg, ldv, sh.Sk, dch, vr, tid);
     for (int k0 = 0; k0 < Skp; k0 += kTQ) {
         __syncthreads();                                        // the previous tile's readers are done
+        if (lcol) tile_set_chunk<DP>(vr, dch, u32x4_t{kOne1, 0u, 0u, 0u}, tid);
         tile_store<DP>(kr, ks_, tid);
         tile_store<DP>(vr, vs_, tid);
         __syncthreads();
@@ -247,19 +252,31 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
 #pragma unroll
         for (int sub = 1; sub < 4; ++sub) mx = fmaxf(mx, fmaxf(fmaxf(st[sub][0], st[sub][1]), fmaxf(st[sub][2], st[sub][3])));
         const float m_new = fmaxf(m, group_max(mx));            // finite: the first tile always holds a valid key (valid_k >= 1)
-        const float alpha = fast_exp2((m - m_new) * scale_log2);    // m = -inf on the first tile: alpha = 0
         const float mc = m_new * scale_log2;
-        float ps = 0.f;
+        // no row of this wave has a new maximum (most tiles after the first few): nothing to rescale -- a wave-uniform branch
+        const bool moved = __builtin_amdgcn_ballot_w64(m_new != m) != 0;
+        if (moved) {
+            const float alpha = fast_exp2((m - m_new) * scale_log2);    // m = -inf on the first tile: alpha = 0
+            l *= alpha;
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
+            for (int dt = 0; dt < DTL; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float p = fast_exp2(fmaf(st[sub][r], scale_log2, -mc)); st[sub][r] = p; ps += p; }
-        l = l * alpha + group_sum(ps);
-        m = m_new;
+                for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+            m = m_new;
+        }
+        if (lcol) {
 #pragma unroll
-        for (int dt = 0; dt < DTL; ++dt)
+            for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+                for (int r = 0; r < 4; ++r) st[sub][r] = fast_exp2(fmaf(st[sub][r], scale_log2, -mc));
+        } else {
+            float ps = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float p = fast_exp2(fmaf(st[sub][r], scale_log2, -mc)); st[sub][r] = p; ps += p; }
+            l += group_sum(ps);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bf16x8_t pf = pack_pair(st[2 * j], st[2 * j + 1]);
@@ -267,6 +284,12 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
             for (int dt = 0; dt < DTL; ++dt)
                 ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DP>(vs_, j, dt, lane), pf, ot[dt], 0, 0, 0);
         }
+    }
+    if (lcol) {                                                 // O^T[D][q]: d tile D / 16, row 8 = lanes 32..47, r = 0
+        float lv = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DTL; ++dt) lv = dt == (sh.D >> 4) ? ot[dt][0] : lv;
+        l = __shfl(lv, 32 + (lane & 15), 64);
     }
     const float inv = 1.f / l;
     bf16_t* og = O + (b * sh.Sq + qrow) * ldo + h * sh.hoff + (lane >> 4) * 4;
