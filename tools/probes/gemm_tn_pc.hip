@@ -1,0 +1,1004 @@
+// RECORD OF A MEASURED-AND-REJECTED KERNEL (round 3) -- not part of the product build.
+// gemm_tn.hip plus a PRODUCER / CONSUMER one-tap kernel (tn_pc_body: tile 128 n x 256 c, four consumer waves with 64 x 128 wave
+// tiles, four DMA waves, ring of six 32-row stages, one barrier per stage, ring unrolled so that slot offsets are immediates), a
+// column planner (tn_plan) and siss_gemm_tn_set_pc_min_rows (common.h needs SISS_K_TNPC in SissKernelId to build it).
+// Exact (11 shapes x single / grouped launches against an f64 matmul).  Saturated (rows 65536, N 2048, C 768, two sets): 912 TF/s
+// against 872-881 for the 128 x 128 tile; ablated: no DMA 1133, no fragment reads 1025, neither 1429, DMA + reads without MFMAs
+// 1121-equivalent.  Both tiles sit on the SAME wall: L2 -> LDS delivers ~13 TB/s chip-wide (4.83 GB in 368 us here, 6.4 GB in 473 us
+// for the 128 x 128 tile), so a TN product's ceiling is (flop per staged byte) x 13 TB/s = 870 TF/s at 128 x 128 (where it is),
+// 1117 at 128 x 256, 2500 for the fused 3-tap kernel (X staged once for three taps: MFMA-bound instead).
+// In the step it LOSES: SD v1.5 B = 16 121.6 / 121.0 ms against 119.7 / 119.1 (same box, alternating), B = 4 48.9 / 49.1 against
+// 48.3 / 48.4, CelebA-HQ 58.93 / 59.04 against 58.75 / 58.70 -- the grouped launches hold few, long blocks per job (a 128 x 256 tile
+// of 8192 rows is ~65 us: tile-round tails), shorter blocks would double the float-atomic traffic that already bounds the split,
+// and a 320-column weight (SD's commonest) leaves a quarter-filled 128 x 128 remainder tile.
+// Panelled TN GEMM on bf16 MFMA: the weight-gradient kernel (SURVEY.md §2b K2 wgrad, K9).
+//
+//   dW[set][p][n][c] += sum_{r in set} Y[r, n] * X[xrow(r) + shift_p, coff_p + c]
+//
+// Y = output cotangent (NHWC + zero halo, flat rows), X = saved forward activation.  Because
+// Y's halo rows are zero, the sum runs over the FLAT padded row range -- a plain GEMM whose
+// reduction dimension is the row index, nine row-shifted panels for a 3x3 filter, no pixel
+// decode.  The dual-cotangent backward (g_x and g_a in one pass) is the `set` dimension: both
+// cotangent sets read the same saved X (x_set_rows = 0) when the forward was shared (SISS), or
+// their own rows (SISS-No-IS).
+//
+// Both operands arrive row-major with the REDUCTION index on rows, so MFMA fragments need a
+// transposed read: tiles are staged [64 rows][128 ch] (256-B rows) by global_load_lds_dwordx4
+// and read with ds_read_b64_tr_b16.  16-B chunk index XOR ((row&3)<<2 | (row>>2)&3) -- on the
+// DMA source address and on the read -- makes every 32-lane half of a transposed read cover
+// all 64 banks exactly once.
+// Split-K over row ranges; partial tiles are accumulated with f32 global atomics (no-return
+// global_atomic_add_f32; 16 consecutive floats per lane group).
+#include "common.h"
+
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+constexpr int BN = 128, BC = 128, BR = 64;   // output tile 128(n) x 128(c); 64 reduction rows / step
+constexpr int kYTile = BR * 256;             // 16 KiB
+constexpr int kMaxPanels = 9;
+
+struct TNParams {
+    const bf16_t* Y; const bf16_t* X; float* dW; const bf16_t* zero_page;
+    float* dbias; float* dbias2;          // optional: column sums of Y per set (bias gradients)
+    long ldy, ldx, set_stride;
+    long x_set_rows;
+    long ldw;                             // row stride of dW (== C unless the job is a column slice of a wider product)
+    int N, C, npanels, nsets, nsplits, rmw;
+    int rows_per_set, row_begin, row_end, rows_per_split;
+    int shift[kMaxPanels];
+    int coff[kMaxPanels];
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ s16x4_t tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// TAPS = 1: one panel per block (1x1 convs, linears, stride-2 panels with channel offsets).
+// TAPS = 3: the three kx taps of one filter row share the block: their X rows are the SAME rows shifted
+//           by one, so the X tile is staged once with two extra rows and read at row offsets 0/1/2, and
+//           the Y tile is staged once for three products -- a third of the DMA instructions, HBM/L2 bytes
+//           and barriers per MFMA, and two thirds of the LDS reads.
+template <int TAPS, bool ILV = false>
+struct TCfg {
+    static constexpr int kWaves = TAPS == 3 ? 8 : 4;              // 3 taps: 8 waves of 64(n) x 32(c) keep 96 acc VGPRs
+    static constexpr int kThreads = kWaves * 64;
+    static constexpr int kCT = TAPS == 3 ? 2 : 4;                 // 16-wide c-tiles per wave
+    static constexpr int kPieces = 16 / kWaves;                   // 4-row DMA pieces per wave and operand
+    static constexpr int kXRows = BR + (TAPS == 3 ? 4 : 0);       // 64 (+ one extra 4-row DMA piece)
+    static constexpr int kStageBytes = kYTile + kXRows * 256;
+    static constexpr int kStages = TAPS == 3 ? (ILV ? 4 : 3) : 2; // 3 taps: one block per CU -> room for a 3-deep ring (4 in the interleaved variant)
+    static constexpr int kSmemBytes = kStages * kStageBytes;
+};
+
+// The whole product of one block.  bid / nwg: the block's index and the block count of ITS launch -- or, in a grouped launch
+// (gemm_tn_grouped_kernel), of its job.
+template <int TAPS, bool ILV = false>
+__device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nwg, char* smem) {
+    using C_ = TCfg<TAPS, ILV>;
+    constexpr int NP = C_::kPieces, CT = C_::kCT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = TAPS == 3 ? w >> 2 : w >> 1, wc = TAPS == 3 ? w & 3 : w & 1;   // wave tile 64(n) x (CT*16)(c)
+    // Grid is 1-D.  Logical order: panel group fastest, then tile, then split, then set -- and each XCD
+    // (blocks b, b+8, ... share an L2) gets a CONTIGUOUS run of logical blocks, so the blocks that
+    // stream the same Y / X rows run together on one XCD and their re-reads hit in L2
+    // (measured before this remap: 5 % L2 hit rate, 9x the operand bytes from HBM).
+    const int tiles_c = (p.C + BC - 1) / BC, tiles_n = (p.N + BN - 1) / BN;
+    const int ngroups = p.npanels / TAPS;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int pn = (bid % ngroups) * TAPS; bid /= ngroups;
+    const int tile = bid % (tiles_c * tiles_n); bid /= tiles_c * tiles_n;
+    const int split = bid % p.nsplits;
+    const int set = bid / p.nsplits;
+    const int tn = tile / tiles_c, tc = tile - tn * tiles_c;
+    const int n0 = tn * BN, c0 = tc * BC;
+    const int r0 = p.row_begin + split * p.rows_per_split;
+    int r1 = r0 + p.rows_per_split; r1 = r1 < p.row_end ? r1 : p.row_end;
+    if (r0 >= r1) return;
+    const int steps = (r1 - r0 + BR - 1) / BR;
+
+    // staging: 4 pieces of 4 rows (256 B each) per wave and operand (+ one extra X piece on wave 0)
+    const bf16_t* ysrc[NP];
+    const bf16_t* xsrc[NP];
+    const bf16_t* xsrc_extra = nullptr;
+    const bf16_t* zsrc = p.zero_page + (lane & 15) * 8;
+    // trow?[j]: the piece's row within the step, or kNever for lanes whose 16-B column chunk lies past the operand's
+    // last column (N < 128 / C < 128 tiles): those lanes take the zero page, so no byte past a row's end is ever read.
+    constexpr int kNever = 1 << 29;
+    int trowy[NP], trowx[NP];
+    const long xrow0 = (long)set * p.x_set_rows + r0 + p.shift[pn];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = (w * NP + j) * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ swz(row);
+        trowy[j] = n0 + lc * 8 < p.N ? row : kNever;
+        trowx[j] = c0 + lc * 8 < p.C ? row : kNever;
+        const long ry = (long)set * p.rows_per_set + r0 + row;
+        ysrc[j] = p.Y + ry * p.ldy + n0 + lc * 8;
+        xsrc[j] = p.X + (xrow0 + row) * p.ldx + p.coff[pn] + c0 + lc * 8;
+    }
+    int trow_extra = kNever;
+    if (TAPS == 3) {
+        const int row = BR + (lane >> 4);
+        const int lc = (lane & 15) ^ swz(row);
+        xsrc_extra = p.X + (xrow0 + row) * p.ldx + p.coff[pn] + c0 + lc * 8;
+        if (c0 + lc * 8 < p.C) trow_extra = row;
+    }
+    const long ystep = (long)BR * p.ldy, xstep = (long)BR * p.ldx;
+    const unsigned smem_a = lds_addr(smem);
+    // Fast form of stage() for the steps whose rows all lie inside [r0, r1) of a tile with all 128 + 128 columns (every step but
+    // the last one or two of full tiles): wave-uniform 64-bit base per step + per-lane 32-bit offsets fixed for the block, so a
+    // piece is s_mov m0 + the load.  The general form below spends, per piece, a compare, two selects against the zero page, a
+    // 64-bit add and an m0 save / restore -- ~65 instructions per step in waves that also issue 48 MFMAs and 40 LDS reads.
+    const bool full_tile = n0 + BN <= p.N && c0 + BC <= p.C;
+    unsigned yoff32[NP], xoff32[NP], xoff32_extra = 0;
+    const bf16_t* const ybase0 = p.Y + ((long)set * p.rows_per_set + r0) * p.ldy + n0;
+    const bf16_t* const xbase0 = p.X + xrow0 * p.ldx + p.coff[pn] + c0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = (w * NP + j) * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ swz(row);
+        yoff32[j] = (unsigned)(((long)row * p.ldy + lc * 8) * 2);
+        xoff32[j] = (unsigned)(((long)row * p.ldx + lc * 8) * 2);
+    }
+    if (TAPS == 3) {
+        const int row = BR + (lane >> 4);
+        xoff32_extra = (unsigned)(((long)row * p.ldx + ((lane & 15) ^ swz(row)) * 8) * 2);
+    }
+    auto stage_fast = [&](int buf, int step) {
+        const unsigned base = smem_a + buf * C_::kStageBytes + (w * NP * 4) * 256;
+        const bf16_t* yb = ybase0 + step * ystep;
+        const bf16_t* xb = xbase0 + step * xstep;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16_saddr(yoff32[j], yb, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16_saddr(xoff32[j], xb, base + kYTile + j * 1024);
+        if (TAPS == 3 && w == 0) glds16_saddr(xoff32_extra, xb, smem_a + buf * C_::kStageBytes + kYTile + BR * 256);
+    };
+    auto stage = [&](int buf, int step) {
+        const unsigned base = smem_a + buf * C_::kStageBytes + (w * NP * 4) * 256;
+        const int rbase = r0 + step * BR;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const bool ok = rbase + trowy[j] < r1;
+            glds16_asm(ok ? ysrc[j] + step * ystep : zsrc, base + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            // an X row matters only if one of the (up to TAPS) Y rows it meets is in range; everything
+            // else comes from the zero page (never read past the operand; 0 * garbage could be NaN)
+            const bool ok = rbase + trowx[j] - (TAPS - 1) < r1;
+            glds16_asm(ok ? xsrc[j] + step * xstep : zsrc, base + kYTile + j * 1024);
+        }
+        if (TAPS == 3 && w == 0) {
+            const bool ok = rbase + trow_extra - (TAPS - 1) < r1;
+            glds16_asm(ok ? xsrc_extra + step * xstep : zsrc, smem_a + buf * C_::kStageBytes + kYTile + BR * 256);
+        }
+    };
+
+    f32x4_t acc[TAPS][4][CT];   // [tap][n-tile][c-tile]
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // Bias gradient for free: column sums of Y are one more product, Y^T . 1, taken by the waves that own
+    // c-tile 0 of panel group 0 (every (set, split, n-tile) exactly once).
+    const bool do_bias = p.dbias != nullptr && pn == 0 && tc == 0 && wc == 0;
+    f32x4_t bacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t ones = bf16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+    // transposed-read addresses: 16-lane group g covers reduction rows 8g..8g+7 of a 32-row
+    // k-step in two 4-row blocks (h); lane 4q+pp of the group addresses row q, columns 4pp..4pp+3.
+    // For tap t the X rows are shifted by t; the swizzle is a function of the PHYSICAL row, and
+    // (row + 32) has the same swizzle, so kk adds a plain 8192 bytes.
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int y_off[2], x_off[TAPS][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * g + 4 * h + q;
+        y_off[h] = row * 256 + ((((wn * 8) | (pp >> 1)) ^ swz(row)) << 4) + 8 * (pp & 1);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int xr = row + t;
+            x_off[t][h] = kYTile + xr * 256 + ((((wc * CT * 2) | (pp >> 1)) ^ swz(xr)) << 4) + 8 * (pp & 1);
+        }
+    }
+
+    auto load_frags = [&](bf16x8_t (&yf)[4], bf16x8_t (&xf)[TAPS][CT], const char* sb, int kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s16x4_t a0 = tr_read(sb + ((y_off[0] ^ (i << 5)) + kk * 8192));
+            s16x4_t a1 = tr_read(sb + ((y_off[1] ^ (i << 5)) + kk * 8192));
+            yf[i] = bf16x8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                s16x4_t b0 = tr_read(sb + ((x_off[t][0] ^ (i << 5)) + kk * 8192));
+                s16x4_t b1 = tr_read(sb + ((x_off[t][1] ^ (i << 5)) + kk * 8192));
+                xf[t][i] = bf16x8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            }
+    };
+    auto mma_tap = [&](bf16x8_t (&yf)[4], bf16x8_t (&xf)[TAPS][CT], int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[t][j], acc[t][i][j], 0, 0, 0);
+    };
+
+    if constexpr (TAPS == 3) {
+        // Ring of three stage buffers, one barrier per K-step, and the fragment reads run one HALF-step ahead of
+        // the MFMAs in registers -- across the barrier too: the barrier at the bottom of step s comes after every
+        // wave's vmcnt(0) for stage s+2, so stage s+1 (landed one barrier earlier) may be read before it.
+        // Without this each wave exposed an LDS round trip ~6 times per step, and both waves of a SIMD (same
+        // block, same barrier) exposed it at the same time.
+        constexpr int SB = C_::kStageBytes;
+        bf16x8_t yf[2][4], xf[2][TAPS][CT];
+        stage(0, 0);
+        if (steps > 1) stage(1, 1);
+        if (ILV && steps > 2) stage(2, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(yf[0], xf[0], smem, 0);
+        int buf = 0;
+        if constexpr (ILV) {
+            // Interleaved variant: the 20 transposed reads of the NEXT half-step are issued one per MFMA under the 24
+            // MFMAs of this half-step (sched_group_barrier pipeline), in the order the next half-step consumes them, instead
+            // of as one burst between two MFMA bursts -- the two waves of a SIMD are phase-locked by the step barrier, so a
+            // burst of reads leaves the matrix pipe idle in BOTH of them.
+            // One half-step: 24 MFMAs (taps 2, 1, 0) with ONE transposed read of the next half-step's fragments issued
+            // behind each of the first 20, pinned by a scheduling fence per pair.  Read order = consumption order (Y
+            // fragments, then taps 2, 1, 0), so the counted LDS wait in front of the next half-step's first MFMA leaves the
+            // younger reads in flight.  Past the last step the reads fetch a stale buffer: harmless, never used.
+            auto half = [&](bf16x8_t (&yc)[4], bf16x8_t (&xc)[TAPS][CT], bf16x8_t (&yn)[4], bf16x8_t (&xn)[TAPS][CT],
+                            const char* sbn, int kkn) {
+                s16x4_t r0;                                              // the first read of the pair in flight
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yc[i], ones, bacc[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < 24; ++m) {
+                    const int t = 2 - m / 8, i = (m % 8) / CT, j = m % CT;
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yc[i], xc[t][j], acc[t][i][j], 0, 0, 0);
+                    if (m < 20) {
+                        // read m: pair (m >> 1) = fragment, m & 1 = its 4-row half; the fragment is assembled the moment its
+                        // second half is issued, so that both reads land in the fragment's own registers (no copies)
+                        s16x4_t rr;
+                        if (m < 8) {
+                            rr = tr_read(sbn + ((y_off[m & 1] ^ ((m >> 1) << 5)) + kkn * 8192));
+                        } else {
+                            const int q = m - 8, tt = 2 - q / 4, ii = (q % 4) >> 1, h = q & 1;
+                            rr = tr_read(sbn + ((x_off[tt][h] ^ (ii << 5)) + kkn * 8192));
+                        }
+                        if (!(m & 1)) {
+                            r0 = rr;
+                        } else {
+                            const bf16x8_t f = bf16x8_t{r0[0], r0[1], r0[2], r0[3], rr[0], rr[1], rr[2], rr[3]};
+                            if (m < 8) yn[m >> 1] = f;
+                            else { const int q = m - 9; xn[2 - q / 4][(q % 4) >> 1] = f; }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // Ring of FOUR stages here: stage s+3 is issued during step s and only has to have landed at the bottom of step
+            // s+1, so the wait at the bottom of a step is COUNTED (this step's own DMA stays in flight).  The two waves of a
+            // SIMD (w and w + 4) issue their DMA half a step apart: a DMA piece costs 60-180 issue cycles during which the
+            // issuing wave feeds no MFMAs -- staggered, the SIMD's other wave keeps the matrix pipe busy meanwhile.
+            const bool early = w < 4;
+            for (int s = 0; s < steps; ++s) {
+                const int b1 = (buf + 1) & 3, b3 = (buf + 3) & 3;
+                const bool more = s + 3 < steps;
+                // (all rows of step s + 3 in range: its Y rows and the X rows two past them)
+                const bool fast = full_tile && r0 + (s + 4) * BR + 4 <= r1;
+                if (more && early) { if (fast) stage_fast(b3, s + 3); else stage(b3, s + 3); }
+                __builtin_amdgcn_sched_barrier(0);
+                half(yf[0], xf[0], yf[1], xf[1], smem + buf * SB, 1);
+                if (more && !early) { if (fast) stage_fast(b3, s + 3); else stage(b3, s + 3); }
+                __builtin_amdgcn_sched_barrier(0);
+                half(yf[1], xf[1], yf[0], xf[0], smem + b1 * SB, 0);
+                if (more) {
+                    if (w == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP + 1) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                buf = b1;
+            }
+        } else
+        for (int s = 0; s < steps; ++s) {
+            const int b1 = buf + 1 == 3 ? 0 : buf + 1, b2 = b1 + 1 == 3 ? 0 : b1 + 1;
+            if (s + 2 < steps) {
+                if (full_tile && r0 + (s + 3) * BR + 4 <= r1) stage_fast(b2, s + 2); else stage(b2, s + 2);
+            }
+            const char* sb = smem + buf * SB;
+            const char* sbn = smem + b1 * SB;
+            // half-step kk = 0
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[0][i], ones, bacc[i], 0, 0, 0);
+            }
+            // taps in REVERSE load order: the first MFMAs need the last-loaded fragment, so the compiler's wait
+            // there is lgkmcnt(0) and no older read is outstanding when the next 20 are issued (lgkmcnt counts
+            // to 15 only; a capped wait would force some of the NEW reads to land before the MFMAs below)
+            mma_tap(yf[0], xf[0], 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(yf[1], xf[1], sb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(yf[0], xf[0], 1);
+            mma_tap(yf[0], xf[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // half-step kk = 1
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[1][i], ones, bacc[i], 0, 0, 0);
+            }
+            mma_tap(yf[1], xf[1], 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < steps) load_frags(yf[0], xf[0], sbn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(yf[1], xf[1], 1);
+            mma_tap(yf[1], xf[1], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            buf = b1;
+        }
+    } else {
+        // One barrier per K-step (see gemm_nt.hip): wait own DMA + own LDS reads, barrier, restage, compute.
+        stage(0, 0);
+        for (int s = 0; s < steps; ++s) {
+            const int buf = s & 1;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < steps) {
+                if (full_tile && r0 + (s + 2) * BR + 4 <= r1) stage_fast(buf ^ 1, s + 1); else stage(buf ^ 1, s + 1);
+            }
+            const char* sb = smem + buf * C_::kStageBytes;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t yf[4], xf[TAPS][CT];
+                load_frags(yf, xf, sb, kk);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, bacc[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) mma_tap(yf, xf, t);
+            }
+        }
+    }
+
+    if (do_bias && (lane & 15) == 0) {      // every column of bacc holds the same sums; lane&15 == 0 keeps column 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                if (n < p.N) {
+                    atomicAdd(p.dbias + (long)set * p.set_stride + n, bacc[i][r]);
+                    if (p.dbias2) atomicAdd(p.dbias2 + (long)set * p.set_stride + n, bacc[i][r]);
+                }
+            }
+    }
+    // acc[t][i][j][r]: n = n0 + wn*64 + i*16 + (lane>>4)*4 + r, c = c0 + wc*64 + j*16 + (lane&15)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        float* out = p.dW + (long)set * p.set_stride + (long)(pn + t) * p.N * p.ldw;
+        if (p.rmw) {
+            // one split: this block OWNS the tile -- plain read-add-write (deterministic; float atomics execute at
+            // the memory side at ~1.3 TB/s chip-wide and dominate the small layers).  All loads of a tap are issued
+            // before the first store (the compiler cannot prove the addresses distinct and would serialise them).
+            float old[4][CT][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int c = c0 + wc * CT * 16 + j * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                        old[i][j][r] = (p.rmw == 1 && n < p.N && c < p.C) ? out[(long)n * p.ldw + c] : 0.f;   // rmw 2: overwrite
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int c = c0 + wc * CT * 16 + j * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                        if (n < p.N && c < p.C) out[(long)n * p.ldw + c] = old[i][j][r] + acc[t][i][j][r];
+                    }
+                }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int c = c0 + wc * CT * 16 + j * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                    if (n < p.N && c < p.C) atomicAdd(out + (long)n * p.ldw + c, acc[t][i][j][r]);
+                }
+            }
+    }
+}
+
+template <int TAPS, bool ILV = false>
+__global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const TNParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn_body<TAPS, ILV>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One-tap products with long reductions (transformer linears, 1x1 shortcuts): producer / consumer form, tile 128(n) x 256(c).
+//
+// The 128 x 128 tile above is LDS-bound by construction: per 64-row step its two blocks per CU move 64 KiB of LDS-DMA writes +
+// 128 KiB of transposed fragment reads through a 128 B/clk LDS pipe (1536 clk) for 1024 clk of MFMA per SIMD -- 830-880 TF/s
+// measured, 1130 the ceiling.  A wider tile in the same one-role form (tools/probes/gemm_tn_wide.hip) lost what it gained on LDS
+// traffic to DMA issue: every LDS-DMA piece blocks the issuing wave's MFMAs for 60-180 cycles.  Here, as in gemm_nt_c3p:
+//   waves 0-3  consumers, one per SIMD: 64(n) x 128(c) wave tiles (4 x 8 accumulators = 128 registers), 24 transposed reads per 32
+//              MFMAs and 32 reduction rows, issued one or two per MFMA a half-stage ahead of their use;
+//   waves 4-7  producers: the LDS-DMA of every stage (Y 8 KiB + two X sub-tiles of 8 KiB per 32 rows), six pieces per wave and stage.
+// Per stage a CU moves 24 KiB of DMA + 48 KiB of reads = 576 clk of LDS pipe against 512-605 clk of MFMA (a lone wave issues an MFMA
+// every ~19 clk, not 16).  Ring of six 24-KiB stages; ONE barrier per stage shared by all eight waves:
+//   at barrier s (the start of the consumers' stage s) stages <= s + 1 have landed (the producers waited, counted) and the slots of
+//   stages <= s - 1 are free (every consumer's reads of them were complete at its previous barrier), so the producers then issue
+//   stage s - 1 + 6 -- three stages (~1800 clk) before it must have landed.
+#ifndef PC_ABLATE
+#define PC_ABLATE 0
+#endif
+constexpr int PC_ROWS = 32, PC_SUB = PC_ROWS * 256, PC_STAGE = 3 * PC_SUB, PC_RING = 6, PC_COLS = 2 * BC, PC_THREADS = 512;
+constexpr int PC_SMEM = PC_RING * PC_STAGE;                          // 147,456
+__device__ __forceinline__ void pc_barrier() { asm volatile("s_barrier" ::: "memory"); }   // (no implicit vmcnt(0): every wait here is explicit)
+
+__device__ __forceinline__ void tn_pc_body(const TNParams& p, int bid, const int nwg, char* smem) {
+    constexpr int HR = PC_ROWS, SUB = PC_SUB, SB = PC_STAGE, R = PC_RING;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_c = (p.C + PC_COLS - 1) / PC_COLS, tiles_n = (p.N + BN - 1) / BN;
+    {   // contiguous runs of logical blocks per XCD (see tn_body)
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int pn = bid % p.npanels; bid /= p.npanels;
+    const int tile = bid % (tiles_c * tiles_n); bid /= tiles_c * tiles_n;
+    const int split = bid % p.nsplits;
+    const int set = bid / p.nsplits;
+    const int tn = tile / tiles_c, tc = tile - tn * tiles_c;
+    const int n0 = tn * BN, c0 = tc * PC_COLS;
+    const int r0 = p.row_begin + split * p.rows_per_split;
+    int r1 = r0 + p.rows_per_split; r1 = r1 < p.row_end ? r1 : p.row_end;
+    if (r0 >= r1) return;                                           // (block-uniform)
+    const int S = (r1 - r0 + HR - 1) / HR;                          // stages
+
+    if (w >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pw = w - 4;
+        const unsigned smem_a = lds_addr(smem);
+        const bf16_t* zsrc = p.zero_page + (lane & 15) * 8;
+        const long xrow0 = (long)set * p.x_set_rows + r0 + p.shift[pn];
+        const bf16_t* const ybase0 = p.Y + ((long)set * p.rows_per_set + r0) * p.ldy + n0;
+        const bf16_t* const xbase0 = p.X + xrow0 * p.ldx + p.coff[pn] + c0;
+        const long ystep = (long)HR * p.ldy, xstep = (long)HR * p.ldx;
+        const bool full_tile = n0 + BN <= p.N && c0 + PC_COLS <= p.C;
+        // this wave's two 4-row pieces (pieces 2 pw, 2 pw + 1 of the stage's eight) of Y and of each X sub-tile
+        int prow[2]; unsigned yoff32[2], xoff32[2]; bool ycol[2], xcol[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            prow[j] = (2 * pw + j) * 4 + (lane >> 4);
+            const int lc = (lane & 15) ^ swz(prow[j]);
+            yoff32[j] = (unsigned)(((long)prow[j] * p.ldy + lc * 8) * 2);
+            xoff32[j] = (unsigned)(((long)prow[j] * p.ldx + lc * 8) * 2);
+            ycol[j] = n0 + lc * 8 < p.N;
+            xcol[j][0] = c0 + lc * 8 < p.C; xcol[j][1] = c0 + BC + lc * 8 < p.C;
+        }
+        auto issue = [&](int st) {
+            const unsigned base = smem_a + (st % R) * SB + (2 * pw) * 1024;
+            const bf16_t* yb = ybase0 + st * ystep;
+            const bf16_t* xb = xbase0 + st * xstep;
+            if (full_tile && r0 + (st + 1) * HR <= r1) {           // every row and column in range: wave-uniform base + 32-bit lane offsets
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    glds16_saddr(yoff32[j], yb, base + j * 1024);
+                    glds16_saddr(xoff32[j], xb, base + SUB + j * 1024);
+                    glds16_saddr(xoff32[j], xb + BC, base + 2 * SUB + j * 1024);
+                }
+            } else {                                                // rows past the range / columns past N, C: the zero page for BOTH operands
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool rok = r0 + st * HR + prow[j] < r1;
+                    glds16_asm(rok && ycol[j] ? (const bf16_t*)((const char*)yb + yoff32[j]) : zsrc, base + j * 1024);
+                    glds16_asm(rok && xcol[j][0] ? (const bf16_t*)((const char*)xb + xoff32[j]) : zsrc, base + SUB + j * 1024);
+                    glds16_asm(rok && xcol[j][1] ? (const bf16_t*)((const char*)(xb + BC) + xoff32[j]) : zsrc, base + 2 * SUB + j * 1024);
+                }
+            }
+        };
+        // wait until at most `stages` of this wave's newest stages (six pieces each) are still in flight
+        auto wait_stages = [&](int stages) {
+            if (stages >= 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if (stages == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (stages == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        int issued = 0;                                             // stages issued so far
+        for (; issued < R && issued < S; ++issued) issue(issued);
+        {   // barrier 0: stages 0 and 1 have landed
+            int out = issued - 2; if (out < 0) out = 0;
+            if (out >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else wait_stages(out);
+            pc_barrier();
+        }
+        for (int s = 0; s < S; ++s) {
+            // past barrier s: the slot of stage s - 1 is free
+            if (s >= 1 && issued < S) { if (!(PC_ABLATE & 1)) issue(issued); ++issued; }
+            // barrier s + 1 promises stages <= s + 2: whatever was issued after them may stay in flight
+            int out = issued - (s + 3); if (out < 0) out = 0;
+            wait_stages(out);
+            pc_barrier();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wn = w >> 1, wc = w & 1;                              // wave tile: n rows [wn * 64, +64) x X sub-tile wc (128 c)
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // transposed-read addresses (see tn_body): 16-lane group g covers rows 8g..8g+7 of the 32-row stage in two 4-row blocks.
+    // Address arithmetic is vector work in a wave that is alone on its SIMD (every vector instruction costs it ~4 issue cycles,
+    // an MFMA slot is 16): the 24 per-lane tile addresses are held for a PAIR of ring slots (the second slot of the pair is the
+    // instruction's immediate offset) and rebuilt every other stage as (per-lane base + pair base) ^ (tile << 5) -- one vector
+    // instruction each; the XOR may follow the add because every base is a multiple of 256 bytes (checked below for the LDS base).
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned sbase = lds_addr(smem);
+    if (sbase & 255u) __builtin_trap();
+    unsigned y_off[2], x_off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * g + 4 * h + q;
+        y_off[h] = sbase + row * 256 + ((((wn * 8) | (pp >> 1)) ^ swz(row)) << 4) + 8 * (pp & 1);
+        x_off[h] = sbase + (1 + wc) * SUB + row * 256 + (((pp >> 1) ^ swz(row)) << 4) + 8 * (pp & 1);
+    }
+    typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
+    unsigned ayn[2][4], axa[2][4], axb[2][4];                      // next stage's Y / c tiles 0-3, this stage's c tiles 4-7
+    auto set_next = [&](unsigned pair_base) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ayn[h][t] = (y_off[h] + pair_base) ^ (t << 5); axa[h][t] = (x_off[h] + pair_base) ^ (t << 5); }
+    };
+    auto set_cur = [&](unsigned pair_base) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) axb[h][t] = (x_off[h] + pair_base) ^ ((4 + t) << 5);
+    };
+    bf16x8_t y[4], xa[4], xb[4];
+    // One stage (K = its ring slot, a compile-time constant: the loop below is unrolled over the ring): block A = 16 MFMAs of c tiles
+    // 0-3 with this stage's c tiles 4-7 read behind the first eight (one transposed read per MFMA slot); block B = 16 MFMAs of c
+    // tiles 4-7 with the NEXT stage's c tiles 0-3 behind the first eight and the next stage's Y fragment i right behind the last MFMA
+    // that uses the current one (ONE set of Y registers: 128 accumulators + three fragment sets + 24 addresses fill the wave's 256).
+    // Reads of slot s + 1 may still be in flight at the barrier that ends stage s: that slot is not refilled before the barrier
+    // after it, and by then every read of it has been consumed.  Past the last stage the reads fetch a stale slot: never used.
+    auto stage = [&](auto K) {
+        constexpr int k = decltype(K)::value;
+        constexpr int imm_cur = (k & 1) * SB, imm_next = ((k + 1) & 1) * SB;
+        if constexpr ((k & 1) == 0) set_cur((k / 2) * 2 * SB);
+        else set_next((((k + 1) % R) / 2) * 2 * SB);
+        s16x4_t r0v;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int i = m >> 2, j = m & 3;
+            if (!(PC_ABLATE & 8)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[i], xa[j], acc[i][j], 0, 0, 0);
+            if (m < 8 && !(PC_ABLATE & 2)) {
+                const int f = m >> 1, h = m & 1;                    // fragment, 4-row half
+                const s16x4_t rr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(axb[h][f] + imm_cur));
+                if (!h) r0v = rr;
+                else xb[f] = bf16x8_t{r0v[0], r0v[1], r0v[2], r0v[3], rr[0], rr[1], rr[2], rr[3]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int i = m >> 2, j = m & 3;
+            if (!(PC_ABLATE & 8)) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y[i], xb[j], acc[i][4 + j], 0, 0, 0);
+            if (!(PC_ABLATE & 2)) {
+                if (m < 8) {
+                    const int f = m >> 1, h = m & 1;
+                    const s16x4_t rr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(axa[h][f] + imm_next));
+                    if (!h) r0v = rr;
+                    else xa[f] = bf16x8_t{r0v[0], r0v[1], r0v[2], r0v[3], rr[0], rr[1], rr[2], rr[3]};   // (xa's last use was block A)
+                }
+                if (j == 3) {                                       // y[i] is dead: the next stage's fragment takes its registers
+                    const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(ayn[0][i] + imm_next));
+                    const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(ayn[1][i] + imm_next));
+                    y[i] = bf16x8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pc_barrier();
+    };
+    pc_barrier();                                                   // barrier 0: stages 0 and 1 are in LDS
+    set_next(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)ayn[0][i]);
+        const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)ayn[1][i]);
+        y[i] = bf16x8_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)axa[0][i]);
+        const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)axa[1][i]);
+        xa[i] = bf16x8_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+    using std::integral_constant;
+    for (int s = 0; s < S; s += R) {                                // (R = 6 stages per trip: ring slots 0..5)
+        stage(integral_constant<int, 0>{});
+        if (s + 1 < S) stage(integral_constant<int, 1>{});
+        if (s + 2 < S) stage(integral_constant<int, 2>{});
+        if (s + 3 < S) stage(integral_constant<int, 3>{});
+        if (s + 4 < S) stage(integral_constant<int, 4>{});
+        if (s + 5 < S) stage(integral_constant<int, 5>{});
+    }
+    // (reads of the stale slot issued by the last stage land in dead registers; nothing waits for them)
+
+    // acc[i][j][r]: n = n0 + wn*64 + i*16 + (lane>>4)*4 + r, c = c0 + wc*128 + j*16 + (lane&15)
+    float* out = p.dW + (long)set * p.set_stride + (long)pn * p.N * p.ldw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (p.rmw) {                                                // this block owns the tile: plain read-add-write (rmw 2: overwrite)
+            float old[8][4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + wc * BC + j * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                    old[j][r] = (p.rmw == 1 && n < p.N && c < p.C) ? out[(long)n * p.ldw + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + wc * BC + j * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                    if (n < p.N && c < p.C) out[(long)n * p.ldw + c] = old[j][r] + acc[i][j][r];
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + wc * BC + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
+                if (n < p.N && c < p.C) atomicAdd(out + (long)n * p.ldw + c, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(PC_THREADS, 1) void gemm_tn_pc_kernel(const TNParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tn_pc_body(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Several independent products in ONE launch (the low-resolution weight gradients: each of them alone leaves most CUs idle
+// and pays a launch's fixed latency; together they fill the chip).  Job j owns blocks [first[j], first[j+1]); first[] are
+// multiples of 8 so that a job's blocks keep their XCD (block index mod 8) -- the surplus blocks of a job exit at once.
+constexpr int kMaxJobs = 14;
+struct TNGroup {
+    int njobs;
+    int first[kMaxJobs + 1];
+    int nwg[kMaxJobs];
+    TNParams job[kMaxJobs];
+};
+static_assert(sizeof(TNGroup) <= 4096, "kernel arguments are limited to 4 KiB");
+
+template <int TAPS>
+__global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_grouped_kernel(const TNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int j = 0;
+    while (j + 1 < g.njobs && (int)blockIdx.x >= g.first[j + 1]) ++j;
+    const int bid = blockIdx.x - g.first[j];
+    if (bid >= g.nwg[j]) return;
+    tn_body<TAPS, TAPS == 3>(g.job[j], bid, g.nwg[j], smem);      // 3 taps: the interleaved variant (4-deep ring)
+}
+
+__global__ __launch_bounds__(PC_THREADS, 1) void gemm_tn_pc_grouped_kernel(const TNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int j = 0;
+    while (j + 1 < g.njobs && (int)blockIdx.x >= g.first[j + 1]) ++j;
+    const int bid = blockIdx.x - g.first[j];
+    if (bid >= g.nwg[j]) return;
+    tn_pc_body(g.job[j], bid, g.nwg[j], smem);
+}
+
+template <int TAPS>
+int launch_tn(const TNParams& p, hipStream_t st) {
+    using C_ = TCfg<TAPS>;
+    static unsigned char attr_set[kMaxDevices], attr_ilv[kMaxDevices];
+    siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
+    dim3 grid(cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits);
+    if constexpr (TAPS == 3) {                             // fragment reads interleaved with the MFMAs: measured +5 % (996 -> 1044, 1057 -> 1112 TF/s)
+        constexpr int smem_ilv = TCfg<3, true>::kSmemBytes;
+        if (siss_ensure_smem((const void*)gemm_tn_kernel<3, true>, smem_ilv, attr_ilv) != SISS_OK) return SISS_ERR_LAUNCH;
+        gemm_tn_kernel<3, true><<<grid, C_::kThreads, smem_ilv, st>>>(p);
+    } else {
+        if (siss_ensure_smem((const void*)gemm_tn_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+        gemm_tn_kernel<TAPS><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
+    }
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+}
+
+int launch_tn_pc(const TNParams& p, hipStream_t st) {
+    static unsigned char attr_set[kMaxDevices];
+    siss_count_dispatch(SISS_K_TNPC);
+    if (siss_ensure_smem((const void*)gemm_tn_pc_kernel, PC_SMEM, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    dim3 grid(cdiv(p.N, BN) * cdiv(p.C, PC_COLS) * p.npanels * p.nsets * p.nsplits);
+    gemm_tn_pc_kernel<<<grid, PC_THREADS, PC_SMEM, st>>>(p);
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+}
+
+// Which kernel runs a product -- and, for the producer / consumer one-tap kernel, how its columns are cut: whole 256-column blocks go
+// to tn_pc_body, a remainder of at most 128 columns to the 128 x 128 tile (a larger one stays in a masked 256-column block).  A slice
+// is the same product on a column range of X and dW (ldw keeps dW's row stride); only the first slice forms the bias gradient.
+enum TNVariant { TN_T3 = 0, TN_T1, TN_PC, TN_NVARIANTS };
+int g_pc_min_rows = 4096;
+
+static TNParams tn_slice(const TNParams& p, int cs, int cw, bool first) {
+    TNParams q = p;
+    q.X = p.X + cs; q.dW = p.dW + cs; q.C = cw;
+    if (!first) { q.dbias = nullptr; q.dbias2 = nullptr; }
+    return q;
+}
+
+static int tn_plan(const TNParams& p, bool fused3, TNVariant (&v)[2], TNParams (&q)[2]) {
+    if (fused3) { v[0] = TN_T3; q[0] = p; return 1; }
+    const int rows = p.row_end - p.row_begin;
+    if (p.C < 256 || rows < g_pc_min_rows) { v[0] = TN_T1; q[0] = p; return 1; }
+    if (p.dbias) {
+        // the producer / consumer kernel has no registers left for the bias gradient's accumulators: with a bias, the last 1..256
+        // columns go to the 128 x 128 tile, which forms it (320 -> 256 + 64, 640 -> 512 + 128, 1280 -> 1024 + 256)
+        const int cpc = (p.C - 1) / PC_COLS * PC_COLS;
+        if (cpc == 0) { v[0] = TN_T1; q[0] = p; return 1; }
+        v[0] = TN_PC; q[0] = tn_slice(p, 0, cpc, false);
+        v[1] = TN_T1; q[1] = tn_slice(p, cpc, p.C - cpc, true);
+        return 2;
+    }
+    const int k2 = p.C / PC_COLS, rem = p.C - PC_COLS * k2;
+    if (rem == 0 || rem > BC) { v[0] = TN_PC; q[0] = p; return 1; }
+    v[0] = TN_PC; q[0] = tn_slice(p, 0, PC_COLS * k2, true);
+    v[1] = TN_T1; q[1] = tn_slice(p, PC_COLS * k2, rem, false);
+    return 2;
+}
+
+}  // namespace
+
+// argument list of siss_gemm_tn as a struct (include/siss_hip.h declares the same layout)
+struct siss_tn_job {
+    const void* Y; long ldy; const void* X; long ldx; float* dW; long set_stride;
+    int N, C, npanels, nsets, rows_per_set, row_begin, row_end, nsplits;
+    long x_set_rows;
+    const void* zero_page; float* dbias; float* dbias2;
+    int shifts[9]; int coffs[9];
+};
+
+static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
+                    int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
+                    long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
+                    float* dbias, float* dbias2, bool grouped, TNParams& p, bool& fused3_out) {
+    SISS_CHECK_ARG(Y && X && dW && shifts && coffs && zero_page);
+    SISS_CHECK_ARG(N > 0 && C > 0 && npanels >= 1 && npanels <= kMaxPanels && nsets >= 1);
+    SISS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && C % 8 == 0);   // N may be ragged (masked at the store)
+    SISS_CHECK_ARG(((uintptr_t)Y | (uintptr_t)X | (uintptr_t)zero_page) % 16 == 0 && (uintptr_t)dW % 4 == 0);
+    SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set);
+    p.Y = (const bf16_t*)Y; p.X = (const bf16_t*)X; p.dW = dW; p.zero_page = (const bf16_t*)zero_page;
+    p.dbias = dbias; p.dbias2 = dbias ? dbias2 : nullptr;
+    p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.x_set_rows = x_set_rows; p.ldw = C;
+    p.N = N; p.C = C; p.npanels = npanels; p.nsets = nsets;
+    p.rows_per_set = rows_per_set; p.row_begin = row_begin; p.row_end = row_end;
+    for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
+    for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 8 == 0);
+    // 3x3 filter rows: panels come in triples whose shifts are consecutive rows with equal channel offsets
+    bool triples = npanels % 3 == 0;
+    for (int g = 0; triples && g < npanels / 3; ++g)
+        triples = p.shift[3 * g + 1] == p.shift[3 * g] + 1 && p.shift[3 * g + 2] == p.shift[3 * g] + 2 &&
+                  p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
+    bool fused3 = triples;
+    const int rows = row_end - row_begin;
+    const bool overwrite = nsplits == -1;                  // one split per tile, dW = product (no read, no zero fill needed)
+    if (overwrite) nsplits = 1;
+    const bool automatic = nsplits <= 0;
+    if (grouped && nsplits <= 0) {
+        // a grouped launch fills the chip with OTHER jobs' blocks: no split for occupancy's sake; splits only bound a
+        // block's K loop (128 steps of 64 rows), and the fused 3-tap variant is always the better one (X read once).
+        // Measured (round 3, same box, 32 / 64 / 128 / 256 steps): SD v1.5 B = 16 146.7 / 143.8 / 142.5 / 143.1 ms,
+        // B = 4 56.4 / 55.9 / 55.7 / 56.1 ms, CelebA-HQ 58.40 / 58.29 / 58.30 / 58.31 ms -- every split re-adds a
+        // 64 KiB tile through float atomics, and the transformer linears reduce over 65 k rows per set.
+        nsplits = cdiv(rows, 128 * BR);
+        if (nsplits < 1) nsplits = 1;
+    }
+    if (nsplits <= 0) {
+        // Auto: pick (kernel variant, split count) by a small cost model (us), measured constants:
+        //   a block's K-step (64 rows): 1.5 us for the 3-tap kernel (one 8-wave block per CU), 0.6 us for the
+        //   one-tap kernel alone on a CU, 1.0 us with a second block beside it;
+        //   every split adds the whole dW once more through float atomics (~1.3 TB/s chip-wide), a single split
+        //   owns its tile and read-add-writes it with plain accesses.
+        // The one-tap variant is only considered for short reductions (the 8x8 / 16x16 layers), where it puts 3x the
+        // blocks on the chip without any split; on long reductions it re-reads X three times.
+        const double bytes = (double)nsets * npanels * N * C * 4.0;
+        const long tiles = (long)cdiv(N, BN) * cdiv(C, BC);
+        double best = 1e30;
+        int best_ns = 1;
+        bool best_f3 = fused3;
+        for (int v = 0; v < 2; ++v) {
+            const bool f3 = v == 0;
+            if (f3 && !fused3) continue;
+            if (!f3 && fused3 && rows >= 8192) continue;
+            const long base = tiles * (f3 ? npanels / 3 : npanels) * nsets;
+            const long slots = f3 ? 256 : 512;
+            const int max_ns = rows / 256 > 1 ? rows / 256 : 1;
+            for (int ns = 1; ns <= max_ns && ns <= 1024; ++ns) {
+                const long blocks = base * ns;
+                const long rounds = cdiv(blocks, slots);
+                if (rounds > 1 && ns > 1) break;           // never split into a second round
+                const double tstep = f3 ? 1.5 : (blocks <= 256 ? 0.6 : 1.0);
+                const double t = (double)rounds * cdiv(cdiv(rows, ns), BR) * tstep +
+                                 (ns > 1 ? ns * bytes / 1.3e6 : 2.0 * bytes / 4.0e6);
+                if (t < best) { best = t; best_ns = ns; best_f3 = f3; }
+            }
+        }
+        nsplits = best_ns;
+        fused3 = best_f3;
+    }
+    p.nsplits = nsplits;
+    p.rmw = overwrite ? 2 : (automatic && nsplits == 1 ? 1 : 0);
+    int rps = cdiv(rows, nsplits);
+    rps = cdiv(rps, BR) * BR;
+    p.rows_per_split = rps;
+    fused3_out = fused3;
+    return SISS_OK;
+}
+
+template <typename Kernel>
+static int launch_group(Kernel kernel, int smem, int threads, unsigned char (&attr_set)[kMaxDevices], int cols, int taps, int kid,
+                        const TNParams* ps, int n, hipStream_t st) {
+    if (siss_ensure_smem((const void*)kernel, smem, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    for (int i0 = 0; i0 < n; i0 += kMaxJobs) {
+        TNGroup g;
+        g.njobs = n - i0 < kMaxJobs ? n - i0 : kMaxJobs;
+        int total = 0;
+        for (int j = 0; j < g.njobs; ++j) {
+            const TNParams& p = ps[i0 + j];
+            g.job[j] = p;
+            g.first[j] = total;
+            g.nwg[j] = cdiv(p.N, BN) * cdiv(p.C, cols) * (p.npanels / taps) * p.nsets * p.nsplits;
+            total += (g.nwg[j] + 7) & ~7;
+            siss_count_dispatch(kid);
+        }
+        g.first[g.njobs] = total;
+        kernel<<<dim3(total), threads, smem, st>>>(g);
+    }
+    return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
+}
+
+static int launch_variant_group(int v, const TNParams* ps, int n, hipStream_t st) {
+    static unsigned char attr[TN_NVARIANTS][kMaxDevices];
+    switch (v) {
+    case TN_T3: return launch_group(gemm_tn_grouped_kernel<3>, TCfg<3, true>::kSmemBytes, TCfg<3>::kThreads, attr[v], BC, 3, SISS_K_TN3, ps, n, st);
+    case TN_T1: return launch_group(gemm_tn_grouped_kernel<1>, TCfg<1>::kSmemBytes, TCfg<1>::kThreads, attr[v], BC, 1, SISS_K_TN1, ps, n, st);
+    default:    return launch_group(gemm_tn_pc_grouped_kernel, PC_SMEM, PC_THREADS, attr[v], PC_COLS, 1, SISS_K_TNPC, ps, n, st);
+    }
+}
+
+extern "C" {
+
+// dW must be zeroed (or hold the running sum for gradient accumulation) before the call.
+// dbias / dbias2 (optional): dbias[set*set_stride + n] += sum over the set's rows of Y[r][n].
+// Rows [row_begin, row_end) of every set are reduced; shifts/coffs are HOST arrays.
+// nsplits == 0: choose the kernel variant and the split count here (cost model below); when that lands on one split
+// the block that owns a tile read-add-writes it with plain accesses instead of atomics.
+// nsplits == -1: one split per tile and dW is OVERWRITTEN with the product (no accumulation: the caller needs no zero
+// fill; attention dK / dV).
+int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
+                 int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
+                 long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
+                 float* dbias, float* dbias2, void* stream) {
+    TNParams p;
+    bool fused3 = false;
+    const int rc = tn_setup(Y, ldy, X, ldx, dW, set_stride, N, C, npanels, shifts, coffs, nsets, rows_per_set, x_set_rows,
+                            row_begin, row_end, nsplits, zero_page, dbias, dbias2, false, p, fused3);
+    if (rc != SISS_OK) return rc;
+    if (fused3) return launch_tn<3>(p, (hipStream_t)stream);
+    TNVariant v[2];
+    TNParams q[2];
+    const int nq = tn_plan(p, false, v, q);
+    if (nq == 1 && v[0] == TN_T1) return launch_tn<1>(p, (hipStream_t)stream);
+    for (int i = 0; i < nq; ++i) {
+        if (nsplits == 0) {
+            // a producer / consumer block owns a CU (8 waves, 144 KiB of LDS): as many splits as fill 256 CUs a whole number of
+            // times, blocks of at most ~16 k reduction rows
+            const int rows = row_end - row_begin;
+            const int cols = v[i] == TN_PC ? PC_COLS : BC;
+            const long base = (long)cdiv(q[i].N, BN) * cdiv(q[i].C, cols) * q[i].npanels * q[i].nsets;
+            const long k = cdiv(base * cdiv(rows, 16384), 256);
+            long ns = 256 * k / base;
+            if (ns < 1) ns = 1;
+            if (ns > rows / 256) ns = rows / 256 > 1 ? rows / 256 : 1;
+            q[i].nsplits = (int)ns;
+            q[i].rmw = ns == 1 ? 1 : 0;
+            q[i].rows_per_split = cdiv(cdiv(rows, ns), BR) * BR;
+        }
+        const int rc2 = v[i] == TN_PC ? launch_tn_pc(q[i], (hipStream_t)stream) : launch_tn<1>(q[i], (hipStream_t)stream);
+        if (rc2 != SISS_OK) return rc2;
+    }
+    return SISS_OK;
+}
+
+// One-panel reductions shorter than this (or narrower than 256 columns) stay on the 128 x 128 tile, which puts twice the blocks on
+// the chip; default 4096 rows.  Returns the previous value (rows <= 0: query only).
+int siss_gemm_tn_set_pc_min_rows(int rows) { const int old = g_pc_min_rows; if (rows > 0) g_pc_min_rows = rows; return old; }
+
+// The same product for `njobs` independent problems in ONE launch per kernel variant (job table passed by value as kernel
+// arguments: nothing is copied to the device, hipGraph-safe).  jobs: HOST array of siss_tn_job (the argument list of
+// siss_gemm_tn as a struct, shifts / coffs inline).  Meant for the low-resolution weight gradients: each of them alone leaves
+// most CUs idle and pays a launch's fixed latency.  All operands must stay valid until the launch has run.
+int siss_gemm_tn_grouped(const void* jobs, int njobs, void* stream) {
+    SISS_CHECK_ARG(jobs && njobs > 0 && njobs <= 256);
+    const siss_tn_job* js = (const siss_tn_job*)jobs;
+    static thread_local std::vector<TNParams> ps[TN_NVARIANTS];
+    for (auto& v : ps) v.clear();
+    for (int i = 0; i < njobs; ++i) {
+        const siss_tn_job& j = js[i];
+        TNParams p;
+        bool fused3 = false;
+        const int rc = tn_setup(j.Y, j.ldy, j.X, j.ldx, j.dW, j.set_stride, j.N, j.C, j.npanels, j.shifts, j.coffs, j.nsets,
+                                j.rows_per_set, j.x_set_rows, j.row_begin, j.row_end, j.nsplits, j.zero_page, j.dbias, j.dbias2,
+                                true, p, fused3);
+        if (rc != SISS_OK) return rc;
+        TNVariant v[2];
+        TNParams q[2];
+        const int nq = tn_plan(p, fused3, v, q);
+        for (int k = 0; k < nq; ++k) ps[v[k]].push_back(q[k]);
+    }
+    for (int v = 0; v < TN_NVARIANTS; ++v)
+        if (!ps[v].empty()) {
+            const int rc = launch_variant_group(v, ps[v].data(), (int)ps[v].size(), (hipStream_t)stream);
+            if (rc != SISS_OK) return rc;
+        }
+    return SISS_OK;
+}
+
+
+}  // extern "C"

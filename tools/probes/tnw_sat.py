@@ -13,7 +13,7 @@ job = lib.TNJob(Y=y.data_ptr(), ldy=N, X=x.data_ptr(), ldx=C, dW=dW.data_ptr(), 
                 rows_per_set=rows, row_begin=0, row_end=rows, nsplits=0, x_set_rows=0, zero_page=zp.data_ptr(), dbias=None, dbias2=None, shifts=z9, coffs=z9)
 arr = (lib.TNJob * 1)(job)
 for wide in (True, False):
-    lib.query("siss_gemm_tn_set_wide_min_rows", 4096 if wide else 1 << 30)
+    lib.query("siss_gemm_tn_set_pc_min_rows", 4096 if wide else 1 << 30)
     for _ in range(3): lib.call("siss_gemm_tn_grouped", arr, 1)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
