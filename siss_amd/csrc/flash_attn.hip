@@ -44,9 +44,11 @@ template <int DP> struct FA {
     // f(row): XOR on the 16-B chunk index.  Row-major fragment reads (16 rows, one chunk column per quarter wave) need the 16
     // (row, chunk) pairs on 16 distinct 16-B bank groups; transposed reads (8 rows x one 32-B column per half wave) need 8
     // distinct 32-B bank groups.  RS = 128: rows alternate between the two halves of the 256-B bank period.
-    __device__ static __forceinline__ int swz(int row) {
-        return RS == 128 ? ((((row >> 1) & 3) << 1) | ((row >> 3) & 1)) : (((row & 7) << 1) | ((row >> 3) & 1));
-    }
+    // (Checked against the lane groups the LDS really serves -- a ds_read_b128 goes in four groups of 16 NON-contiguous lanes,
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- for the row-major reads, the transposed reads (2 x 32 lanes)
+    // and the tile stores (8 x 8 lanes): these two forms are conflict-free for all three.  The earlier forms, which also folded
+    // row bit 3 into chunk bit 0, made every row-major read 2-way conflicted: SQ_LDS_BANK_CONFLICT was 31-35 % of SQ_LDS_IDX_ACTIVE.)
+    __device__ static __forceinline__ int swz(int row) { return RS == 128 ? (row & 6) : ((row & 7) << 1); }
     __device__ static __forceinline__ int off(int row, int chunk) { return row * RS + ((chunk ^ swz(row)) << 4); }
 };
 
@@ -65,14 +67,15 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ g, long ld,
         r.v[i] = (row < rows && c < dch) ? *reinterpret_cast<const u32x4_t*>(g + (long)row * ld + c * 8) : u32x4_t{0u, 0u, 0u, 0u};
     }
 }
+// skip_c: a chunk column somebody else writes (the augmented column of a Q / dO tile: dK / dV kernel), -1: none
 template <int DP>
-__device__ __forceinline__ void tile_store(const TileRegs<DP>& r, char* lds, int tid) {
+__device__ __forceinline__ void tile_store(const TileRegs<DP>& r, char* lds, int tid, int skip_c = -1) {
     using F = FA<DP>;
 #pragma unroll
     for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i) {
         const int idx = i * kThreadsFA + tid;
         const int row = idx / F::CH, c = idx - row * F::CH;
-        *reinterpret_cast<u32x4_t*>(lds + F::off(row, c)) = r.v[i];
+        if (c != skip_c) *reinterpret_cast<u32x4_t*>(lds + F::off(row, c)) = r.v[i];
     }
 }
 
@@ -306,7 +309,8 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
 // backward).  Og != null: delta[q] = <dO[q], O[q]> is formed here, from fragments laid out like Q's, and WRITTEN to `delta`
 // for the dK / dV kernel that follows; Og == null: `delta` is an input.
 // ====================================================================================================================
-template <int DP, bool AUG, int DL>
+// PRE: q already holds scale * log2(e) * Q (siss_flash_attn_*_merged with q_prescaled): the score needs no multiply before its exp2.
+template <int DP, bool AUG, int DL, bool PRE>
 __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                                   long ldk, const bf16_t* __restrict__ V, long ldv,
                                                                   const bf16_t* __restrict__ Og, long ldo,
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if constexpr (AUG) st[sub][r] = fast_exp2(st[sub][r] * scale_log2) * dp[sub][r];        // (the MFMAs subtracted lse / c and delta)
+                if constexpr (AUG) st[sub][r] = fast_exp2(PRE ? st[sub][r] : st[sub][r] * scale_log2) * dp[sub][r];        // (the MFMAs subtracted lse / c and delta)
                 else st[sub][r] = fast_exp2(fmaf(st[sub][r], scale_log2, -lse)) * (dp[sub][r] - dl);
             }
         if (k0 + kTQ > valid_k) {
@@ -422,19 +426,17 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
 // backward, dK / dV:  dV = P^T dO,  dK = scale * dS^T Q             grid (Sk_pad / 64, nB*heads)
 // S[q][key] = mfma(Q rows, K rows): a lane keeps ONE key and 4 consecutive queries of each 16-query sub-tile.
 // ====================================================================================================================
-template <int DP, bool AUG, int DL>
+template <int DP, bool AUG, int DL, bool PRE>
 __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t* __restrict__ Q, long ldq, const bf16_t* __restrict__ K,
                                                                     long ldk, const bf16_t* __restrict__ V, long ldv,
                                                                     const bf16_t* __restrict__ dO, long lddo,
                                                                     const float* __restrict__ LSE2, const float* __restrict__ delta,
                                                                     bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV,
-                                                                    long lddv, int Bf, FAShape sh, float scale, float scale_log2,
+                                                                    long lddv, int Bf, FAShape sh, float kscale, float scale_log2,
                                                                     int qchunk, float* __restrict__ part) {
     using F = FA<DP>;
     constexpr int DTL = DL ? DL : F::DT, KSL = DL ? (DL * 16 + (AUG ? 8 : 0) + 31) / 32 : F::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* qs_ = smem;
-    char* dos_ = smem + F::TILE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const long z = blockIdx.y;
     const long bz = z / sh.H;
@@ -473,24 +475,57 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     const float* dlg = delta + z * Sqp;
     const float lmul = -1.f / scale_log2;
     TileRegs<DP> qr, dor;
-    RowVals<DP> lrow, drow;
+    // Augmented columns of the Q / dO tiles: ONE lane per row -- wave 0 splits -lse / c of the tile's 64 queries into the Q tile's pad
+    // chunk, wave 1 -delta into the dO tile's -- straight to LDS beside the tile stores (which skip that chunk).  (Patching the
+    // prefetch registers instead ran the split on 8 live lanes of EVERY wave, twice per tile and operand: ~100 of the ~280 vector
+    // instructions of a tile in loops that are bound by vector issue.)  The row value is loaded with the tile's prefetch.
+    float aug_cur = 0.f, aug_next = 0.f;
     // query range of this block: all of them, or (few keys: cross attention) the blockIdx.z-th chunk of `qchunk` rows, whose
     // partial dK / dV go to `part` in f32 for flash_dkdv_reduce_kernel
     const int qb0 = part ? blockIdx.z * qchunk : 0;
     const int qb1 = part ? (qb0 + qchunk < Sqp ? qb0 + qchunk : Sqp) : Sqp;
     tile_load<DP>(qg + (long)qb0 * ldq, ldq, sh.Sq - qb0, dch, qr, tid);
     tile_load<DP>(dog + (long)qb0 * lddo, lddo, sh.Sq - qb0, dch, dor, tid);
-    if constexpr (AUG) { rowvals_load<DP>(lrow, dch, lseg + qb0, tid); rowvals_load<DP>(drow, dch, dlg + qb0, tid); }
-    for (int q0 = qb0; q0 < qb1; q0 += kTQ) {
+    if constexpr (AUG) { if (w == 0) aug_next = lseg[qb0 + lane]; else if (w == 1) aug_next = dlg[qb0 + lane]; }
+    // registers -> LDS (+ the augmented columns); `qs_` / `dos_` are the buffers written
+    auto to_lds = [&](char* qs_, char* dos_) {
+        tile_store<DP>(qr, qs_, tid, AUG ? dch : -1);
+        tile_store<DP>(dor, dos_, tid, AUG ? dch : -1);
+        if constexpr (AUG) {
+            aug_cur = aug_next;
+            if (w == 0) *reinterpret_cast<u32x4_t*>(qs_ + F::off(lane, dch)) = split_bf16(aug_cur * lmul, 3);
+            else if (w == 1) *reinterpret_cast<u32x4_t*>(dos_ + F::off(lane, dch)) = split_bf16(-aug_cur, 2);
+        }
+    };
+    auto prefetch = [&](int q0n) {
+        tile_load<DP>(qg + (long)q0n * ldq, ldq, sh.Sq - q0n, dch, qr, tid);
+        tile_load<DP>(dog + (long)q0n * lddo, lddo, sh.Sq - q0n, dch, dor, tid);
+        if constexpr (AUG) { if (w == 0) aug_next = lseg[q0n + lane]; else if (w == 1) aug_next = dlg[q0n + lane]; }
+    };
+    // DB (64-wide operands: 4 x 8 KiB of LDS): TWO buffers per operand -- tile t + 1 goes to LDS before tile t's products, ONE barrier
+    // per tile (it orders both "everybody is done reading tile t" and "tile t + 1 is visible"); the wider tiles keep one buffer and
+    // two barriers (four 16-32 KiB tiles per block would cost a resident block).
+    constexpr bool DB = DP == 64;
+    char* const qs0 = smem; char* const dos0 = smem + F::TILE;
+    if constexpr (DB) {
+        to_lds(qs0, dos0);
+        if (qb0 + kTQ < qb1) prefetch(qb0 + kTQ);
         __syncthreads();
-        if constexpr (AUG) { rowvals_apply<DP>(qr, lrow, dch, lmul, 3, tid); rowvals_apply<DP>(dor, drow, dch, -1.f, 2, tid); }
-        tile_store<DP>(qr, qs_, tid);
-        tile_store<DP>(dor, dos_, tid);
-        __syncthreads();
-        if (q0 + kTQ < qb1) {
-            tile_load<DP>(qg + (long)(q0 + kTQ) * ldq, ldq, sh.Sq - q0 - kTQ, dch, qr, tid);
-            tile_load<DP>(dog + (long)(q0 + kTQ) * lddo, lddo, sh.Sq - q0 - kTQ, dch, dor, tid);
-            if constexpr (AUG) { rowvals_load<DP>(lrow, dch, lseg + q0 + kTQ, tid); rowvals_load<DP>(drow, dch, dlg + q0 + kTQ, tid); }
+    }
+    int it = 0;
+    for (int q0 = qb0; q0 < qb1; q0 += kTQ, ++it) {
+        char* qs_ = qs0; char* dos_ = dos0;
+        if constexpr (DB) {
+            qs_ = qs0 + (it & 1) * 2 * F::TILE; dos_ = dos0 + (it & 1) * 2 * F::TILE;
+            if (q0 + kTQ < qb1) {
+                to_lds(qs0 + ((it + 1) & 1) * 2 * F::TILE, dos0 + ((it + 1) & 1) * 2 * F::TILE);
+                if (q0 + 2 * kTQ < qb1) prefetch(q0 + 2 * kTQ);
+            }
+        } else {
+            __syncthreads();
+            to_lds(qs_, dos_);
+            __syncthreads();
+            if (q0 + kTQ < qb1) prefetch(q0 + kTQ);
         }
         f32x4_t s[4], dp[4];
 #pragma unroll
@@ -511,7 +546,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(s[sub][r] * scale_log2);
+                    const float p = fast_exp2(PRE ? s[sub][r] : s[sub][r] * scale_log2);
                     s[sub][r] = p;
                     ds[sub][r] = p * dp[sub][r];                                                    // (scale: once, on the finished dK tile)
                 }
@@ -547,6 +582,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
                 dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DP>(qs_, j, dt, lane), dsf, dkt[dt], 0, 0, 0);
             }
         }
+        if constexpr (DB) __syncthreads();
     }
     if (part) {
         // [z][chunk][key][dK: DTL * 16 | dV: DTL * 16] f32, unscaled
@@ -563,7 +599,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
 #pragma unroll
     for (int dt = 0; dt < DTL; ++dt) {
         if (!(k_ok && dt * 16 + (lane >> 4) * 4 < sh.D)) continue;
-        *reinterpret_cast<u32x2_t*>(okg + dt * 16) = u32x2_t{pack_bf2(dkt[dt][0] * scale, dkt[dt][1] * scale), pack_bf2(dkt[dt][2] * scale, dkt[dt][3] * scale)};
+        *reinterpret_cast<u32x2_t*>(okg + dt * 16) = u32x2_t{pack_bf2(dkt[dt][0] * kscale, dkt[dt][1] * kscale), pack_bf2(dkt[dt][2] * kscale, dkt[dt][3] * kscale)};
         *reinterpret_cast<u32x2_t*>(ovg + dt * 16) = u32x2_t{pack_bf2(dvt[dt][0], dvt[dt][1]), pack_bf2(dvt[dt][2], dvt[dt][3])};
     }
 }
@@ -596,9 +632,9 @@ __global__ __launch_bounds__(256) void flash_dkdv_reduce_kernel(const float* __r
 inline int fa_dpad(int D) { return D <= 64 ? 64 : (D <= 128 ? 128 : (D <= 192 ? 192 : 0)); }
 
 struct FwdArgs { const void *q, *k, *v; void* o; long ldq, ldk, ldv, ldo; float* lse2; };
-int fa_launch_fwd(const FwdArgs& a, int nbh, const FAShape& sh, float scale, void* stream) {
+int fa_launch_fwd(const FwdArgs& a, int nbh, const FAShape& sh, float scale, bool pre, void* stream) {
     const dim3 grid(sh.Sqp / kTQ, nbh);
-    const float sl2 = scale * 1.4426950408889634f;
+    const float sl2 = pre ? 1.f : scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
 #define FA_FWD(DP, DL)                                                                                                   \
     do {                                                                                                                  \
@@ -638,41 +674,46 @@ void fa_qsplit(const FAShape& sh, int nbh, int DW, int& nch, int& qchunk, float*
     qchunk = tiles_per * kTQ;
 }
 
-int fa_launch_bwd(const BwdArgs& a, int nbh, int Bf, const FAShape& sh, float scale, void* stream) {
-    const float sl2 = scale * 1.4426950408889634f;
+// pre: q holds scale * log2(e) * Q.  Scores then are base-2 logits as they come (sl2 = 1; only the augmented kernels have a
+// multiply to drop, hence their PRE forms), dQ is still the gradient with respect to the UNSCALED query -- scale * dS K as before --
+// and dK = scale * dS^T Q = ln(2) * dS^T q.
+int fa_launch_bwd(const BwdArgs& a, int nbh, int Bf, const FAShape& sh, float scale, bool pre, void* stream) {
+    const float sl2 = pre ? 1.f : scale * 1.4426950408889634f;
+    const float kscale = pre ? 0.6931471805599453f : scale;
     hipStream_t st = (hipStream_t)stream;
     float* ws = nullptr;
     // dQ first: it forms delta = rowsum(dO o O) for its 64 queries (when O is given) and leaves it for the dK / dV kernel
-#define FA_BWD(DP, AUG, DL)                                                                                                   \
+#define FA_BWD(DP, AUG, DL, PRE)                                                                                                   \
     do {                                                                                                                     \
         static unsigned char a1[kMaxDevices], a2[kMaxDevices];                                                               \
-        if (siss_ensure_smem((const void*)flash_bwd_dq_kernel<DP, AUG, DL>, 2 * FA<DP>::TILE, a1) != SISS_OK) return SISS_ERR_LAUNCH; \
-        if (siss_ensure_smem((const void*)flash_bwd_dkdv_kernel<DP, AUG, DL>, 2 * FA<DP>::TILE, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
-        flash_bwd_dq_kernel<DP, AUG, DL><<<dim3(sh.Sqp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                       \
+        if (siss_ensure_smem((const void*)flash_bwd_dq_kernel<DP, AUG, DL, PRE>, 2 * FA<DP>::TILE, a1) != SISS_OK) return SISS_ERR_LAUNCH; \
+        constexpr int smem_kv = (DP == 64 ? 4 : 2) * FA<DP>::TILE;                                                           \
+        if (siss_ensure_smem((const void*)flash_bwd_dkdv_kernel<DP, AUG, DL, PRE>, smem_kv, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
+        flash_bwd_dq_kernel<DP, AUG, DL, PRE><<<dim3(sh.Sqp / kTQ, nbh), kThreadsFA, 2 * FA<DP>::TILE, st>>>(                       \
             (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.o, a.ldo,     \
             (const bf16_t*)a.d_o, a.lddo, a.lse2, a.delta, (bf16_t*)a.dq, a.lddq, Bf, sh, scale, sl2);                      \
         constexpr int DW = (DL ? DL : FA<DP>::DT) * 16;                                                                     \
         int nch = 1, qchunk = sh.Sqp;                                                                                        \
         fa_qsplit(sh, nbh, DW, nch, qchunk, ws);                                                                             \
-        flash_bwd_dkdv_kernel<DP, AUG, DL><<<dim3(sh.Skp / kTQ, nbh, nch), kThreadsFA, 2 * FA<DP>::TILE, st>>>(            \
+        flash_bwd_dkdv_kernel<DP, AUG, DL, PRE><<<dim3(sh.Skp / kTQ, nbh, nch), kThreadsFA, smem_kv, st>>>(                     \
             (const bf16_t*)a.q, a.ldq, (const bf16_t*)a.k, a.ldk, (const bf16_t*)a.v, a.ldv, (const bf16_t*)a.d_o, a.lddo,  \
-            a.lse2, a.delta, (bf16_t*)a.dk, a.lddk, (bf16_t*)a.dv, a.lddv, Bf, sh, scale, sl2, qchunk, nch > 1 ? ws : nullptr); \
+            a.lse2, a.delta, (bf16_t*)a.dk, a.lddk, (bf16_t*)a.dv, a.lddv, Bf, sh, kscale, sl2, qchunk, nch > 1 ? ws : nullptr); \
         if (nch > 1) {                                                                                                       \
             siss_count_dispatch(SISS_K_FLASH_QSPLIT);                                                                        \
             const long total = (long)nbh * sh.Sk * (sh.D >> 2);                                                              \
             flash_dkdv_reduce_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(ws, nch, DW, (bf16_t*)a.dk, a.lddk, \
-                (bf16_t*)a.dv, a.lddv, sh, scale, total);                                                                    \
+                (bf16_t*)a.dv, a.lddv, sh, kscale, total);                                                                    \
         }                                                                                                                    \
     } while (0)
     const int dp = fa_dpad(sh.D);
     // A head dim of at most 56 (one whole pad chunk in the 64-wide operands: SD's D = 40, the 4096-key sites) takes the
     // augmented-contraction kernels: 5.58 -> 4.98 ms per launch at B = 16.  The wider tiles do NOT: there the loops are less
     // VALU-bound and the extra registers cost a resident wave (dK / dV kernel at D_pad = 128: 232 -> 256 VGPRs, 772 -> 1069 us).
-    if (dp == 64 && sh.D <= 48) FA_BWD(64, true, 3);
-    else if (dp == 64 && sh.D + 8 <= dp) FA_BWD(64, true, 0);
-    else if (dp == 64) FA_BWD(64, false, 0);
-    else if (dp == 128) { if (sh.D <= 80) FA_BWD(128, false, 5); else FA_BWD(128, false, 0); }
-    else { if (sh.D <= 160) FA_BWD(192, false, 10); else FA_BWD(192, false, 0); }
+    if (dp == 64 && sh.D <= 48) { if (pre) FA_BWD(64, true, 3, true); else FA_BWD(64, true, 3, false); }
+    else if (dp == 64 && sh.D + 8 <= dp) { if (pre) FA_BWD(64, true, 0, true); else FA_BWD(64, true, 0, false); }
+    else if (dp == 64) FA_BWD(64, false, 0, false);
+    else if (dp == 128) { if (sh.D <= 80) FA_BWD(128, false, 5, false); else FA_BWD(128, false, 0, false); }
+    else { if (sh.D <= 160) FA_BWD(192, false, 10, false); else FA_BWD(192, false, 0, false); }
 #undef FA_BWD
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
@@ -696,21 +737,24 @@ int siss_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, fl
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0);
     siss_count_dispatch(SISS_K_FLASH_FWD);
     const FAShape sh{1, 0, D_pad, Sq_pad, Sk_pad, Sq_pad, Sk_pad, valid_k};
-    return fa_launch_fwd(FwdArgs{q, k, v, o, D_pad, D_pad, D_pad, D_pad, lse2}, BH, sh, scale, stream);
+    return fa_launch_fwd(FwdArgs{q, k, v, o, D_pad, D_pad, D_pad, D_pad, lse2}, BH, sh, scale, false, stream);
 }
 
 // The same on the projections' own layout: q / o rows [B * Sq][ld >= H * D], k / v rows [B * Sk][ld], head h at columns
 // [h * D, (h + 1) * D) -- no head-split / head-merge copies and no padded tensors.  D % 8 == 0, D <= 192; every ld % 8 == 0;
 // lse2 [B * H][ceil64(Sq)] f32.  Keys: all Sk rows are valid.
+// q_prescaled != 0: q holds scale * log2(e) * Q (the projection's epilogue applied the factor before its one rounding to bf16:
+// siss_gemm_nt's alpha, siss_gemm_nt_alpha_cols for a fused q / k / v product); o and lse2 mean the same, and the backward still
+// returns the gradient with respect to the UNSCALED query -- the score elements then cost one vector multiply less.
 int siss_flash_attn_fwd_merged(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo,
-                               float* lse2, int B, int H, int Sq, int Sk, int D, float scale, void* stream) {
+                               float* lse2, int B, int H, int Sq, int Sk, int D, float scale, int q_prescaled, void* stream) {
     SISS_CHECK_ARG(q && k && v && o && lse2 && B > 0 && H > 0 && Sq > 0 && Sk > 0 && D > 0 && D % 8 == 0 && fa_dpad(D));
     SISS_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && ldq >= (long)H * D && ldk >= (long)H * D &&
                    ldv >= (long)H * D && ldo >= (long)H * D);
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0);
     siss_count_dispatch(SISS_K_FLASH_FWD);
     const FAShape sh{H, D, D, Sq, Sk, up64(Sq), up64(Sk), Sk};
-    return fa_launch_fwd(FwdArgs{q, k, v, o, ldq, ldk, ldv, ldo, lse2}, B * H, sh, scale, stream);
+    return fa_launch_fwd(FwdArgs{q, k, v, o, ldq, ldk, ldv, ldo, lse2}, B * H, sh, scale, q_prescaled != 0, stream);
 }
 
 // dQ, dK, dV for nBH cotangent (batch, head) entries against BH forward entries (entry z uses forward entry z % BH: the
@@ -727,7 +771,7 @@ int siss_flash_attn_bwd(const void* q, const void* k, const void* v, const void*
     const FAShape sh{1, 0, D_pad, Sq_pad, Sk_pad, Sq_pad, Sk_pad, valid_k};
     const long d = D_pad;
     return fa_launch_bwd(BwdArgs{q, k, v, nullptr, d_o, dq, dk, dv, d, d, d, d, d, d, d, d, lse2, const_cast<float*>(delta)},
-                         nBH, BH, sh, scale, stream);
+                         nBH, BH, sh, scale, false, stream);
 }
 
 // The same on the projections' own layout (see siss_flash_attn_fwd_merged): nB cotangent batch entries against B forward ones
@@ -736,7 +780,7 @@ int siss_flash_attn_bwd(const void* q, const void* k, const void* v, const void*
 int siss_flash_attn_bwd_merged(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo,
                                const void* d_o, long lddo, const float* lse2, float* delta, void* dq, long lddq, void* dk,
                                long lddk, void* dv, long lddv, int nB, int B, int H, int Sq, int Sk, int D, float scale,
-                               void* stream) {
+                               int q_prescaled, void* stream) {
     SISS_CHECK_ARG(q && k && v && o && d_o && lse2 && delta && dq && dk && dv && B > 0 && nB >= B && nB % B == 0 && H > 0);
     SISS_CHECK_ARG(Sq > 0 && Sk > 0 && D > 0 && D % 8 == 0 && fa_dpad(D));
     const long need = (long)H * D;
@@ -748,7 +792,7 @@ int siss_flash_attn_bwd_merged(const void* q, long ldq, const void* k, long ldk,
     siss_count_dispatch(SISS_K_FLASH_BWD);
     const FAShape sh{H, D, D, Sq, Sk, up64(Sq), up64(Sk), Sk};
     return fa_launch_bwd(BwdArgs{q, k, v, o, d_o, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, lse2, delta},
-                         nB * H, B, sh, scale, stream);
+                         nB * H, B, sh, scale, q_prescaled != 0, stream);
 }
 
 }  // extern "C"

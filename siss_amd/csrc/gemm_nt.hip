@@ -358,8 +358,9 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
                      int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream,
                      float* qstats = nullptr, int* qstats_written = nullptr, int d2s = 0, const void* A2 = nullptr, long lda2 = 0,
                      const void* W2 = nullptr, int K2 = 0, const float* bias2 = nullptr, const void* Wx = nullptr, void* Cx = nullptr,
-                     long ldcx = 0, int Nx = 0) {
+                     long ldcx = 0, int Nx = 0, int alpha_cols = 0) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
+    SISS_CHECK_ARG(alpha_cols == 0 || (alpha_cols > 0 && alpha_cols % 4 == 0 && npanels == 1 && !mul_r));   // (one-panel products: the generic kernel)
     if (qstats_written) *qstats_written = 0;
     SISS_CHECK_ARG(M > 0 && N > 0 && Kp > 0 && Kp % BK == 0 && npanels >= 1 && npanels <= kMaxPanels);
     SISS_CHECK_ARG(lda % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0) && batch >= 1);
@@ -372,7 +373,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb;
     p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
     p.M = M; p.N = N; p.Kp = Kp; p.npanels = npanels;
-    p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha;
+    p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha; p.alpha_cols = alpha_cols;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     p.ksplit = 1; p.slab = nullptr; p.qstats = nullptr; p.d2s = d2s;
     p.A2 = (const bf16_t*)A2; p.W2 = (const bf16_t*)W2; p.bias2 = A2 ? bias2 : nullptr; p.lda2 = lda2; p.K2 = A2 ? K2 : 0;
@@ -457,6 +458,15 @@ int siss_gemm_nt(const void* A, long lda, const void* W, void* C, long ldc, cons
                  int batch, long strideA, long strideW, long strideC, void* stream) {
     return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, R, ldr, M, N, Kp, npanels, shifts, coffs,
                             rows_per_image, Hp, Wp, alpha, batch, strideA, strideW, strideC, nullptr, 0, stream);
+}
+
+// siss_gemm_nt (one panel) whose alpha scales only the FIRST alpha_cols output columns (alpha_cols % 4 == 0; the others take 1): the
+// query part of a fused q / k / v projection, pre-scaled by softmax_scale * log2(e) for siss_flash_attn_*_merged(..., q_prescaled = 1).
+int siss_gemm_nt_alpha_cols(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const void* R, long ldr,
+                            int M, int N, int Kp, float alpha, int alpha_cols, void* stream) {
+    const int zero = 0;
+    return gemm_nt_dispatch(A, lda, W, C, ldc, bias, nullptr, N, R, ldr, M, N, Kp, 1, &zero, &zero, 1, 0, 0, alpha, 1, 0, 0, 0,
+                            nullptr, 0, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, alpha_cols);
 }
 
 // siss_gemm_nt that may also hand the GroupNorm statistics of its OUTPUT to the consumer.  `qstats` (f32, siss_conv_qstats_words

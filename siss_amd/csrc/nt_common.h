@@ -16,6 +16,7 @@ struct NTParams {
     int M, N, Kp, npanels;
     int rows_per_image, Hp, Wp;       // Hp == 0: no halo mask
     float alpha, inv_wp;
+    int alpha_cols;                   // 0: alpha scales every output column; else only columns [0, alpha_cols) (the others take 1)
     const float* rowsub;              // optional f32 [batch][M]: subtracted from the accumulator row before alpha
     int mul_r;                        // 1: the epilogue MULTIPLIES by R instead of adding it  (C = R o (alpha (acc - rowsub)))
     int ksplit;                       // > 1: split-K -- gridDim.y blocks per tile write f32 partial tiles to `slab`
@@ -90,8 +91,9 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
             for (int i = 0; i < 4; ++i) {
                 const int nl = wn * 64 + i * 16 + fq * 4;
                 f32x4_t v = acc[i][j];
+                const float al = (p.alpha_cols == 0 || n0 + nl < p.alpha_cols) ? p.alpha : 1.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (v[r] - rsub) * p.alpha + bias4[i][r];
+                for (int r = 0; r < 4; ++r) v[r] = (v[r] - rsub) * al + bias4[i][r];
                 if (rb && n0 + nl + 4 <= p.N) {
                     const f32x4_t t = *reinterpret_cast<const f32x4_t*>(rb + n0 + nl);
 #pragma unroll

@@ -34,6 +34,7 @@ SIGNATURES = {
     "siss_conv_weight_dgrad_multi_bf16": [P, P, P, I, I, P],
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_nt_qstats": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, P, IP, P],
+    "siss_gemm_nt_alpha_cols": [P, L, P, P, L, P, P, L, I, I, I, F, I, P],
     "siss_conv3x3_sc": [P, L, P, P, L, P, P, L, P, L, P, I, P, I, I, I, IP, IP, I, I, I, P, IP, P],
     "siss_conv3x3_sc_takes": [I, I, I, I, I, I, L, L, L],
     "siss_conv3x3_dgrad_sc": [P, L, P, P, L, P, L, P, P, L, I, I, I, I, IP, IP, I, I, I, P],
@@ -85,8 +86,8 @@ SIGNATURES = {
     "siss_head_merge": [P, P, I, I, I, I, I, I, P],
     "siss_flash_attn_fwd": [P, P, P, P, P, I, I, I, I, I, F],
     "siss_flash_attn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F],
-    "siss_flash_attn_fwd_merged": [P, L, P, L, P, L, P, L, P, I, I, I, I, I, F],
-    "siss_flash_attn_bwd_merged": [P, L, P, L, P, L, P, L, P, L, P, P, P, L, P, L, P, L, I, I, I, I, I, I, F],
+    "siss_flash_attn_fwd_merged": [P, L, P, L, P, L, P, L, P, I, I, I, I, I, F, I],
+    "siss_flash_attn_bwd_merged": [P, L, P, L, P, L, P, L, P, L, P, P, P, L, P, L, P, L, I, I, I, I, I, I, F, I],
     "siss_softmax_rows_fwd": [P, P, L, I, I, I, P],
     "siss_quick_gelu": [P, P, L, P],
     "siss_softmax_rows_bwd": [P, P, P, L, L, I, I, F, P],
@@ -312,6 +313,10 @@ def call(name, *args):
         # variants that only add operands are booked under their plain form (same work, same shape key)
         if name == "siss_gemm_nt_qstats":
             name, args = "siss_gemm_nt", list(args[:20]) + [1, 0, 0, 0]
+        elif name == "siss_gemm_nt_alpha_cols":             # (A, lda, W, C, ldc, bias, R, ldr, M, N, Kp, alpha, alpha_cols)
+            a = args
+            name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], a[5], None, a[9], a[6], a[7], a[8], a[9], a[10], 1,
+                                          int_array([0]), int_array([0]), 1, 0, 0, a[11], 1, 0, 0, 0]
         elif name == "siss_gemm_nt_d2s":
             a = args
             name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], None, None, a[8], a[5], a[6], a[7], a[8], a[9], a[10],

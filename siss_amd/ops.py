@@ -43,9 +43,15 @@ def dgrad_weight(w_native_f32):
 # ---------------------------------------------------------------- panelled NT GEMM
 def gemm_nt(a_ptr, lda, w, c_ptr, ldc, M, N, Kp, shifts, coffs, *, bias=None, rowbias=None, ldrb=None,
             res_ptr=None, ldr=0, rows_per_image=1, hp=0, wp=0, alpha=1.0, batch=1,
-            stride_a=0, stride_w=0, stride_c=0, qstats=None):
+            stride_a=0, stride_w=0, stride_c=0, qstats=None, alpha_cols=0):
     """qstats (f32 tensor of lib siss_conv_qstats_words(M, N) floats): ask the product to leave the GroupNorm statistics
     of its output there; returns True when it did (the launch went to the persistent 3x3 kernel), else False/None."""
+    if alpha_cols:
+        # alpha scales only the first alpha_cols output columns (one-panel products: the pre-scaled query part of a fused q / k / v
+        # projection, siss_flash_attn_*_merged(q_prescaled = 1))
+        assert len(shifts) == 1 and shifts[0] == 0 and coffs[0] == 0 and batch == 1 and rowbias is None and qstats is None
+        lib.call("siss_gemm_nt_alpha_cols", a_ptr, lda, w, c_ptr, ldc, bias, res_ptr, ldr, M, N, Kp, float(alpha), int(alpha_cols))
+        return
     if qstats is not None:
         assert batch == 1
         written = lib.C.c_int(0)

@@ -188,15 +188,22 @@ class UNetCondEngine(UNetEngine):
         # self-attention on the fused path: q, k and v are ONE projection (the three weights lie back to back in the flat
         # buffer: a [3C][C] matrix) into one [rows, 3C] tensor -- the normalised input is read once, and the attention kernels
         # take the three column blocks by pointer + row stride
+        # fused path: the query leaves its projection already multiplied by softmax_scale * log2(e) (the product's alpha, applied in
+        # f32 before the one rounding to bf16): the attention kernels' scores are base-2 logits as they come, one vector multiply
+        # less per score element in loops that are bound by vector issue (q_prescaled = 1; dq is still d / d(unscaled q))
+        qmul = float(scale) * 1.4426950408889634
         fused_qkv = (flash and xq is xkv and Ckv == C and wk.data_ptr() == wq.data_ptr() + 2 * C * C
                      and wv.data_ptr() == wk.data_ptr() + 2 * C * C)
         if fused_qkv:
             qkv = bb(".qkv", (rq, 3 * C))
-            ops.gemm_nt(lib.ptr(xq), C, wq, lib.ptr(qkv), 3 * C, rq, 3 * C, C, [0], [0])
+            ops.gemm_nt(lib.ptr(xq), C, wq, lib.ptr(qkv), 3 * C, rq, 3 * C, C, [0], [0], alpha=qmul, alpha_cols=C)
             q, k, v, ldqkv = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], 3 * C
         else:
             q, k, v, ldqkv = keep(".q", (rq, C)), keep(".k", (rk, C)), keep(".v", (rk, C)), C
-            self._linear(xq, pre + ".to_q", q, rq, C, C, bias=False)
+            if flash:
+                ops.gemm_nt(lib.ptr(xq), C, wq, lib.ptr(q), C, rq, C, C, [0], [0], alpha=qmul)
+            else:
+                self._linear(xq, pre + ".to_q", q, rq, C, C, bias=False)
             self._linear(xkv, pre + ".to_k", k, rk, C, Ckv, bias=False)
             self._linear(xkv, pre + ".to_v", v, rk, C, Ckv, bias=False)
         o = bb(".o", (rq, C))
@@ -204,7 +211,7 @@ class UNetCondEngine(UNetEngine):
             # QK^T -> softmax -> .V in ONE kernel (csrc/flash_attn.hip): the S x S matrices never reach HBM; the base-2
             # log-sum-exp is all the backward needs besides q, k, v, o
             lse = bb(".lse", (BH, Sqp), torch.float32)
-            lib.call("siss_flash_attn_fwd_merged", q, ldqkv, k, ldqkv, v, ldqkv, o, C, lse, B, Hh, Sq, Sk, D, float(scale))
+            lib.call("siss_flash_attn_fwd_merged", q, ldqkv, k, ldqkv, v, ldqkv, o, C, lse, B, Hh, Sq, Sk, D, float(scale), 1)
         else:
             qh, kh, vh = bb(".qh", (BH, Sqp, Dp)), bb(".kh", (BH, Skp, Dp)), bb(".vh", (BH, Skp, Dp))
             lib.call("siss_head_split", q, qh, B, Sq, Hh, D, Sqp, Dp)
@@ -243,7 +250,7 @@ class UNetCondEngine(UNetEngine):
                 # (batch, head) entries in one launch pair, cotangent batch b against forward batch b % B; delta[q] =
                 # sum_k P[q][k] dP[q][k] = <dO[q], O[q]> is formed by the dQ kernel from tiles it loads anyway
                 lib.call("siss_flash_attn_bwd_merged", q, ldqkv, k, ldqkv, v, ldqkv, o, C, do, C, lse, delta, dq, ldqkv, dk, ldqkv,
-                         dv, ldqkv, nb, B, Hh, Sq, Sk, D, float(scale))
+                         dv, ldqkv, nb, B, Hh, Sq, Sk, D, float(scale), 1)
             else:
                 doh = tb(".doh", (nBH, Sqp, Dp))
                 lib.call("siss_head_split", do, doh, nb, Sq, Hh, D, Sqp, Dp)

@@ -130,7 +130,8 @@ MERGED_CASES = [  # B, H, Sq, Sk, D, extra row-stride columns
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,D,extra", MERGED_CASES)
-def test_flash_attention_on_the_projection_layout(dev, B, H, Sq, Sk, D, extra):
+@pytest.mark.parametrize("pre", [0, 1])
+def test_flash_attention_on_the_projection_layout(dev, B, H, Sq, Sk, D, extra, pre):
     """siss_flash_attn_fwd_merged / _bwd_merged: the same kernels reading q / k / v / dO and writing o / dq / dk / dv in the
     projections' own [B * S, heads * D] layout (head h at columns h * D) -- no head-split / head-merge copies, no padding in
     memory; delta = rowsum(dO o O) formed inside the dQ kernel.  Against torch fp32 attention + autograd, two cotangent sets."""
@@ -146,6 +147,12 @@ def test_flash_attention_on_the_projection_layout(dev, B, H, Sq, Sk, D, extra):
     heads = lambda t, n, S: t[:, :C].float().cpu().view(n, S, H, D).permute(0, 2, 1, 3)        # [n, H, S, D]
     scale = D ** -0.5
     qr, kr, vr = (heads(t, B, S).clone().requires_grad_(True) for t, S in ((q, Sq), (k, Sk), (v, Sk)))
+    if pre:
+        # q_prescaled: the tensor handed to the kernels is scale * log2(e) * Q (as the projection's epilogue leaves it); the query
+        # the reference differentiates is that bf16 tensor divided by the factor again -- dq is d / d(unscaled q)
+        cq = scale * math.log2(math.e)
+        q = (q.float() * cq).to(torch.bfloat16)
+        qr = (heads(q, B, Sq) / cq).clone().requires_grad_(True)
     s = (qr @ kr.transpose(2, 3)) * scale
     o_ref = torch.softmax(s, dim=-1) @ vr
     dor = heads(do, sets * B, Sq)
@@ -155,19 +162,20 @@ def test_flash_attention_on_the_projection_layout(dev, B, H, Sq, Sk, D, extra):
     o = torch.full((B * Sq, ld), 7.0, dtype=torch.bfloat16, device=dev)
     lse = torch.zeros(B * H, Sqp, device=dev)
     lib.dispatch_counts(reset=True)
-    lib.call("siss_flash_attn_fwd_merged", q, ld, k, ld, v, ld, o, ld, lse, B, H, Sq, Sk, D, float(scale))
+    lib.call("siss_flash_attn_fwd_merged", q, ld, k, ld, v, ld, o, ld, lse, B, H, Sq, Sk, D, float(scale), pre)
     torch.cuda.synchronize()
     _close(heads(o, B, Sq), o_ref.detach(), 1e-2, "O")
     if extra:
         assert float((o[:, C:].float() - 7.0).abs().max()) == 0.0, "columns past heads * D are not the kernel's to write"
     lse_ref = torch.logsumexp(s, dim=-1) / math.log(2.0)
-    assert (lse.view(B, H, Sqp)[:, :, :Sq].cpu() - lse_ref.detach()).abs().max() < 2e-3
+    # (at D % 16 == 8 the denominator is summed over the bf16-rounded p the P V product uses -- the ones column --: up to 2^-9 relative)
+    assert (lse.view(B, H, Sqp)[:, :, :Sq].cpu() - lse_ref.detach()).abs().max() < 3e-3
 
     dq = torch.full((sets * B * Sq, ld), 3.0, dtype=torch.bfloat16, device=dev)
     dk, dv = (torch.full((sets * B * Sk, ld), 3.0, dtype=torch.bfloat16, device=dev) for _ in range(2))
     delta = torch.zeros(sets * B * H * Sqp, device=dev)
     lib.call("siss_flash_attn_bwd_merged", q, ld, k, ld, v, ld, o, ld, do, ld, lse, delta, dq, ld, dk, ld, dv, ld,
-             sets * B, B, H, Sq, Sk, D, float(scale))
+             sets * B, B, H, Sq, Sk, D, float(scale), pre)
     torch.cuda.synchronize()
     cnt = lib.dispatch_counts(reset=True)
     assert cnt["flash_attn_fwd"] == 1 and cnt["flash_attn_bwd"] == 1

@@ -239,3 +239,23 @@ def test_norms_recombine_clip_adamw_vs_torch(dev):
         err = (fo.p.cpu() - ref_p.detach()).abs()
         assert (err > 1e-6 + 1e-5 * ref_p.detach().abs()).float().mean() < 1e-4
         assert err.max() < 1e-2 * 5e-3
+
+
+def test_gemm_nt_alpha_on_the_first_columns_only(dev):
+    """siss_gemm_nt_alpha_cols: C[:, :alpha_cols] = alpha * A W^T (+ bias), the other columns unscaled -- the fused q / k / v projection
+    whose query part leaves pre-scaled for the attention kernels.  Against an f32 matmul of the same bf16 operands; a split-K shape too."""
+    from siss_amd import lib, ops
+    lib.ensure_workspace("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K, ac) in ((1000, 960, 320, 320), (300, 384, 1280, 128), (4096, 320, 320, 320)):
+        a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        c = torch.full((M, N), 5.0, dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt(lib.ptr(a), K, w, lib.ptr(c), N, M, N, K, [0], [0], bias=bias, alpha=0.37, alpha_cols=ac)
+        torch.cuda.synchronize()
+        ref = a.float() @ w.float().T
+        ref[:, :ac] *= 0.37
+        ref += bias
+        err = (c.float() - ref).abs().max().item()
+        assert err <= 1e-2 * ref.abs().max().item(), (M, N, K, ac, err)

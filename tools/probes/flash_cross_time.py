@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
+PRE = int(os.environ.get('PRE', '0'))      # 1: q pre-scaled by scale * log2(e) (q_prescaled form)
 from siss_amd import lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dev = torch.device("cuda:0")
@@ -15,8 +16,8 @@ for S, D in ((4096, 40), (1024, 80), (256, 160)):
     Sp = -(-S // 64) * 64
     lse = torch.zeros(B * H, Sp, device=dev); delta = torch.zeros(sets * B * H * Sp, device=dev)
     sc = D ** -0.5
-    f = lambda: lib.call("siss_flash_attn_fwd_merged", q, ld, k, ld, v, ld, o, ld, lse, B, H, S, Sk, D, sc)
-    b = lambda: lib.call("siss_flash_attn_bwd_merged", q, ld, k, ld, v, ld, o, ld, do, ld, lse, delta, dq, ld, dk, ld, dv, ld, sets * B, B, H, S, Sk, D, sc)
+    f = lambda: lib.call("siss_flash_attn_fwd_merged", q, ld, k, ld, v, ld, o, ld, lse, B, H, S, Sk, D, sc, PRE)
+    b = lambda: lib.call("siss_flash_attn_bwd_merged", q, ld, k, ld, v, ld, o, ld, do, ld, lse, delta, dq, ld, dk, ld, dv, ld, sets * B, B, H, S, Sk, D, sc, PRE)
     for fn, nm in ((f, "fwd"), (b, "bwd")):
         for _ in range(3): fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
