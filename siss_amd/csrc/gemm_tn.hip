@@ -17,6 +17,7 @@
 // Split-K over row ranges; partial tiles are accumulated with f32 global atomics (no-return
 // global_atomic_add_f32; 16 consecutive floats per lane group).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -254,8 +255,37 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
             // behind each of the first 20, pinned by a scheduling fence per pair.  Read order = consumption order (Y
             // fragments, then taps 2, 1, 0), so the counted LDS wait in front of the next half-step's first MFMA leaves the
             // younger reads in flight.  Past the last step the reads fetch a stale buffer: harmless, never used.
-            auto half = [&](bf16x8_t (&yc)[4], bf16x8_t (&xc)[TAPS][CT], bf16x8_t (&yn)[4], bf16x8_t (&xn)[TAPS][CT],
-                            const char* sbn, int kkn) {
+            // Read addresses: the 20 per-lane fragment addresses are held for a PAIR of ring buffers (anchor = buffer 0 or 2; the
+            // odd buffer of the pair and the second 32-row half are the instruction's immediate offset -- the loop is unrolled over
+            // the ring, so the buffer is a compile-time constant) and rebuilt when the reads move to the other pair: twice per four
+            // steps, as (per-lane offset + anchor) ^ tile bits -- 20 vector instructions each (the XOR may follow the add: anchors
+            // and the LDS base are multiples of 256 bytes).  Before this every read was preceded by a v_add for the buffer base: 40
+            // vector instructions per step beside 48 MFMAs -- with two waves per SIMD the vector issue (an MFMA holds it for 8 of
+            // its 16 cycles, a v_add for 4) was as busy as the matrix pipe (rocprofv3: 2.0 vector instructions per MFMA,
+            // profiles/r03r_pmc_mix_celeb.txt).
+            typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
+            if (smem_a & 255u) __builtin_trap();
+            unsigned aY[2][4], aX[TAPS][2][CT];
+            auto set_anchor = [&](unsigned anchor) {
+                asm volatile("" : "+s"(anchor));                         // opaque: keeps LICM from holding BOTH anchors' sets in registers
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned yb = smem_a + anchor + y_off[h];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) aY[h][i] = yb ^ (i << 5);
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) {
+                        const unsigned xb = smem_a + anchor + x_off[t][h];
+#pragma unroll
+                        for (int ii = 0; ii < CT; ++ii) aX[t][h][ii] = xb ^ (ii << 5);
+                    }
+                }
+            };
+            set_anchor(0);
+            // BN_ = ring buffer the NEXT half-step's fragments are read from, KK = its 32-row half
+            auto half = [&](auto BN_, auto KK, bf16x8_t (&yc)[4], bf16x8_t (&xc)[TAPS][CT], bf16x8_t (&yn)[4], bf16x8_t (&xn)[TAPS][CT]) {
+                constexpr int bn = decltype(BN_)::value, kkn = decltype(KK)::value;
+                constexpr int imm = (bn & 1) * SB + kkn * 8192;
                 s16x4_t r0;                                              // the first read of the pair in flight
                 if (do_bias) {
 #pragma unroll
@@ -270,10 +300,10 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
                         // second half is issued, so that both reads land in the fragment's own registers (no copies)
                         s16x4_t rr;
                         if (m < 8) {
-                            rr = tr_read(sbn + ((y_off[m & 1] ^ ((m >> 1) << 5)) + kkn * 8192));
+                            rr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(aY[m & 1][m >> 1] + imm));
                         } else {
                             const int q = m - 8, tt = 2 - q / 4, ii = (q % 4) >> 1, h = q & 1;
-                            rr = tr_read(sbn + ((x_off[tt][h] ^ (ii << 5)) + kkn * 8192));
+                            rr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(aX[tt][h][ii] + imm));
                         }
                         if (!(m & 1)) {
                             r0 = rr;
@@ -291,17 +321,19 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
             // SIMD (w and w + 4) issue their DMA half a step apart: a DMA piece costs 60-180 issue cycles during which the
             // issuing wave feeds no MFMAs -- staggered, the SIMD's other wave keeps the matrix pipe busy meanwhile.
             const bool early = w < 4;
-            for (int s = 0; s < steps; ++s) {
-                const int b1 = (buf + 1) & 3, b3 = (buf + 3) & 3;
+            using std::integral_constant;
+            auto step = [&](auto B_, int s) {                            // B_ = the ring buffer of step s (= s mod 4)
+                constexpr int b = decltype(B_)::value, b1 = (b + 1) & 3, b3 = (b + 3) & 3;
                 const bool more = s + 3 < steps;
                 // (all rows of step s + 3 in range: its Y rows and the X rows two past them)
                 const bool fast = full_tile && r0 + (s + 4) * BR + 4 <= r1;
                 if (more && early) { if (fast) stage_fast(b3, s + 3); else stage(b3, s + 3); }
                 __builtin_amdgcn_sched_barrier(0);
-                half(yf[0], xf[0], yf[1], xf[1], smem + buf * SB, 1);
+                half(integral_constant<int, b>{}, integral_constant<int, 1>{}, yf[0], xf[0], yf[1], xf[1]);
                 if (more && !early) { if (fast) stage_fast(b3, s + 3); else stage(b3, s + 3); }
+                if constexpr (b & 1) set_anchor((b1 >> 1) * 2 * SB);      // the second half reads the other pair's even buffer
                 __builtin_amdgcn_sched_barrier(0);
-                half(yf[1], xf[1], yf[0], xf[0], smem + b1 * SB, 0);
+                half(integral_constant<int, b1>{}, integral_constant<int, 0>{}, yf[1], xf[1], yf[0], xf[0]);
                 if (more) {
                     if (w == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP + 1) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
@@ -309,7 +341,12 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_s_barrier();
-                buf = b1;
+            };
+            for (int s = 0; s < steps; s += 4) {
+                step(integral_constant<int, 0>{}, s);
+                if (s + 1 < steps) step(integral_constant<int, 1>{}, s + 1);
+                if (s + 2 < steps) step(integral_constant<int, 2>{}, s + 2);
+                if (s + 3 < steps) step(integral_constant<int, 3>{}, s + 3);
             }
         } else
         for (int s = 0; s < steps; ++s) {
@@ -352,19 +389,41 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
         }
     } else {
         // One barrier per K-step (see gemm_nt.hip): wait own DMA + own LDS reads, barrier, restage, compute.
-        stage(0, 0);
-        for (int s = 0; s < steps; ++s) {
-            const int buf = s & 1;
+        // (the loop runs two steps per trip so that the stage buffer -- and with it every fragment read's offset from the 16 per-lane
+        // addresses: buffer * 32 KiB + half * 8 KiB -- is an instruction immediate instead of a vector add per read)
+        typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
+        unsigned aY[2][4], aX1[2][CT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aY[h][i] = smem_a + (y_off[h] ^ (i << 5));
+#pragma unroll
+            for (int i = 0; i < CT; ++i) aX1[h][i] = smem_a + (x_off[0][h] ^ (i << 5));
+        }
+        auto frag_at = [&](unsigned a0, unsigned a1, auto IMM) {
+            constexpr int imm = decltype(IMM)::value;
+            const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(a0 + imm));
+            const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(a1 + imm));
+            return bf16x8_t{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        };
+        auto one = [&](auto BUF, int s) {
+            constexpr int buf = decltype(BUF)::value;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (s + 1 < steps) {
                 if (full_tile && r0 + (s + 2) * BR + 4 <= r1) stage_fast(buf ^ 1, s + 1); else stage(buf ^ 1, s + 1);
             }
-            const char* sb = smem + buf * C_::kStageBytes;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8_t yf[4], xf[TAPS][CT];
-                load_frags(yf, xf, sb, kk);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    yf[i] = kk ? frag_at(aY[0][i], aY[1][i], std::integral_constant<int, buf * C_::kStageBytes + 8192>{})
+                               : frag_at(aY[0][i], aY[1][i], std::integral_constant<int, buf * C_::kStageBytes>{});
+#pragma unroll
+                for (int i = 0; i < CT; ++i)
+                    xf[0][i] = kk ? frag_at(aX1[0][i], aX1[1][i], std::integral_constant<int, buf * C_::kStageBytes + 8192>{})
+                                  : frag_at(aX1[0][i], aX1[1][i], std::integral_constant<int, buf * C_::kStageBytes>{});
                 if (do_bias) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, bacc[i], 0, 0, 0);
@@ -372,6 +431,11 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) mma_tap(yf, xf, t);
             }
+        };
+        stage(0, 0);
+        for (int s = 0; s < steps; s += 2) {
+            one(std::integral_constant<int, 0>{}, s);
+            if (s + 1 < steps) one(std::integral_constant<int, 1>{}, s + 1);
         }
     }
 
