@@ -36,8 +36,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+// two floats -> one packed pair: ONE v_cvt_pk_bf16_f32 (a two-element vector conversion).  Written as two scalar casts + shift / or
+// it only became that instruction where the SLP vectoriser paired the casts; flash_attn.hip is built without it and paid
+// 2 conversions + a shift + an SDWA or per pair (64 instead of 16 vector instructions per tile in the dK / dV loop).
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_pk __attribute__((ext_vector_type(2)));
+    const bf16x2_pk b = __builtin_convertvector(f32x2_pk{lo, hi}, bf16x2_pk);
+    return __builtin_bit_cast(uint32_t, b);
 }
 
 // (a.lo + b.lo, a.hi + b.hi) of two packed bf16 pairs: f32 adds, ONE rounding (RNE) by v_cvt_pk_bf16_f32 -- 7 instructions.  The

@@ -67,6 +67,41 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ g, long ld,
         r.v[i] = (row < rows && c < dch) ? *reinterpret_cast<const u32x4_t*>(g + (long)row * ld + c * 8) : u32x4_t{0u, 0u, 0u, 0u};
     }
 }
+// The same for a tile whose 64 rows all exist (every tile but a ragged last one), for the operand widths whose chunk column is one
+// per thread (CH divides the block: 64- and 128-wide): no row predicate, ONE column predicate for all of a thread's loads, addresses
+// = wave-uniform tile base + per-thread 32-bit offsets fixed for the block.  Lanes whose chunk column is past the head dim load
+// nothing and keep what their registers hold: zeros, or the ones of an augmented tile (set once).  The general form above costs, per
+// tile and wave, ~16 register zeroings, a 64-bit address build per load and an EXEC region per load -- ~40 of ~160 vector
+// instructions in loops that are bound by vector issue (3 waves per SIMD: 28 MFMAs x 8 + 160 x 4 issue cycles against 28 x 16 of
+// matrix pipe per tile).
+template <int DP> struct TileOffs { unsigned o[FA<DP>::CH * kTQ / kThreadsFA]; bool cok; };
+template <int DP> constexpr bool kTileFast = kThreadsFA % FA<DP>::CH == 0;
+template <int DP>
+__device__ __forceinline__ void tile_offs(TileOffs<DP>& t, long ld, int dch, int tid) {
+    using F = FA<DP>;
+#pragma unroll
+    for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i) {
+        const int idx = i * kThreadsFA + tid;
+        const int row = idx / F::CH, c = idx - row * F::CH;
+        t.o[i] = (unsigned)(((long)row * ld + c * 8) * 2);
+    }
+    t.cok = tid % F::CH < dch;
+}
+template <int DP>
+__device__ __forceinline__ void tile_load_full(const bf16_t* __restrict__ g, const TileOffs<DP>& t, TileRegs<DP>& r) {
+    using F = FA<DP>;
+    if (t.cok) {
+#pragma unroll
+        for (int i = 0; i < F::CH * kTQ / kThreadsFA; ++i)
+            r.v[i] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(g) + t.o[i]);
+    }
+}
+template <int DP>
+__device__ __forceinline__ void tile_zero(TileRegs<DP>& r) {
+#pragma unroll
+    for (int i = 0; i < FA<DP>::CH * kTQ / kThreadsFA; ++i) r.v[i] = u32x4_t{0u, 0u, 0u, 0u};
+}
+
 // skip_c: a chunk column somebody else writes (the augmented column of a Q / dO tile: dK / dV kernel), -1: none
 template <int DP>
 __device__ __forceinline__ void tile_store(const TileRegs<DP>& r, char* lds, int tid, int skip_c = -1) {
@@ -220,18 +255,29 @@ __global__ __launch_bounds__(kThreadsFA) void flash_fwd_kernel(const bf16_t* __r
     const bf16_t* kg = K + b * sh.Sk * ldk + h * sh.hoff;
     const bf16_t* vg = V + b * sh.Sk * ldv + h * sh.hoff;
     TileRegs<DP> kr, vr;
-    tile_load<DP>(kg, ldk, sh.Sk, dch, kr, tid);
-    tile_load<DP>(vg, ldv, sh.Sk, dch, vr, tid);
+    TileOffs<DP> ko, vo;
+    tile_offs<DP>(ko, ldk, dch, tid); tile_offs<DP>(vo, ldv, dch, tid);
+    tile_zero<DP>(kr); tile_zero<DP>(vr);
+    // tile at key row k0n -> registers (full tiles: tile_load_full; a ragged last tile: the general form, which also rewrites the pad
+    // chunks, so the ones column goes back in)
+    auto fetch = [&](int k0n) {
+        if (kTileFast<DP> && k0n + kTQ <= sh.Sk) {
+            tile_load_full<DP>(kg + (long)k0n * ldk, ko, kr);
+            tile_load_full<DP>(vg + (long)k0n * ldv, vo, vr);
+        } else {
+            tile_load<DP>(kg + (long)k0n * ldk, ldk, sh.Sk - k0n, dch, kr, tid);
+            tile_load<DP>(vg + (long)k0n * ldv, ldv, sh.Sk - k0n, dch, vr, tid);
+            if (lcol) tile_set_chunk<DP>(vr, dch, u32x4_t{kOne1, 0u, 0u, 0u}, tid);
+        }
+    };
+    if (lcol) tile_set_chunk<DP>(vr, dch, u32x4_t{kOne1, 0u, 0u, 0u}, tid);
+    fetch(0);
     for (int k0 = 0; k0 < Skp; k0 += kTQ) {
         __syncthreads();                                        // the previous tile's readers are done
-        if (lcol) tile_set_chunk<DP>(vr, dch, u32x4_t{kOne1, 0u, 0u, 0u}, tid);
         tile_store<DP>(kr, ks_, tid);
         tile_store<DP>(vr, vs_, tid);
         __syncthreads();
-        if (k0 + kTQ < Skp) {                                   // next tile: in flight under this tile's products
-            tile_load<DP>(kg + (long)(k0 + kTQ) * ldk, ldk, sh.Sk - k0 - kTQ, dch, kr, tid);
-            tile_load<DP>(vg + (long)(k0 + kTQ) * ldv, ldv, sh.Sk - k0 - kTQ, dch, vr, tid);
-        }
+        if (k0 + kTQ < Skp) fetch(k0 + kTQ);                    // next tile: in flight under this tile's products
         f32x4_t st[4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -369,19 +415,31 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dq_kernel(const bf16_t* 
     const bf16_t* kg = K + bf * sh.Sk * ldk + h * sh.hoff;
     const bf16_t* vg = V + bf * sh.Sk * ldv + h * sh.hoff;
     TileRegs<DP> kr, vr;
-    tile_load<DP>(kg, ldk, sh.Sk, dch, kr, tid);
-    tile_load<DP>(vg, ldv, sh.Sk, dch, vr, tid);
+    TileOffs<DP> ko, vo;
+    tile_offs<DP>(ko, ldk, dch, tid); tile_offs<DP>(vo, ldv, dch, tid);
+    tile_zero<DP>(kr); tile_zero<DP>(vr);
+    auto ones_cols = [&]() {
+        if constexpr (AUG) { tile_set_chunk<DP>(kr, dch, u32x4_t{kOne2, kOne1, 0u, 0u}, tid); tile_set_chunk<DP>(vr, dch, u32x4_t{kOne2, 0u, 0u, 0u}, tid); }
+    };
+    // (the ones columns sit in registers no full-tile load touches: set once, and again after a general-form load)
+    auto fetch = [&](int k0n) {
+        if (kTileFast<DP> && k0n + kTQ <= sh.Sk) {
+            tile_load_full<DP>(kg + (long)k0n * ldk, ko, kr);
+            tile_load_full<DP>(vg + (long)k0n * ldv, vo, vr);
+        } else {
+            tile_load<DP>(kg + (long)k0n * ldk, ldk, sh.Sk - k0n, dch, kr, tid);
+            tile_load<DP>(vg + (long)k0n * ldv, ldv, sh.Sk - k0n, dch, vr, tid);
+            ones_cols();
+        }
+    };
+    ones_cols();
+    fetch(0);
     for (int k0 = 0; k0 < Skp; k0 += kTQ) {
         __syncthreads();
-        // (the ones columns are placed when the tile goes to LDS: the prefetched registers are not touched while the loads fly)
-        if constexpr (AUG) { tile_set_chunk<DP>(kr, dch, u32x4_t{kOne2, kOne1, 0u, 0u}, tid); tile_set_chunk<DP>(vr, dch, u32x4_t{kOne2, 0u, 0u, 0u}, tid); }
         tile_store<DP>(kr, ks_, tid);
         tile_store<DP>(vr, vs_, tid);
         __syncthreads();
-        if (k0 + kTQ < Skp) {
-            tile_load<DP>(kg + (long)(k0 + kTQ) * ldk, ldk, sh.Sk - k0 - kTQ, dch, kr, tid);
-            tile_load<DP>(vg + (long)(k0 + kTQ) * ldv, ldv, sh.Sk - k0 - kTQ, dch, vr, tid);
-        }
+        if (k0 + kTQ < Skp) fetch(k0 + kTQ);
         f32x4_t st[4], dp[4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
@@ -484,8 +542,19 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
     // partial dK / dV go to `part` in f32 for flash_dkdv_reduce_kernel
     const int qb0 = part ? blockIdx.z * qchunk : 0;
     const int qb1 = part ? (qb0 + qchunk < Sqp ? qb0 + qchunk : Sqp) : Sqp;
-    tile_load<DP>(qg + (long)qb0 * ldq, ldq, sh.Sq - qb0, dch, qr, tid);
-    tile_load<DP>(dog + (long)qb0 * lddo, lddo, sh.Sq - qb0, dch, dor, tid);
+    TileOffs<DP> qo, doo;
+    tile_offs<DP>(qo, ldq, dch, tid); tile_offs<DP>(doo, lddo, dch, tid);
+    tile_zero<DP>(qr); tile_zero<DP>(dor);
+    auto fetch = [&](int q0n) {
+        if (kTileFast<DP> && q0n + kTQ <= sh.Sq) {
+            tile_load_full<DP>(qg + (long)q0n * ldq, qo, qr);
+            tile_load_full<DP>(dog + (long)q0n * lddo, doo, dor);
+        } else {
+            tile_load<DP>(qg + (long)q0n * ldq, ldq, sh.Sq - q0n, dch, qr, tid);
+            tile_load<DP>(dog + (long)q0n * lddo, lddo, sh.Sq - q0n, dch, dor, tid);
+        }
+    };
+    fetch(qb0);
     if constexpr (AUG) { if (w == 0) aug_next = lseg[qb0 + lane]; else if (w == 1) aug_next = dlg[qb0 + lane]; }
     // registers -> LDS (+ the augmented columns); `qs_` / `dos_` are the buffers written
     auto to_lds = [&](char* qs_, char* dos_) {
@@ -498,8 +567,7 @@ __global__ __launch_bounds__(kThreadsFA) void flash_bwd_dkdv_kernel(const bf16_t
         }
     };
     auto prefetch = [&](int q0n) {
-        tile_load<DP>(qg + (long)q0n * ldq, ldq, sh.Sq - q0n, dch, qr, tid);
-        tile_load<DP>(dog + (long)q0n * lddo, lddo, sh.Sq - q0n, dch, dor, tid);
+        fetch(q0n);
         if constexpr (AUG) { if (w == 0) aug_next = lseg[q0n + lane]; else if (w == 1) aug_next = dlg[q0n + lane]; }
     };
     // DB (64-wide operands: 4 x 8 KiB of LDS): TWO buffers per operand -- tile t + 1 goes to LDS before tile t's products, ONE barrier
