@@ -109,6 +109,36 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
     const int nc = n0 + chunk * 8;
     if (nc >= p.N) return;
     constexpr int kRowsPerIt = kThreads / 16;
+    if (p.Hp == 0 && !p.d2s && nc + 8 <= p.N) {
+        // Rows without a pixel structure (linears, attention products): no halo logic, and the output / residual addresses are
+        // running pointers (one 64-bit add per row instead of a 64-bit multiply-add) -- these launches have K loops of 5-20 steps,
+        // so the epilogue's vector instructions weigh as much as their MFMAs.
+        const int row0 = tid >> 4;
+        bf16_t* dst = C + (long)(m0 + row0) * p.ldc + nc;
+        const bf16_t* rsrc = p.R ? p.R + (long)bz * p.strideC + (long)(m0 + row0) * p.ldr + nc : nullptr;
+        const long dstep = (long)kRowsPerIt * p.ldc, rstep = (long)kRowsPerIt * p.ldr;
+        int rows_left = (p.M - m0 < vrows ? p.M - m0 : vrows) - row0;
+        const char* src = smem + row0 * kCRow + chunk * 16;
+#pragma unroll 4
+        for (int it = 0; it < BM / kRowsPerIt; ++it) {
+            if (rows_left <= 0) break;
+            u32x4_t o = *reinterpret_cast<const u32x4_t*>(src + it * kRowsPerIt * kCRow);
+            if (rsrc) {
+                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(rsrc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o0 = __builtin_bit_cast(float, o[e] << 16), o1 = __builtin_bit_cast(float, o[e] & 0xffff0000u);
+                    const float r0 = __builtin_bit_cast(float, rr[e] << 16), r1 = __builtin_bit_cast(float, rr[e] & 0xffff0000u);
+                    o[e] = p.mul_r ? pack_bf2(o0 * r0, o1 * r1) : pack_bf2(o0 + r0, o1 + r1);
+                }
+                rsrc += rstep;
+            }
+            *reinterpret_cast<u32x4_t*>(dst) = o;
+            dst += dstep;
+            rows_left -= kRowsPerIt;
+        }
+        return;
+    }
 #pragma unroll 4
     for (int it = 0; it < BM / kRowsPerIt; ++it) {
         const int row = it * kRowsPerIt + (tid >> 4);
