@@ -7,6 +7,7 @@
 # Also here, as records of measured-and-rejected kernels (they are NOT part of either build):
 #   gemm_nt_c3.hip     one-tile-per-block predecessor of gemm_nt_c3p      gemm_nt_conv3.hip  A tile shared by three taps in the generic kernel
 #   groupnorm2p.hip    two-phase on-chip GroupNorm (2x slower than two passes)
+#   gemm_tn_wide.hip   one-tap wgrad with a 128 x 384 tile (all-role waves)        gemm_tn_pc.hip     the same as producer / consumer, 128 x 256
 set -e
 cd "$(dirname "$0")/../.."
 out=tools/probes/_probe_build; mkdir -p $out

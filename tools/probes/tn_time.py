@@ -1,6 +1,7 @@
 """Time the one-panel weight-gradient products of the SD v1.5 transformer blocks (two cotangent sets sharing X) through
 siss_gemm_tn_grouped, ALL jobs of a level in ONE call (as the step queues them), with the producer / consumer kernel on (default) and
-off.  python tools/probes/tn_time.py [B]"""
+off.  python tools/probes/tn_time.py [B]
+Needs a variant library built from tools/probes/gemm_tn_pc.hip (SISS_LIB_PATH); the product library has no such setter."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
