@@ -421,7 +421,10 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     // Large grids: single-buffered blocks at 4 per CU (latency hidden by the other three) measured 10-15 %
     // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
     const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;
-    if (tiles128 >= 2048) return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
+    // (more tiles than the double-buffered form keeps resident -- 2 blocks x 256 CUs -- : that form would run a second, partly
+    // empty round; A/B of the threshold on one box, 2048 / 1100 / 520 / 384 / 260 tiles: SD v1.5 B = 16 112.5 / 112.8 / 111.3 /
+    // 111.5 / 111.8 ms, B = 4 46.0 / 46.9 / 45.8 / 46.2 / 46.3 ms, CelebA-HQ unchanged -- e.g. 8192 x 1280 x K 10240: 640 tiles)
+    if (tiles128 > 512) return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
     // at most one block per CU anyway: a 4-deep ring (128 KiB) keeps three K-steps of DMA in flight, so a step
     // costs its MFMA time instead of an L2 round trip (the 8x8 .. 32x32 layers are bound by the serial K loop)
     if (tiles128 <= 256) {
