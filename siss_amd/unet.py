@@ -158,11 +158,13 @@ class UNetEngine:
     d2s_epilogue = True    # downsample dgrad: depth-to-space in the plane GEMMs' epilogue (no dz tensor, no scatter pass)
     direct_cat = True      # convs that feed a concat write into the concat buffer directly (False: copy both parts)
     fold_shortcut = True   # a resnet's 1x1 conv_shortcut rides in its conv2's 3x3 product (False: own product + residual add)
-    # Weight gradients of the LOW-RESOLUTION layers (at most group_rows reduction rows per set: the 8x8 .. 32x32 levels) are not
-    # launched one by one -- each alone leaves most CUs idle and pays a launch's fixed ~10-40 us -- but queued and run as grouped
-    # launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).  They only feed the flat gradient buffer, so
-    # nothing waits for them; their cotangent operand is held back from the buffer pool until the group has run.  0 = off.
-    group_rows = 20000
+    # Weight gradients of all but the top-resolution layers (at most group_rows reduction rows per set: CelebA-HQ's 8x8 .. 128x128
+    # levels) are not launched one by one -- each alone leaves CUs idle in its last round of blocks and pays a launch's fixed
+    # ~10-40 us -- but queued and run as grouped launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).
+    # They only feed the flat gradient buffer, so nothing waits for them; their cotangent operand is held back from the buffer
+    # pool until the group has run.  0 = off.  Swept on one box (20 k / 70 k / 280 k / 1.1 M rows): CelebA-HQ 57.03 / 56.69 /
+    # 56.45 / 56.91 ms (the 256 x 256 wgrads are better off with their own one-round grids), SD v1.5 B = 16 111.0 -> 109.6 ms.
+    group_rows = 280000
     group_max = 42
     group_attn = True      # ... the attention blocks' linears too
 
