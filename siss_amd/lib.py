@@ -25,8 +25,8 @@ SIGNATURES = {
     "siss_opt_partials_words": [],
     "siss_opt_scalars_words": [],
     "siss_grad_norms_scale": [P, P, L, I, F, F, F, F, P, P, P],
-    "siss_grad_norm_partials": [P, P, L, P, IP],
-    "siss_grad_scalars": [P, I, I, F, F, F, F, P],
+    "siss_grad_norm_partials": [P, P, L, P, IP, P],
+    "siss_grad_scalars": [P, I, I, F, F, F, F, P, P],
     "siss_recombine_clip_adamw": [P, P, P, P, P, P, P, L, F, F, F, F, F, P, P],
     "siss_cast_f32_bf16": [P, P, L, P],
     "siss_conv_weight_dgrad_layout": [P, P, I, I, I, P],
@@ -48,7 +48,7 @@ SIGNATURES = {
     "siss_gemm_nt_mulsub": [P, L, P, P, L, P, L, P, I, I, I, F, I, L, L, L, P],
     "siss_rowdot": [P, P, P, L, L, I, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
-    "siss_gemm_tn_grouped": [P, I],
+    "siss_gemm_tn_grouped": [P, I, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_set_slab": [I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
@@ -84,10 +84,10 @@ SIGNATURES = {
     "siss_geglu_bwd": [P, P, P, L, L, I, P],
     "siss_head_split": [P, P, I, I, I, I, I, I, P],
     "siss_head_merge": [P, P, I, I, I, I, I, I, P],
-    "siss_flash_attn_fwd": [P, P, P, P, P, I, I, I, I, I, F],
-    "siss_flash_attn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F],
-    "siss_flash_attn_fwd_merged": [P, L, P, L, P, L, P, L, P, I, I, I, I, I, F, I],
-    "siss_flash_attn_bwd_merged": [P, L, P, L, P, L, P, L, P, L, P, P, P, L, P, L, P, L, I, I, I, I, I, I, F, I],
+    "siss_flash_attn_fwd": [P, P, P, P, P, I, I, I, I, I, F, P],
+    "siss_flash_attn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
+    "siss_flash_attn_fwd_merged": [P, L, P, L, P, L, P, L, P, I, I, I, I, I, F, I, P],
+    "siss_flash_attn_bwd_merged": [P, L, P, L, P, L, P, L, P, L, P, P, P, L, P, L, P, L, I, I, I, I, I, I, F, I, P],
     "siss_softmax_rows_fwd": [P, P, L, I, I, I, P],
     "siss_quick_gelu": [P, P, L, P],
     "siss_softmax_rows_bwd": [P, P, P, L, L, I, I, F, P],

@@ -35,6 +35,19 @@ def test_library_exports_every_declared_symbol():
     lib.load()
 
 
+def test_ctypes_table_has_the_arity_of_every_prototype():
+    """siss_amd/lib.py's argument table against include/siss_hip.h: every entry point is bound with as many arguments as its
+    prototype declares (the launchers' trailing `void* stream` included: lib.call appends its VALUE) -- a signature that drifts
+    from the header would otherwise only show as garbage arguments on the GPU."""
+    from siss_amd import lib
+    h = open(os.path.join(ROOT, "include", "siss_hip.h")).read()
+    protos = dict(re.findall(r"\b(?:int|long) (siss_\w+)\(([^;{]*?)\)\s*;", h, flags=re.S))
+    assert len(protos) == len(lib.SIGNATURES)
+    for name, args in protos.items():
+        params = [a.strip() for a in args.replace("\n", " ").split(",") if a.strip() and a.strip() != "void"]
+        assert len(lib.SIGNATURES[name]) == len(params), (name, len(lib.SIGNATURES[name]), params)
+
+
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
     from siss_amd import lib
     monkeypatch.setattr(lib, "_lib", None)
