@@ -51,7 +51,7 @@ def parse():
 
 
 CPU_MICRO_BATCH = 4          # the CPU oracle walks the B samples of a step in micro-batches of 4 (bounded host memory)
-CPU_CROSS_BATCH = 2          # round 1-2's sample, kept beside the full-size figure as a cross-check
+CPU_TIMED_STEPS = 3          # 1 warm-up + 3 timed steps, the median is reported
 
 
 def cpu_baseline(cfg_kw, seed, sd=False, B=16):
@@ -60,7 +60,8 @@ def cpu_baseline(cfg_kw, seed, sd=False, B=16):
     micro-batches of 4 with gradient accumulation, the way config/delete_celeb.yaml itself ships the step (batch 4 x GA 16;
     same arithmetic: the loss is normalised by B, GroupNorm / attention are per sample), which bounds the autograd memory on
     the host.  One untimed warm-up step at batch 4 first (thread pool, oneDNN primitive caches, first touch of the
-    parameters + optimizer state).  Returns (seconds for the B-sample step, cores, seconds for a batch-2 step)."""
+    parameters + optimizer state), then CPU_TIMED_STEPS timed steps.  Returns (median seconds for the B-sample step, cores,
+    all timed steps' seconds)."""
     from oracle import schedule as S
     from oracle.loss import OracleDeletionLoss
     from oracle.step import unlearning_step
@@ -109,10 +110,10 @@ def cpu_baseline(cfg_kw, seed, sd=False, B=16):
                         loss_params={"lambd": 0.5}, conditioning=cond)
         return time.perf_counter() - t0
     micro = min(CPU_MICRO_BATCH, B)
-    step(micro, micro)                                              # warm-up, untimed
-    dt_cross = step(min(CPU_CROSS_BATCH, B), min(CPU_CROSS_BATCH, B))
-    dt = step(B - B % micro if B >= micro else B, micro)
-    return dt, cores, dt_cross
+    step(micro, micro)                                              # warm-up, untimed (1 warm-up + 3 timed)
+    n = B - B % micro if B >= micro else B
+    dts = [step(n, micro) for _ in range(CPU_TIMED_STEPS)]
+    return sorted(dts)[len(dts) // 2], cores, dts
 
 
 def hbm_traffic(launcher):
@@ -146,8 +147,28 @@ def hbm_traffic(launcher):
     return (round(tot / n) if n else None), src
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process -- before this process has
+    made any GPU call (it never makes one) -- let it inherit stdout / stderr, so rank 0's JSON line is this command's JSON line, and
+    return its exit code.  What `accelerate launch` + `accelerator.prepare` do for the reference (delete_celeb.py:99-101,304)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                      # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -409,7 +430,7 @@ def main():
                                                 "attention_head_dim", "norm_num_groups", "norm_eps",
                                                 "downsample_padding", "flip_sin_to_cos", "freq_shift")
                   + (("cross_attention_dim",) if sd else ())}
-        cdt, cores, cdt2 = cpu_baseline(cfg_kw, 42, sd, B)
+        cdt, cores, cdts = cpu_baseline(cfg_kw, 42, sd, B)
         try:
             model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
         except Exception:
@@ -417,14 +438,13 @@ def main():
         Bc = B - B % min(CPU_MICRO_BATCH, B) if B >= CPU_MICRO_BATCH else B
         cpu = {"value": round(Bc / cdt, 5), "unit": "samples/sec", "cores": cores, "cpu_model": model,
                "kind": "port",
-               "sample": f"1 untimed warm-up step at batch {min(CPU_MICRO_BATCH, B)}, then ONE timed optimizer step over the full per-GPU "
-                         f"batch of {Bc} (as {max(Bc // CPU_MICRO_BATCH, 1)} micro-batches of {min(CPU_MICRO_BATCH, B)} with gradient accumulation: "
-                         f"same arithmetic, bounded host memory) of the same UNet / resolution, fp32 torch CPU oracle, {cdt:.1f} s",
+               "sample": f"1 untimed warm-up step at batch {min(CPU_MICRO_BATCH, B)}, then {len(cdts)} timed optimizer steps (median reported) "
+                         f"over the full per-GPU batch of {Bc} (as {max(Bc // CPU_MICRO_BATCH, 1)} micro-batches of {min(CPU_MICRO_BATCH, B)} with "
+                         f"gradient accumulation: same arithmetic, bounded host memory) of the same UNet / resolution, fp32 torch CPU oracle, "
+                         f"{cdt:.1f} s per step",
                "extrapolated": False,
                "steps_per_sec_at_bs%d" % Bc: round(1.0 / cdt, 6),
-               "cross_check": {"batch": min(CPU_CROSS_BATCH, B), "seconds": round(cdt2, 2),
-                               "samples_per_sec": round(min(CPU_CROSS_BATCH, B) / cdt2, 5),
-                               "note": "rounds 1-2 reported this batch-2 step, extrapolated"}}
+               "timed_steps_s": [round(x, 2) for x in cdts]}
 
     if rank == 0:
         steps_per_sec = 1e3 / ms

@@ -352,6 +352,28 @@ int siss_gemm_nt_set_c3p_blocks(int n) {
 }  // extern "C"
 
 namespace {
+// THE eligibility predicate of the persistent 3x3 kernel (gemm_nt_c3p.hip) for everything but the panel pattern: used by
+// gemm_nt_dispatch AND by the host-side siss_conv3x3_*_takes queries, so the two cannot drift apart.  The kernel addresses its
+// tensors by 32-bit byte offsets (tensors of 4 GiB and more stay on the generic kernels); ldr / lda2 / ldcx = 0: operand absent.
+constexpr long kC3pMinTiles = 256;
+bool c3p_eligible(int M, int N, int Kp, int rows_per_image, int Wp, long lda, long ldc, long ldr, long lda2, int K2, long ldcx, int Nx) {
+    const long lim = 1L << 32;
+    if (M <= 0 || N <= 0 || Kp <= 0 || Kp % BK || N % BN || rows_per_image < 256 || (Wp != 0 && Wp < 8)) return false;
+    if ((long)cdiv(M, 128) * cdiv(N, BN) < kC3pMinTiles) return false;
+    if (!((long)M * ldc * 2 < lim && (long)(M + 2) * lda * 2 < lim && (long)N * Kp * 2 < lim)) return false;
+    if (ldr && !((long)M * ldr * 2 < lim)) return false;
+    if (lda2 && !(K2 > 0 && K2 % BK == 0 && (long)(M + 2) * lda2 * 2 < lim && (long)N * K2 * 2 < lim)) return false;
+    if (ldcx && !(Nx > 0 && Nx % BN == 0 && Kp >= 2 * BK && (long)M * ldcx * 2 < lim && (long)Nx * Kp * 2 < lim)) return false;
+    return true;
+}
+bool is_conv3x3_pattern(const int* shifts, const int* coffs) {
+    for (int g = 0; g < 3; ++g)
+        if (!(shifts[3 * g + 1] == shifts[3 * g] + 1 && shifts[3 * g + 2] == shifts[3 * g] + 2 && coffs[3 * g + 1] == coffs[3 * g] &&
+              coffs[3 * g + 2] == coffs[3 * g]))
+            return false;
+    return true;
+}
+
 int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, const float* bias,
                      const float* rowbias, long ldrb, const void* R, long ldr, int M, int N, int Kp, int npanels,
                      const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, float alpha,
@@ -400,16 +422,8 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     // kx taps, DMA / store waves beside the MFMA waves).  Measured sweep of the threshold (round 1, 2048 .. 32): 256 gives the
     // shortest step.  It addresses its tensors by 32-bit byte offsets: tensors of 4 GiB and more stay on the kernels below.
     {
-        bool conv3 = npanels == 9 && batch == 1 && !rowsub && !mul_r && !d2s;
-        for (int g = 0; conv3 && g < 3; ++g)
-            conv3 = p.shift[3 * g + 1] == p.shift[3 * g] + 1 && p.shift[3 * g + 2] == p.shift[3 * g] + 2 &&
-                    p.coff[3 * g + 1] == p.coff[3 * g] && p.coff[3 * g + 2] == p.coff[3 * g];
-        constexpr long kC3pMinTiles = 256;
-        const long tiles = (long)cdiv(M, 128) * cdiv(N, BN);
-        const bool fits32 = (long)M * ldc * 2 < (1L << 32) && (!R || (long)M * ldr * 2 < (1L << 32)) && (long)(M + 2) * lda * 2 < (1L << 32) &&
-                            (long)N * Kp * 2 < (1L << 32) && (!A2 || ((long)(M + 2) * lda2 * 2 < (1L << 32) && (long)N * K2 * 2 < (1L << 32))) &&
-                            (!Cx || ((long)M * ldcx * 2 < (1L << 32) && (long)Nx * Kp * 2 < (1L << 32) && Kp >= 2 * BK));
-        if (conv3 && N % BN == 0 && rows_per_image >= 256 && (Wp == 0 || Wp >= 8) && tiles >= kC3pMinTiles && fits32) {
+        const bool conv3 = npanels == 9 && batch == 1 && !rowsub && !mul_r && !d2s && is_conv3x3_pattern(p.shift, p.coff);
+        if (conv3 && c3p_eligible(M, N, Kp, rows_per_image, Wp, lda, ldc, R ? ldr : 0, A2 ? lda2 : 0, K2, Cx ? ldcx : 0, Nx)) {
             if (qstats && Hp > 0 && ((uintptr_t)qstats % 16) == 0) {
                 p.qstats = qstats;                          // only the persistent kernel forms them; the caller is told
                 if (qstats_written) *qstats_written = 1;
@@ -494,15 +508,13 @@ int siss_gemm_nt_qstats(const void* A, long lda, const void* W, void* C, long ld
 // qstats / written: as siss_gemm_nt_qstats (both may be null).  Each term is accumulated in f32 and rounded ONCE (the two-launch form
 // rounds the shortcut's output to bf16 first).
 int siss_conv3x3_sc_takes(int M, int N, int Kp, int K2, int rows_per_image, int Wp, long lda, long ldc, long lda2) {
-    if (M <= 0 || N <= 0 || Kp <= 0 || Kp % BK || K2 <= 0 || K2 % BK || N % BN || rows_per_image < 256 || (Wp != 0 && Wp < 8)) return 0;
-    if ((long)cdiv(M, 128) * cdiv(N, BN) < 256) return 0;
-    return (long)M * ldc * 2 < (1L << 32) && (long)(M + 2) * lda * 2 < (1L << 32) && (long)N * Kp * 2 < (1L << 32) &&
-           (long)(M + 2) * lda2 * 2 < (1L << 32) && (long)N * K2 * 2 < (1L << 32);
+    return lda2 > 0 && c3p_eligible(M, N, Kp, rows_per_image, Wp, lda, ldc, 0, lda2, K2, 0, 0) ? 1 : 0;
 }
 int siss_conv3x3_sc(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const float* rowbias, long ldrb,
                     const void* A2, long lda2, const void* W2, int K2, const float* bias2, int M, int N, int Kp, const int* shifts,
                     const int* coffs, int rows_per_image, int Hp, int Wp, float* qstats, int* written, void* stream) {
-    SISS_CHECK_ARG(A2 && W2 && siss_conv3x3_sc_takes(M, N, Kp, K2, rows_per_image, Wp, lda, ldc, lda2));
+    SISS_CHECK_ARG(A2 && W2 && shifts && coffs && is_conv3x3_pattern(shifts, coffs));     // (a 3x3 filter's nine panels: layout.conv3x3_panels)
+    SISS_CHECK_ARG(siss_conv3x3_sc_takes(M, N, Kp, K2, rows_per_image, Wp, lda, ldc, lda2));
     return gemm_nt_dispatch(A, lda, W, C, ldc, bias, rowbias, ldrb, nullptr, 0, M, N, Kp, 9, shifts, coffs, rows_per_image, Hp, Wp,
                             1.0f, 1, 0, 0, 0, nullptr, 0, stream, qstats, written, 0, A2, lda2, W2, K2, bias2);
 }
@@ -512,16 +524,15 @@ int siss_conv3x3_sc(const void* A, long lda, const void* W, void* C, long ldc, c
 // ldcx elements, halo rows zeroed) -- both read the same cotangent A.  On its own the 1x1 product is HBM-bound (it writes Nx / N times
 // the 3x3 product's output); here it runs as extra column tiles of the persistent kernel.  R (optional) is added to C only.
 // siss_conv3x3_dgrad_sc_takes: whether a product of this shape lands on that kernel (else: two siss_gemm_nt calls).
-int siss_conv3x3_dgrad_sc_takes(int M, int N, int Kp, int Nx, int rows_per_image, int Wp, long lda, long ldc, long ldcx) {
-    if (M <= 0 || N <= 0 || Kp < 2 * BK || Kp % BK || Nx <= 0 || Nx % BN || N % BN || rows_per_image < 256 || (Wp != 0 && Wp < 8)) return 0;
-    if ((long)cdiv(M, 128) * cdiv(N, BN) < 256) return 0;
-    return (long)M * ldc * 2 < (1L << 32) && (long)(M + 2) * lda * 2 < (1L << 32) && (long)N * Kp * 2 < (1L << 32) &&
-           (long)M * ldcx * 2 < (1L << 32) && (long)Nx * Kp * 2 < (1L << 32);
+// (ldr: the row stride of R, 0 without one -- R is addressed by 32-bit offsets too)
+int siss_conv3x3_dgrad_sc_takes(int M, int N, int Kp, int Nx, int rows_per_image, int Wp, long lda, long ldc, long ldcx, long ldr) {
+    return ldcx > 0 && c3p_eligible(M, N, Kp, rows_per_image, Wp, lda, ldc, ldr, 0, 0, ldcx, Nx) ? 1 : 0;
 }
 int siss_conv3x3_dgrad_sc(const void* A, long lda, const void* W, void* C, long ldc, const void* R, long ldr, const void* Wx, void* Cx,
                           long ldcx, int Nx, int M, int N, int Kp, const int* shifts, const int* coffs, int rows_per_image, int Hp,
                           int Wp, void* stream) {
-    SISS_CHECK_ARG(Wx && Cx && siss_conv3x3_dgrad_sc_takes(M, N, Kp, Nx, rows_per_image, Wp, lda, ldc, ldcx));
+    SISS_CHECK_ARG(Wx && Cx && shifts && coffs && is_conv3x3_pattern(shifts, coffs));
+    SISS_CHECK_ARG(siss_conv3x3_dgrad_sc_takes(M, N, Kp, Nx, rows_per_image, Wp, lda, ldc, ldcx, R ? ldr : 0));
     return gemm_nt_dispatch(A, lda, W, C, ldc, nullptr, nullptr, N, R, ldr, M, N, Kp, 9, shifts, coffs, rows_per_image, Hp, Wp,
                             1.0f, 1, 0, 0, 0, nullptr, 0, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, Wx, Cx, ldcx, Nx);
 }

@@ -38,7 +38,7 @@ SIGNATURES = {
     "siss_conv3x3_sc": [P, L, P, P, L, P, P, L, P, L, P, I, P, I, I, I, IP, IP, I, I, I, P, IP, P],
     "siss_conv3x3_sc_takes": [I, I, I, I, I, I, L, L, L],
     "siss_conv3x3_dgrad_sc": [P, L, P, P, L, P, L, P, P, L, I, I, I, I, IP, IP, I, I, I, P],
-    "siss_conv3x3_dgrad_sc_takes": [I, I, I, I, I, I, L, L, L],
+    "siss_conv3x3_dgrad_sc_takes": [I, I, I, I, I, I, L, L, L, L],
     "siss_conv_qstats_words": [L, I],
     "siss_gemm_nt_d2s": [P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, I, P],
     "siss_gemm_nt_set_workspace": [P, L],

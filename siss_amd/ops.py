@@ -131,10 +131,11 @@ def conv_dgrad(dy: Act, wT_bf16, out: Act, residual: Act = None, ksize=3):
     return out
 
 
-def conv3x3_dgrad_sc_takes(dy: Act, ci, out: Act, out_x: Act):
-    """Whether conv_dgrad_sc can run the 1x1 shortcut's dgrad (-> out_x) inside the 3x3 dgrad (-> out) over the same cotangent."""
+def conv3x3_dgrad_sc_takes(dy: Act, ci, out: Act, out_x, residual: Act = None):
+    """Whether conv_dgrad_sc can run the 1x1 shortcut's dgrad (-> out_x) inside the 3x3 dgrad (-> out) over the same cotangent
+    (residual: what conv_dgrad_sc will be given -- its size is part of the kernel's 32-bit addressing limit)."""
     return bool(lib.query("siss_conv3x3_dgrad_sc_takes", dy.rows, ci, dy.c, out_x.c, dy.rows_per_image, dy.wp, dy.c,
-                          getattr(out, "ld", out.c), getattr(out_x, "ld", out_x.c)))
+                          getattr(out, "ld", out.c), getattr(out_x, "ld", out_x.c), residual.c if residual is not None else 0))
 
 
 def conv_dgrad_sc(dy: Act, wT_bf16, out: Act, wT_sc_bf16, out_x: Act, residual: Act = None):

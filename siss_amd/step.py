@@ -125,20 +125,35 @@ class SISSStepper:
         # the timed steps are real optimizer steps: put parameters, AdamW moments, the step counter and the stepper's own
         # state (NegGrad's decaying superfactor, the last step's statistics) back afterwards -- the run that follows starts
         # from what it was given, whichever candidate wins
+        self._gather_optimizer_state()          # sharded steps before this call left the moments current on the owner's shard only
         saved = [t.clone() for t in (self.opt.p, self.opt.m, self.opt.v, self.opt.scalars)]
         saved_state = (self.superfactor, self.last, self._micro)
         errors = {}
         for name, (mode, exch) in candidates.items():
             self.set_overlap(mode, exch)
+            exc = None
             try:
                 step_fn()                                        # settle (scratch buffers, communicator channels)
-            except (RuntimeError, NotImplementedError) as exc:
-                # a collective this backend does not offer raises on EVERY rank at the call: the candidate is dropped everywhere
-                # (the sharded update's all-to-all is the likely one); the serial all-reduce must work or the run has no exchange
-                if name == "serial":
-                    raise
-                errors[name] = (str(exc) or type(exc).__name__)[:200]
+            except (RuntimeError, NotImplementedError) as e:
+                exc = e
+            # A failure may be rank-LOCAL (torch's OOM is a RuntimeError; a launch error): the ranks AGREE on it before any of
+            # them decides -- a rank that skipped the candidate alone would leave the others waiting in the barrier below.
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, exc is not None, group=self.pg)
+            if any(gathered):
+                # collectives a backward hook already started must retire before the next candidate rewrites the gradient
+                # buffer they read -- wait on them, do not just forget them
+                for work in self._pending:
+                    try:
+                        if work is not None:
+                            work.wait()
+                    except Exception:
+                        pass
+                torch.cuda.synchronize()
                 self._pending, self._micro, self._state_shard = [], 0, None
+                if name == "serial":            # the serial all-reduce must work or the run has no exchange
+                    raise exc if exc is not None else RuntimeError("the serial gradient exchange failed on another rank")
+                errors[name] = ((str(exc) or type(exc).__name__) if exc is not None else "failed on another rank")[:200]
                 continue
             dist.barrier(group=self.pg); torch.cuda.synchronize()
             t0 = time.perf_counter()

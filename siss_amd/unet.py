@@ -18,6 +18,7 @@ Parameter names are the diffusers state-dict keys, so checkpoints round-trip.
 """
 import math
 from dataclasses import dataclass
+from types import SimpleNamespace
 
 import torch
 
@@ -550,8 +551,9 @@ class UNetEngine:
                 ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
 
         def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None, sc_dgrad=None):
-            """sc_dgrad = (pre2, out2): also form the dgrad of the 1x1 convolution `pre2` over the SAME cotangent into out2 -- inside
-            this 3x3 dgrad when its kernel takes it (returns (dx, True)), else not at all (returns (dx, False): the caller runs it)."""
+            """sc_dgrad = (pre2, c2, get_out2): also form the dgrad of the 1x1 convolution `pre2` (c2 input channels) over the SAME
+            cotangent into get_out2() -- inside this 3x3 dgrad when its kernel takes it (returns (dx, out2)), else not at all (returns
+            (dx, None): the caller runs it, and no buffer was taken)."""
             dW = ps.grads[self.gbase:, ps.specs[pre + ".weight"].off:]
             # the bias gradient (column sums of dy) rides along in the wgrad GEMM as one more product
             self._wgrad(dy, x, dW, co, x.c, ksize, dbias=ps.g(pre + ".bias", self.gbase) if bias_grad else None,
@@ -562,14 +564,17 @@ class UNetEngine:
                 self._wsync(accum)
             dx = accum if accum is not None else self._get(dy.n, x.h, x.w, x.c)
             if sc_dgrad is not None:
-                pre2, out2 = sc_dgrad
+                pre2, c2, get_out2 = sc_dgrad
                 # (not with more than twice the 3x3 product's columns: every x tile pays a tile's fixed epilogue for a third of its
                 # MFMAs -- measured at 128 x 128, 128 -> 128 with a 384-channel shortcut: 424 us folded against 129 + 149 us apart)
-                if self.fold_shortcut and ksize == 3 and out2.c <= 2 * x.c and ops.conv3x3_dgrad_sc_takes(dy, x.c, dx, out2):
+                # The x-shaped target (the concat-wide input on the up path) is only taken from the pool once the fold is decided.
+                if (self.fold_shortcut and ksize == 3 and c2 <= 2 * x.c
+                        and ops.conv3x3_dgrad_sc_takes(dy, x.c, dx, SimpleNamespace(c=c2, ld=c2), residual=accum)):
+                    out2 = get_out2()
                     ops.conv_dgrad_sc(dy, self.wT[pre + ".weight"], dx, self.wT[pre2 + ".weight"][0], out2, residual=accum)
-                    return dx, True
+                    return dx, out2
                 ops.conv_dgrad(dy, self.wT[pre + ".weight"], dx, residual=accum, ksize=ksize)
-                return dx, False
+                return dx, None
             ops.conv_dgrad(dy, self.wT[pre + ".weight"], dx, residual=accum, ksize=ksize)
             return dx
         return y, bwd
@@ -669,11 +674,10 @@ class UNetEngine:
             gb = self.gbase
             # conv2 (its bias gradient equals the shortcut conv's bias gradient: same pre-activation).  With a shortcut, its dgrad
             # (dout . W_sc, HBM-bound on its own) rides in conv2's 3x3 dgrad over the same cotangent where that kernel takes it
-            sc_folded = False
+            acc_sc = None
             if has_sc:
-                acc_sc = self._get(nb, x.h, x.w, x.c)
-                da2, sc_folded = c2_b(dout, bias_grad2=ps.g(pre + ".conv_shortcut.bias", gb),
-                                      sc_dgrad=(pre + ".conv_shortcut", acc_sc))
+                da2, acc_sc = c2_b(dout, bias_grad2=ps.g(pre + ".conv_shortcut.bias", gb),
+                                   sc_dgrad=(pre + ".conv_shortcut", x.c, lambda: self._get(nb, x.h, x.w, x.c)))
             else:
                 da2 = c2_b(dout)
             # column sums of dh = cotangent of time_emb_proj's output (and of conv1's bias); the weight
@@ -684,11 +688,10 @@ class UNetEngine:
             self._put(dh)
             prior = self.gmap.pop(id(x), None)          # cotangent x already received from another consumer
             if has_sc:
-                if sc_folded:
+                if acc_sc is not None:
                     sc_b(dout, bias_grad=False, need_dx=False)      # the shortcut's weight gradient only
                     acc = acc_sc
                 else:
-                    self._put(acc_sc)
                     acc = sc_b(dout, bias_grad=False)
                 self._put(dout)
             else:

@@ -40,3 +40,19 @@ def test_bench_multi_rank_path_and_replica_selfcheck():
     assert chk == {"rccl_ranks_seen": 2, "replicas_identical": True, "finite": True, "backend": "gloo"}, chk
     assert out["config"]["global_batch"] == 4 and out["value"] > 0
     assert out["config"]["dp_allreduce"]["allreduce"]["ms"] > 0
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` with NO torchrun on the command line and no WORLD_SIZE in the environment: the parent starts
+    the ranks itself (a child `torch.distributed.run`, before any GPU call) and its stdout carries rank 0's JSON line -- how a
+    driver that runs `--gpus 8` the way it runs `--gpus 1` reaches the data-parallel path (gloo rehearsal on the one GPU)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SISS_DIST_BACKEND="gloo", SISS_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--config", "small", "--batch", "2", "--no-cpu-baseline", "--no-kernel-timing"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["dp_selfcheck"]["rccl_ranks_seen"] == 2
+    assert out["config"]["dp_selfcheck"]["replicas_identical"] is True
