@@ -45,6 +45,7 @@ def parse():
                     help="replay the step from a captured hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--engine-attr", action="append", default=[], help="name=int: set a schedule switch of the engine (A/B runs)")
     ap.add_argument("--lib-set", action="append", default=[], help="name=int: call a process-wide setter of the library (A/B runs)")
+    ap.add_argument("--lib", default=None, help="path of another build of libsiss_hip.so (same-box A/B of a kernel change)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -192,6 +193,8 @@ def main():
     from siss_amd.config import UNet2DConfig
     from siss_amd.step import SISSStepper
     from siss_amd.unet import UNetEngine
+    if a.lib:
+        lib.LIB_PATH = os.path.abspath(a.lib)
 
     sd = a.config == "sd15"
     if a.config == "celebahq256":
@@ -361,11 +364,13 @@ def main():
     if not a.no_kernel_timing:
         # every rank runs these steps (the step holds a collective when N>1); only rank 0 records events
         lib.PROF = [] if rank == 0 else None
+        side_stream, eng.wgrad_stream = eng.wgrad_stream, 0      # one stream: a launch's events then bracket that launch alone
         ksteps = min(a.steps, 3)
         for _ in range(ksteps):
             one_step()
         sync()
         prof, lib.PROF = lib.PROF, None
+        eng.wgrad_stream = side_stream
     if not a.no_kernel_timing and rank == 0:
         ksym = {}
         hbm = {}

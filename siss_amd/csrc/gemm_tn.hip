@@ -17,6 +17,7 @@
 // Split-K over row ranges; partial tiles are accumulated with f32 global atomics (no-return
 // global_atomic_add_f32; 16 consecutive floats per lane group).
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -636,12 +637,21 @@ static int launch_tn_group(const TNParams* ps, int n, hipStream_t st) {
     using C_ = TCfg<TAPS, TAPS == 3>;
     static unsigned char attr_set[kMaxDevices];
     if (siss_ensure_smem((const void*)gemm_tn_grouped_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
-    for (int i0 = 0; i0 < n; i0 += kMaxJobs) {
+    // Blocks are dispatched in grid order, one resident block per CU: a launch ends with whichever blocks were dispatched last,
+    // and a long block (up to 128 K-steps, ~190 us) dispatched near the end leaves most CUs idle behind it.  Longest blocks
+    // first (LPT): jobs sorted by descending K-steps per block and dealt round-robin to the launches, so that every launch
+    // starts with its longest blocks and drains through its shortest ones (the 8 x 8 levels' ~25-step blocks).
+    int order[256];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order, order + n, [&](int a, int b) { return ps[a].rows_per_split > ps[b].rows_per_split; });
+    const int nlaunch = cdiv(n, kMaxJobs);
+    for (int l = 0; l < nlaunch; ++l) {
         TNGroup g;
-        g.njobs = n - i0 < kMaxJobs ? n - i0 : kMaxJobs;
+        g.njobs = 0;
         int total = 0;
-        for (int j = 0; j < g.njobs; ++j) {
-            const TNParams& p = ps[i0 + j];
+        for (int i = l; i < n; i += nlaunch) {
+            const TNParams& p = ps[order[i]];
+            const int j = g.njobs++;
             g.job[j] = p;
             g.first[j] = total;
             g.nwg[j] = cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits;
