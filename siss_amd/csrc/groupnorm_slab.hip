@@ -5,7 +5,7 @@
 // of one sample on chip, so the statistics need no other block: one launch instead of two, no atomics for the statistics,
 // every byte read once, bitwise deterministic (fixed-order LDS folds).
 // (The two-phase persistent form for the LARGE sites -- per-sample barrier, fixed-point accumulators -- measured 2x slower
-// than the two-pass kernels and lives in tools/probes/groupnorm2p.hip)
+// than the two-pass kernels and lives in tools/probes/groupnorm2p.hip; docs/experiments.md.)
 #include "common.h"
 #include <type_traits>
 

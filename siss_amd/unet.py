@@ -153,7 +153,7 @@ class ParamStore:
 
 class UNetEngine:
     """Static-schedule UNet.  ``forward(x, t)`` then ``backward(c, nsets)``."""
-    # Schedule switches: plain attributes, the defaults are the measured-best settings (DESIGN.md section 3.2); the parity
+    # Schedule switches: plain attributes, the defaults are the measured-best settings (docs/experiments.md); the parity
     # tests flip them on an instance to compare the two forms of the same math.
     epi_stats = True       # GroupNorm statistics from the producing conv's epilogue (no statistics pass at the large sites)
     d2s_epilogue = True    # downsample dgrad: depth-to-space in the plane GEMMs' epilogue (no dz tensor, no scatter pass)

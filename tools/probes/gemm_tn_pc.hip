@@ -1,4 +1,4 @@
-// RECORD OF A MEASURED-AND-REJECTED KERNEL (round 3) -- not part of the product build.
+// RECORD OF A MEASURED-AND-REJECTED KERNEL (round 3; docs/experiments.md) -- not part of the product build.
 // gemm_tn.hip plus a PRODUCER / CONSUMER one-tap kernel (tn_pc_body: tile 128 n x 256 c, four consumer waves with 64 x 128 wave
 // tiles, four DMA waves, ring of six 32-row stages, one barrier per stage, ring unrolled so that slot offsets are immediates), a
 // column planner (tn_plan) and siss_gemm_tn_set_pc_min_rows (common.h needs SISS_K_TNPC in SissKernelId to build it).

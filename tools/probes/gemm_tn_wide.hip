@@ -1,4 +1,4 @@
-// RECORD OF A MEASURED-AND-REJECTED KERNEL (round 3) -- not part of the product build.
+// RECORD OF A MEASURED-AND-REJECTED KERNEL (round 3; docs/experiments.md) -- not part of the product build.
 // gemm_tn.hip plus a WIDE one-tap tile (128 n x 384 / 256 c, tn_wide_body<NT>) for the transformer linears' weight gradients, a
 // column planner (tn_plan) and siss_gemm_tn_set_wide_min_rows.  Bit-for-bit parity with the f32 matmul held (8 shapes x single /
 // grouped launches), but it is SLOWER than the 128 x 128 tile: saturated (rows 65536, N 2048, C 768, two sets) 812 vs 881 TF/s;

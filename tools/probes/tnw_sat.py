@@ -1,6 +1,6 @@
 """Saturated single-job timing of the one-panel weight-gradient kernels: rows 65536, N 2048, C 768 (or argv[1]), two sets.
 Needs a VARIANT library built from tools/probes/gemm_tn_pc.hip (or gemm_tn_wide.hip with its setter name) and loaded through
-SISS_LIB_PATH: the product library has no siss_gemm_tn_set_pc_min_rows.  Record of DESIGN.md section 3.2's rejected kernels."""
+SISS_LIB_PATH: the product library has no siss_gemm_tn_set_pc_min_rows.  Record of docs/experiments.md's rejected kernels."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
