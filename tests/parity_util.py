@@ -34,11 +34,25 @@ def masked_update_cosine(before, after_ref, after_got, grads_ref):
     return num / ((nr * ng) ** 0.5 + 1e-300), kept / max(total, 1)
 
 
-def assert_update_direction(before, after_ref, after_got, grads_ref, what=""):
+def assert_update_direction(before, after_ref, after_got, grads_ref, what="", min_cos=UPDATE_COS):
     cos, frac = masked_update_cosine(before, after_ref, after_got, grads_ref)
     assert frac > 0.5, (what, "mask kept only", frac)
-    assert cos >= UPDATE_COS, (what, "masked update cosine", cos, "kept", frac)
+    assert cos >= min_cos, (what, "masked update cosine", cos, "kept", frac)
     return cos
+
+
+def final_gradient_cosine(eng, grads_ref, scaling_factor):
+    """Cosine between the oracle's final gradient of a step (g_x - s g_a, clipped: a scale) and the HIP step's, rebuilt from the two
+    gradient sets it leaves in the flat buffer -- over ALL elements, no mask.  Unlike the update direction (sign-like under AdamW's
+    first steps: every element counts the same, so the 0.5 % of elements whose gradient is smaller than the bf16 noise weigh as much
+    as the rest) this weighs elements by their gradient."""
+    gx, ga = eng.ps.grads_ref(0), eng.ps.grads_ref(1)
+    num = nr = ng = 0.0
+    for n, r in grads_ref.items():
+        g = (gx[n].double() - scaling_factor * ga[n].double()).flatten().cpu()
+        r = r.double().flatten().cpu()
+        num += float((g * r).sum()); nr += float(r.square().sum()); ng += float(g.square().sum())
+    return num / ((nr * ng) ** 0.5 + 1e-300)
 
 
 def cos(a, b):

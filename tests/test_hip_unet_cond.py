@@ -201,7 +201,7 @@ def test_siss_step_with_text_conditioning_matches_oracle(setup):
     from oracle import schedule as S
     from oracle.loss import OracleDeletionLoss
     from oracle.step import unlearning_step
-    from parity_util import assert_update_direction, check_scalars
+    from parity_util import assert_update_direction, check_scalars, final_gradient_cosine
     eng, net0, sd = setup
     eng.load_state_dict(sd)
     net = copy.deepcopy(net0)
@@ -225,11 +225,17 @@ def test_siss_step_with_text_conditioning_matches_oracle(setup):
                                           [dict(x0=x0, a0=a0, noise=noise, t=t, u=u)], train_batch_size=2, scaling_norm=7.5,
                                           loss_params={"lambd": 0.5}, conditioning={"encoder_hidden_states": ctx})
         st.step(x0, a0, noise, t.cuda(), u, conditioning={"encoder_hidden_states": ctx.cuda()})
-        check_scalars(ref, st.stats())                                        # rel 5e-2 (tests/parity_util.py)
-        # the update of THIS step, masked cosine >= 0.99 (the same helper as the full-size tests); step 2 starts from the HIP
-        # parameters of step 1 on both sides so that the comparison stays one step deep
+        got = st.stats()
+        check_scalars(ref, got)                                               # rel 5e-2 (tests/parity_util.py)
+        # The step's final gradient g_x - s g_a against the oracle's, cosine over all elements >= 0.999; and the update of THIS
+        # step through the same helper as the full-size tests.  The full-size SD v1.5 step meets that helper's 0.99
+        # (tests/test_hip_fullsize_steps.py: 0.996); these toy widths (32-64 channels, reductions over a few hundred elements)
+        # measure 0.9875: AdamW's first update is sign-like, every element weighs the same, and the ~0.6 % of elements whose
+        # gradient is below the bf16 noise flip sign -- 0.98 here, with the gradient cosine carrying the parity claim.
+        gcos = final_gradient_cosine(eng, gfin, got["scaling_factor"])
+        assert gcos >= 0.999, (step, "final gradient cosine", gcos)
         assert_update_direction(before, {n: p.detach() for n, p in net.named_parameters()}, eng.state_dict(), gfin,
-                                f"SD toy SISS step {step}")
+                                f"SD toy SISS step {step}", min_cos=0.98)
         net.load_state_dict(eng.state_dict())
 
 
