@@ -67,9 +67,9 @@ __global__ __launch_bounds__(kThreads) void softmax_bwd_kernel(const bf16_t* __r
 // ---- multi-head attention with a SMALL head dim (diffusers default attention_head_dim = 8: MNIST UNet) -------
 // d = 8 is far below an MFMA tile; one block per (sample, head) keeps the head's K / V (and Q, dO, O in the
 // backward) in LDS as f32 and runs an online-softmax row per thread.  Tokens are compact [N][S][C], C = heads*D.
-template <int D>
-__global__ __launch_bounds__(kThreads) void mha_small_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                                 const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+template <int D, typename T>
+__global__ __launch_bounds__(kThreads) void mha_small_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                 const T* __restrict__ v, T* __restrict__ o,
                                                                  float* __restrict__ lse, int S, int C, float scale) {
     extern __shared__ float sh[];          // K [S][D], V [S][D]
     float* sk = sh; float* sv = sh + S * D;
@@ -77,14 +77,14 @@ __global__ __launch_bounds__(kThreads) void mha_small_fwd_kernel(const bf16_t* _
     const long base = (long)b * S * C + h * D;
     for (int i = threadIdx.x; i < S * D; i += kThreads) {
         const int r = i / D, c = i - r * D;
-        sk[i] = bf2f(k[base + (long)r * C + c]);
-        sv[i] = bf2f(v[base + (long)r * C + c]);
+        sk[i] = to_f(k[base + (long)r * C + c]);
+        sv[i] = to_f(v[base + (long)r * C + c]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < S; i += kThreads) {
         float qi[D], acc[D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) { qi[c] = bf2f(q[base + (long)i * C + c]) * scale; acc[c] = 0.f; }
+        for (int c = 0; c < D; ++c) { qi[c] = to_f(q[base + (long)i * C + c]) * scale; acc[c] = 0.f; }
         float m = -INFINITY, l = 0.f;
         for (int j = 0; j < S; ++j) {
             float sc = 0.f;
@@ -98,17 +98,17 @@ __global__ __launch_bounds__(kThreads) void mha_small_fwd_kernel(const bf16_t* _
         }
         const float inv = 1.f / l;
 #pragma unroll
-        for (int c = 0; c < D; ++c) o[base + (long)i * C + c] = f2bf(acc[c] * inv);
+        for (int c = 0; c < D; ++c) o[base + (long)i * C + c] = from_f<T>(acc[c] * inv);
         lse[((long)b * heads + h) * S + i] = m + __logf(l);
     }
 }
 
 // n2 cotangent samples against nx saved samples (saved index = n2 % nx)
-template <int D>
+template <int D, typename T>
 __global__ __launch_bounds__(kThreads) void mha_small_bwd_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-    const bf16_t* __restrict__ o, const float* __restrict__ lse, const bf16_t* __restrict__ dout,
-    bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int nx, int S, int C, float scale) {
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+    const T* __restrict__ o, const float* __restrict__ lse, const T* __restrict__ dout,
+    T* __restrict__ dq, T* __restrict__ dk, T* __restrict__ dv, int nx, int S, int C, float scale) {
     extern __shared__ float sh[];          // Q, K, V, dO [S][D] each, delta [S], lse [S]
     float* sq = sh; float* sk = sq + S * D; float* sv = sk + S * D; float* sd = sv + S * D;
     float* sdel = sd + S * D; float* sl = sdel + S;
@@ -116,12 +116,12 @@ __global__ __launch_bounds__(kThreads) void mha_small_bwd_kernel(
     const long bs = (long)n * S * C + h * D, bd = (long)n2 * S * C + h * D;
     for (int i = threadIdx.x; i < S * D; i += kThreads) {
         const int r = i / D, c = i - r * D;
-        sq[i] = bf2f(q[bs + (long)r * C + c]); sk[i] = bf2f(k[bs + (long)r * C + c]);
-        sv[i] = bf2f(v[bs + (long)r * C + c]); sd[i] = bf2f(dout[bd + (long)r * C + c]);
+        sq[i] = to_f(q[bs + (long)r * C + c]); sk[i] = to_f(k[bs + (long)r * C + c]);
+        sv[i] = to_f(v[bs + (long)r * C + c]); sd[i] = to_f(dout[bd + (long)r * C + c]);
     }
     for (int i = threadIdx.x; i < S; i += kThreads) {
         float t = 0.f;
-        for (int c = 0; c < D; ++c) t += bf2f(dout[bd + (long)i * C + c]) * bf2f(o[bs + (long)i * C + c]);
+        for (int c = 0; c < D; ++c) t += to_f(dout[bd + (long)i * C + c]) * to_f(o[bs + (long)i * C + c]);
         sdel[i] = t;
         sl[i] = lse[((long)n * heads + h) * S + i];
     }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void mha_small_bwd_kernel(
             for (int c = 0; c < D; ++c) acc[c] += ds * sk[j * D + c];
         }
 #pragma unroll
-        for (int c = 0; c < D; ++c) dq[bd + (long)i * C + c] = f2bf(acc[c]);
+        for (int c = 0; c < D; ++c) dq[bd + (long)i * C + c] = from_f<T>(acc[c]);
     }
     // dK, dV: thread per key row
     for (int j = threadIdx.x; j < S; j += kThreads) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void mha_small_bwd_kernel(
             for (int c = 0; c < D; ++c) { ak[c] += ds * sq[i * D + c]; av[c] += p * sd[i * D + c]; }
         }
 #pragma unroll
-        for (int c = 0; c < D; ++c) { dk[bd + (long)j * C + c] = f2bf(ak[c]); dv[bd + (long)j * C + c] = f2bf(av[c]); }
+        for (int c = 0; c < D; ++c) { dk[bd + (long)j * C + c] = from_f<T>(ak[c]); dv[bd + (long)j * C + c] = from_f<T>(av[c]); }
     }
 }
 
@@ -193,7 +193,7 @@ int siss_mha_small_fwd(const void* q, const void* k, const void* v, void* o, flo
     dim3 grid(C / D, N);
     const size_t smem = (size_t)S * D * 2 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    MHA_DISPATCH(D, (mha_small_fwd_kernel<kD><<<grid, kThreads, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, S, C, scale)));
+    MHA_DISPATCH(D, (mha_small_fwd_kernel<kD, bf16_t><<<grid, kThreads, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, S, C, scale)));
     SISS_LAUNCH_RET();
 }
 
@@ -205,7 +205,30 @@ int siss_mha_small_bwd(const void* q, const void* k, const void* v, const void* 
     dim3 grid(C / D, n2);
     const size_t smem = ((size_t)S * D * 4 + 2 * S) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    MHA_DISPATCH(D, (mha_small_bwd_kernel<kD><<<grid, kThreads, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, lse, (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, nx, S, C, scale)));
+    MHA_DISPATCH(D, (mha_small_bwd_kernel<kD, bf16_t><<<grid, kThreads, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, lse, (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, nx, S, C, scale)));
+    SISS_LAUNCH_RET();
+}
+
+
+// The same with f32 tokens (the f32 parity mode: f32_path.hip)
+int siss_mha_small_fwd_f32(const void* q, const void* k, const void* v, void* o, float* lse, int N, int S, int C, int D,
+                           float scale, void* stream) {
+    SISS_CHECK_ARG(q && k && v && o && lse && N > 0 && S > 0 && C > 0 && D > 0 && C % D == 0);
+    SISS_CHECK_ARG((long)S * D * 2 * 4 <= 64 * 1024 && N <= 65535);
+    dim3 grid(C / D, N);
+    const size_t smem = (size_t)S * D * 2 * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    MHA_DISPATCH(D, (mha_small_fwd_kernel<kD, float><<<grid, kThreads, smem, st>>>((const float*)q, (const float*)k, (const float*)v, (float*)o, lse, S, C, scale)));
+    SISS_LAUNCH_RET();
+}
+int siss_mha_small_bwd_f32(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
+                           void* dq, void* dk, void* dv, int n2, int nx, int S, int C, int D, float scale, void* stream) {
+    SISS_CHECK_ARG(q && k && v && o && lse && dout && dq && dk && dv && n2 > 0 && nx > 0 && S > 0 && C % D == 0);
+    SISS_CHECK_ARG(((long)S * D * 4 + 2 * S) * 4 <= 64 * 1024 && n2 <= 65535);
+    dim3 grid(C / D, n2);
+    const size_t smem = ((size_t)S * D * 4 + 2 * S) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    MHA_DISPATCH(D, (mha_small_bwd_kernel<kD, float><<<grid, kThreads, smem, st>>>((const float*)q, (const float*)k, (const float*)v, (const float*)o, lse, (const float*)dout, (float*)dq, (float*)dk, (float*)dv, nx, S, C, scale)));
     SISS_LAUNCH_RET();
 }
 

@@ -36,6 +36,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+// Element access generic over the ACTIVATION type: bf16_t (the product path) or float (the f32 parity mode, f32_path.hip and the
+// `_f32` entry points: `mixed_precision: null` of the reference's YAMLs -- every tensor f32, every product on v_mfma_f32_16x16x4_f32).
+__device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+__device__ __forceinline__ float to_f(float v) { return v; }
+template <typename T> __device__ __forceinline__ T from_f(float f);
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float f) { return f2bf(f); }
+template <> __device__ __forceinline__ float from_f<float>(float f) { return f; }
 // two floats -> one packed pair: ONE v_cvt_pk_bf16_f32 (a two-element vector conversion).  Written as two scalar casts + shift / or
 // it only became that instruction where the SLP vectoriser paired the casts; flash_attn.hip is built without it and paid
 // 2 conversions + a shift + an SDWA or per pair (64 instead of 16 vector instructions per tile in the dK / dV loop).

@@ -16,14 +16,15 @@ class Act:
 
     __slots__ = ("buf", "n", "h", "w", "c", "guard", "cat_parts", "cat_done", "qstats")
 
-    def __init__(self, n, h, w, c, device="cuda", buf=None):
+    def __init__(self, n, h, w, c, device="cuda", buf=None, dtype=torch.bfloat16):
+        """dtype: bf16 (the product path) or f32 (the f32 parity mode: csrc/f32_path.hip)."""
         self.n, self.h, self.w, self.c = n, h, w, c
         self.cat_parts, self.cat_done = None, False
         self.qstats = None                            # GroupNorm statistics left by the producing conv (engine bookkeeping)
         self.guard = (w + 2) + 2                      # rows of zero guard on each side
         rows = self.rows + 2 * self.guard
         if buf is None:
-            buf = torch.zeros(rows * c, dtype=torch.bfloat16, device=device)
+            buf = torch.zeros(rows * c, dtype=dtype, device=device)
         assert buf.numel() == rows * c
         self.buf = buf
 
@@ -63,16 +64,16 @@ class Act:
 
     def set_from_nchw(self, x):
         assert tuple(x.shape) == (self.n, self.c, self.h, self.w), (x.shape, (self.n, self.c, self.h, self.w))
-        self.interior().copy_(x.permute(0, 2, 3, 1).to(torch.bfloat16))
+        self.interior().copy_(x.permute(0, 2, 3, 1).to(self.buf.dtype))
         return self
 
     @staticmethod
-    def from_nchw(x, device="cuda"):
+    def from_nchw(x, device="cuda", dtype=torch.bfloat16):
         n, c, h, w = x.shape
-        return Act(n, h, w, c, device=device).set_from_nchw(x.to(device))
+        return Act(n, h, w, c, device=device, dtype=dtype).set_from_nchw(x.to(device))
 
     def like(self, c=None, n=None):
-        return Act(n or self.n, self.h, self.w, c or self.c, device=self.buf.device)
+        return Act(n or self.n, self.h, self.w, c or self.c, device=self.buf.device, dtype=self.buf.dtype)
 
     def halo_is_zero(self):
         p = self.padded().float()

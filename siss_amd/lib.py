@@ -97,6 +97,42 @@ SIGNATURES = {
     "siss_linear_multi_bwd": [P, P, P, P, P, P, P, P, I, I, I, L, I, I, P],
     "siss_linear_small_bwd": [P, P, P, P, P, I, P, P, P, I, I, I, L, L, I, I, I, P],
 }
+# ---- the f32 parity mode (csrc/f32_path.hip): same argument lists as the bf16 entry points, f32 tensors.  F32_ENTRY maps a bf16
+# entry point to its f32 form; F32_SAME lists the ones that never see an activation (f32 / index tensors only) and serve both
+# modes.  In f32 mode (f32_mode(True): set by an f32 engine around its launches) call() takes the f32 form and REFUSES an entry
+# point that has none -- a bf16 kernel handed f32 bytes would produce numbers, not an error.
+F32_ENTRY = {n: n + "_f32" for n in (
+    "siss_gemm_nt", "siss_gemm_tn", "siss_groupnorm_fwd_ld", "siss_groupnorm_bwd_ld", "siss_upsample2x", "siss_upsample2x_bwd",
+    "siss_concat", "siss_concat_tail", "siss_concat_bwd", "siss_add_inplace", "siss_space_to_depth_ld", "siss_depth_to_space",
+    "siss_pad_to_compact", "siss_compact_add_to_pad", "siss_im2col3x3", "siss_conv_out_fprop", "siss_mha_small_fwd",
+    "siss_mha_small_bwd", "siss_softmax_fwd", "siss_softmax_bwd")}
+F32_ENTRY.update({"siss_transpose_bf16": "siss_transpose_f32", "siss_cast_f32_bf16": "siss_copy_f32",
+                  "siss_conv_weight_dgrad_multi_bf16": "siss_conv_weight_dgrad_multi_f32"})
+F32_SAME = {"siss_timestep_sincos", "siss_linear_small_fwd", "siss_linear_small_bwd", "siss_linear_multi_fwd", "siss_linear_multi_bwd",
+            "siss_nchw_channel_sums", "siss_mixture_fwd", "siss_mixture_select", "siss_loss_bwd_seed", "siss_mse_bwd_seed",
+            "siss_ddpm_step", "siss_grad_norms_scale", "siss_grad_norm_partials", "siss_grad_scalars", "siss_recombine_clip_adamw"}
+for _b, _f in F32_ENTRY.items():
+    SIGNATURES[_f] = SIGNATURES[_b]
+_F32 = False
+
+
+class f32_mode:
+    """`with lib.f32_mode(engine.f32):` -- the launches inside go to the f32 entry points when the flag is set."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _F32
+        self.prev, _F32 = _F32, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _F32
+        _F32 = self.prev
+        return False
+
+
 _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words",
              "siss_gn_partial_words", "siss_dispatch_count", "siss_conv_qstats_words"}
 
@@ -302,6 +338,12 @@ def kernel_symbol(name, a):
 def call(name, *args):
     """Call a launcher on torch's current stream; tensors are passed as raw pointers."""
     lib = load()
+    if _F32:
+        if name in F32_ENTRY:
+            name = F32_ENTRY[name]
+        elif name not in F32_SAME:
+            raise RuntimeError(f"{name} has no f32 form: the f32 parity mode covers the UNet2DModel path with the fused bf16 "
+                               "kernels switched off (csrc/f32_path.hip)")
     fn = getattr(lib, name)
     conv = [ptr(a) if (torch.is_tensor(a) or a is None) else
             (C.cast(a, C.c_void_p) if isinstance(a, C.Array) and a._type_ is not C.c_int else a) for a in args]   # job tables

@@ -45,18 +45,20 @@ class UNet2DModel:
     class_name = "UNet2DModel"
 
     @staticmethod
-    def _make_engine(config, device):
-        return UNetEngine(config, device)
+    def _make_engine(config, device, dtype=torch.bfloat16):
+        return UNetEngine(config, device, dtype=dtype)
 
     def _cond_args(self, kwargs):
         """Positional conditioning tensors of the engine's forward, from the reference's **conditioning."""
         return ()
 
-    def __init__(self, config=None, device="cuda", **kwargs):
+    def __init__(self, config=None, device="cuda", compute_dtype=torch.bfloat16, **kwargs):
+        """compute_dtype: torch.bfloat16 (bf16 MFMA operands: `mixed_precision: bf16`, the fast path) or torch.float32 (the f32
+        parity mode: `mixed_precision: null`, the reference's shipped default -- every tensor and product f32)."""
         if config is None:
             config = self.config_cls.from_dict(kwargs) if kwargs else self.config_cls()
         self.config = config
-        self.engine = self._make_engine(config, device)
+        self.engine = self._make_engine(config, device, compute_dtype)
         self.device = self.engine.device
         self.dtype = torch.float32
         self.training = True
@@ -126,12 +128,12 @@ class UNet2DModel:
         self.engine.load_state_dict(sd, strict)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder=None, device="cuda", **unused):
+    def from_pretrained(cls, path, subfolder=None, device="cuda", compute_dtype=torch.bfloat16, **unused):
         from safetensors.torch import load_file
         d = os.path.join(path, subfolder) if subfolder else path
         if not os.path.exists(os.path.join(d, "config.json")) and os.path.exists(os.path.join(path, "unet")):
             d = os.path.join(path, "unet")
-        m = cls(cls.config_cls.from_json(os.path.join(d, "config.json")), device=device)
+        m = cls(cls.config_cls.from_json(os.path.join(d, "config.json")), device=device, compute_dtype=compute_dtype)
         m.load_state_dict(load_file(os.path.join(d, "diffusion_pytorch_model.safetensors")))
         return m
 
@@ -153,9 +155,9 @@ class UNet2DConditionModel(UNet2DModel):
     class_name = "UNet2DConditionModel"
 
     @staticmethod
-    def _make_engine(config, device):
+    def _make_engine(config, device, dtype=torch.bfloat16):
         from .unet_cond import UNetCondEngine
-        return UNetCondEngine(config, device)
+        return UNetCondEngine(config, device, dtype=dtype)
 
     def _cond_args(self, kwargs):
         e = kwargs.get("encoder_hidden_states")

@@ -56,18 +56,21 @@ class SISSStepper:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.io_dtype = torch.bfloat16 if mixed_precision == "bf16" else torch.float32
-        if mixed_precision != "bf16" and not SISSStepper._warned_fp32:
-            # config/delete_*.yaml ship mixed_precision: null (fp32 everywhere in the reference).  Here that selects f32
-            # image / noise I/O, f32 master weights, gradients and optimizer state -- but every GEMM still takes bf16
-            # MFMA operands with f32 accumulation (there is no f32-operand GEMM path).
+        f32_engine = getattr(engine, "f32", False)
+        if f32_engine and mixed_precision == "bf16":
+            raise ValueError("mixed_precision='bf16' on an f32 engine: build the engine with dtype=torch.bfloat16")
+        if mixed_precision != "bf16" and not f32_engine and not SISSStepper._warned_fp32:
+            # config/delete_*.yaml ship mixed_precision: null (fp32 everywhere in the reference).  On an f32 ENGINE
+            # (UNetEngine(dtype=torch.float32): what the task loop builds for null) that is what runs.  On a bf16 engine it selects
+            # f32 image / noise I/O, f32 master weights, gradients and optimizer state -- with bf16 MFMA operands.
             import warnings
-            warnings.warn("siss_amd: mixed_precision is not 'bf16': I/O, master weights, gradients and optimizer state are "
-                          "f32, but convolutions / linears still run on bf16 MFMA operands with f32 accumulation "
-                          "(no f32-operand GEMM path) -- results match an fp32 run to bf16 tolerance, not bitwise",
+            warnings.warn("siss_amd: mixed_precision is not 'bf16' on a bf16 engine: I/O, master weights, gradients and optimizer "
+                          "state are f32, but convolutions / linears run on bf16 MFMA operands with f32 accumulation -- results "
+                          "match an fp32 run to bf16 tolerance; UNetEngine(cfg, device, dtype=torch.float32) is the f32 path",
                           RuntimeWarning, stacklevel=2)
             SISSStepper._warned_fp32 = True
         self.opt = FlatAdamW(engine.ps.flat, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                             max_grad_norm=max_grad_norm, shadow=engine.ps.shadow)
+                             max_grad_norm=max_grad_norm, shadow=None if f32_engine else engine.ps.shadow)
         self._micro = 0
         self.last = None
         self._pending = []

@@ -49,13 +49,23 @@ class _DeleteBase(Task):
         self.cfg = cfg
 
     # -- pieces a subclass may override --------------------------------------------------------
+    def compute_dtype(self):
+        """`mixed_precision: null` -- the reference's shipped default: fp32 everywhere (delete_celeb.yaml:103) -- runs the f32 engine
+        (every tensor and product f32: the parity mode, 1/16 of the bf16 MFMA rate at best); `bf16` the bf16 MFMA path."""
+        if self.cfg.get("mixed_precision") == "bf16":
+            return torch.bfloat16
+        print("[siss_amd] mixed_precision is null: true f32 compute (the reference's default; a parity mode here, far slower than "
+              "mixed_precision=bf16, which is what the benchmark runs)")
+        return torch.float32
+
     def load_unet(self, device):
         from .model import UNet2DModel
         cfg = self.cfg
         path = cfg.get("checkpoint_path")
+        dt = self.compute_dtype()
         if path and os.path.isdir(str(path)):
             sub = (cfg.get("subfolders") or {}).get("unet")
-            return UNet2DModel.from_pretrained(path, subfolder=sub, device=device)
+            return UNet2DModel.from_pretrained(path, subfolder=sub, device=device, compute_dtype=dt)
         # The reference hard-fails here (DDPMPipeline.from_pretrained, delete_celeb.py:181).  Random-init weights of the
         # same architecture are for benchmarks / smoke runs only and must be asked for: allow_random_init=true.
         if not cfg.get("allow_random_init"):
@@ -63,7 +73,7 @@ class _DeleteBase(Task):
                 f"checkpoint_path {path!r} is not a directory on disk (no network: hub ids cannot be fetched); "
                 "pass allow_random_init=true to train random-init weights of the configured architecture instead")
         ucfg = {k: v for k, v in (cfg.get("unet") or {}).items() if not k.startswith("_")}
-        m = UNet2DModel(UNet2DConfig.from_dict(ucfg) if ucfg else self.default_unet(), device=device)
+        m = UNet2DModel(UNet2DConfig.from_dict(ucfg) if ucfg else self.default_unet(), device=device, compute_dtype=dt)
         m.engine.init_random(seed=int(cfg.random_seed))
         print(f"[siss_amd] allow_random_init: checkpoint {path!r} not on disk, RANDOM-INIT weights of the same architecture")
         return m

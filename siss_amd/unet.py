@@ -82,10 +82,11 @@ class ParamStore:
             self.split = off
         self.total = off
 
-    def allocate(self, device, nsets=2):
+    def allocate(self, device, nsets=2, f32=False):
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.grads = torch.zeros(nsets, self.total, dtype=torch.float32, device=device)
-        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=device)
+        # the operand copy of the parameters: their bf16 rounding -- or, in the f32 parity mode, the master itself
+        self.shadow = self.flat if f32 else torch.zeros(self.total, dtype=torch.bfloat16, device=device)
         self.nsets = nsets
 
     # views -----------------------------------------------------------------
@@ -176,16 +177,25 @@ class UNetEngine:
     # before the data-parallel hook).  Captured into the step's hipGraph as a fork / join.  0 = everything on one stream.
     wgrad_stream = 0
 
-    def __init__(self, cfg: UNet2DConfig, device="cuda"):
+    def __init__(self, cfg: UNet2DConfig, device="cuda", dtype=torch.bfloat16):
+        """dtype = torch.float32: the f32 PARITY MODE (`mixed_precision: null` of the reference's YAMLs; csrc/f32_path.hip) -- every
+        activation and operand f32, every product on the f32 MFMA, the same engine code; the fused bf16-only forms (persistent
+        3x3 kernel and what rides in it, depth-to-space epilogue, grouped / side-stream wgrads, slab GroupNorm) are off.  An
+        instrument (1/16 of the bf16 MFMA rate at best, and simple kernels): it pins the network to the fp32 oracle at 1e-4."""
         lib.load()
         self.cfg = cfg
         self.device = torch.device(device)
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.adt, self.f32 = dtype, dtype == torch.float32
+        if self.f32:
+            self.epi_stats = self.d2s_epilogue = self.fold_shortcut = False
+            self.group_rows = self.wgrad_stream = 0
         if self.device.type == "cuda":
             lib.ensure_workspace(self.device)
         self.ps = ParamStore()
         self._declare_params()
         self.ps.relayout(self._grads_final_early)
-        self.ps.allocate(self.device)
+        self.ps.allocate(self.device, f32=self.f32)
         self._build_temb_tables()
         self.wT = {}
         self._wds = {}
@@ -324,20 +334,21 @@ class UNetEngine:
         """bf16 operand copies derived from the f32 master: the fprop shadow (optionally; the fused
         AdamW kernel already refreshes it) and the transposed/flipped dgrad copies."""
         ps = self.ps
-        if cast_shadow:
+        if cast_shadow and not self.f32:                 # (f32 mode: the operand copy IS the master)
             lib.call("siss_cast_f32_bf16", ps.flat, ps.shadow, ps.total)
         if not self.wT:
             self._build_wt_jobs()
         # (from the bf16 shadow, which holds the rounded master at this point: cast above, or refreshed by the fused AdamW launch)
-        lib.call("siss_conv_weight_dgrad_multi_bf16", ps.shadow, self._wt_all, self._wt_jobs, self._wt_njobs,
-                 self._wt_tiles)
+        with lib.f32_mode(self.f32):
+            lib.call("siss_conv_weight_dgrad_multi_bf16", ps.shadow, self._wt_all, self._wt_jobs, self._wt_njobs,
+                     self._wt_tiles)
         for pre, (buf, idx) in self._wds.items():
             torch.index_select(self.wT[pre + ".conv.weight"], 0, idx, out=buf)
         # conv_out dgrad operand: Wn^T, [Cin][K = 9*Cout padded to 64] bf16 (k = tap*Cout + co)
         w = ps.p("conv_out.weight")
         k = w.shape[0] * w.shape[1]
         if getattr(self, "_wd_out", None) is None:
-            self._wd_out = torch.zeros(w.shape[2], -(-k // 64) * 64, dtype=torch.bfloat16, device=self.device)
+            self._wd_out = torch.zeros(w.shape[2], -(-k // 64) * 64, dtype=self.adt, device=self.device)
         self._wd_out[:, :k] = w.reshape(k, w.shape[2]).t()
 
     def _ds_weights(self, pre, order):
@@ -364,7 +375,7 @@ class UNetEngine:
                 jobs.append((n, sp.off, off, t, co, ci, tiles))
                 off += -(-t * co * ci // 64) * 64
                 tiles += t * (-(-co // 64)) * (-(-ci // 64))        # 64 x 64 tiles: optimizer.hip conv_weight_dgrad_multi_kernel
-        self._wt_all = torch.empty(off, dtype=torch.bfloat16, device=self.device)
+        self._wt_all = torch.empty(off, dtype=self.adt, device=self.device)
         rec = np.zeros(len(jobs), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("taps", "<i4"), ("co", "<i4"),
                                                    ("ci", "<i4"), ("tile0", "<i4")]))
         for i, (n, src, dst, t, co, ci, t0) in enumerate(jobs):
@@ -378,7 +389,7 @@ class UNetEngine:
         k = (name, n, h, w, c)
         a = self._acts.get(k)
         if a is None:
-            a = Act(n, h, w, c, self.device)
+            a = Act(n, h, w, c, self.device, dtype=self.adt)
             self._acts[k] = a
         return a
 
@@ -394,7 +405,7 @@ class UNetEngine:
 
     def _get(self, n, h, w, c):
         lst = self._pool.setdefault((n, h, w, c), [])
-        a = lst.pop() if lst else Act(n, h, w, c, self.device)
+        a = lst.pop() if lst else Act(n, h, w, c, self.device, dtype=self.adt)
         self._wsync(a)
         return a
 
@@ -489,7 +500,7 @@ class UNetEngine:
         mean = self._buf(nm + ".mean", (x.n, G))
         rstd = self._buf(nm + ".rstd", (x.n, G))
         if compact_out:
-            y = self._buf(nm + ".y", (x.n * x.h * x.w, x.c), torch.bfloat16)
+            y = self._buf(nm + ".y", (x.n * x.h * x.w, x.c), self.adt)
             yptr = y
         else:
             y = self._act(nm + ".y", x.n, x.h, x.w, x.c)
@@ -779,7 +790,7 @@ class UNetEngine:
         rows = B * S
         nm = self._name(pre)
         hn, gn_b = self.gn(x, pre + ".group_norm", False, compact_out=True)
-        bb = lambda s, shape: self._buf(nm + s, shape, torch.bfloat16)
+        bb = lambda s, shape: self._buf(nm + s, shape, self.adt)
         q, k, v = bb(".q", (rows, C)), bb(".k", (rows, C)), bb(".v", (rows, C))
         vT, sc, p = bb(".vT", (B, C, S)), bb(".s", (B, S, S)), bb(".p", (B, S, S))
         o, y = bb(".o", (rows, C)), bb(".y", (rows, C))
@@ -809,10 +820,10 @@ class UNetEngine:
             nb, gb, ns, si = self.nb, self.gbase, self.nsets, self.set_images
             rows2 = nb * S
             dout = self._take(out)
-            tb = lambda s, shape, dt=torch.bfloat16: self._buf("attn" + s, shape, dt)
+            tb = lambda s, shape, dt=self.adt: self._buf("attn" + s, shape, dt)
             # the operands of this site's four weight-gradient products get buffers of their OWN (8 MB each at B = 16): the
             # products are queued and run later in a grouped launch, when the shared scratch has long been reused
-            own = (lambda s, shape: self._buf(nm + ".bwd" + s, shape, torch.bfloat16)) if self.group_attn and self.group_rows else tb
+            own = (lambda s, shape: self._buf(nm + ".bwd" + s, shape, self.adt)) if self.group_attn and self.group_rows else tb
             dy = own(".dy", (rows2, C))
             lib.call("siss_pad_to_compact", dout.data, dy, nb, x.h, x.w, C)
             zp = ops.zero_page(self.device)
@@ -876,7 +887,8 @@ class UNetEngine:
             # dhn = dq Wq + dk Wk + dv Wv: three panels of one product -- panel p reads rows [p * rows2, (p + 1) * rows2) of the
             # stacked cotangents (row shift) against the p-th of the three consecutive transposed weight copies
             wq, wk, wv = (self.wT[pre + n + ".weight"] for n in (".to_q", ".to_k", ".to_v"))
-            assert wk.data_ptr() == wq.data_ptr() + 2 * C * C and wv.data_ptr() == wk.data_ptr() + 2 * C * C
+            esz = wq.element_size()
+            assert wk.data_ptr() == wq.data_ptr() + esz * C * C and wv.data_ptr() == wk.data_ptr() + esz * C * C
             ops.gemm_nt(lib.ptr(dqkv), C, wq, lib.ptr(dhn), C, rows2, C, C, [0, rows2, 2 * rows2], [0, 0, 0])
             dx = gn_b(dhn, accum=dout)        # residual path: d_out passes straight through
             self._give(x, dx)
@@ -1005,6 +1017,10 @@ class UNetEngine:
     # ------------------------------------------------------------------ whole network
     def forward(self, x, t):
         """x: [N, Cin, H, W] f32/bf16 NCHW (device), t: [N] int64.  Returns pred [N, Cout, H, W] f32."""
+        with lib.f32_mode(self.f32):
+            return self._forward(x.float() if self.f32 else x, t)
+
+    def _forward(self, x, t):
         cfg, ps = self.cfg, self.ps
         assert x.is_cuda and x.dim() == 4 and x.is_contiguous()
         N, cin, H, W = x.shape
@@ -1135,6 +1151,10 @@ class UNetEngine:
         """cot: [nb, Cout, H, W] f32 cotangent of pred, nb = nsets * set_images.  With the shared
         forward (SISS) nb = 2*N: rows [0,N) seed g_x and rows [N,2N) seed g_a.  Gradients are
         ACCUMULATED into ps.grads[grad_base_set + set] (call zero_grad() at the start of a step)."""
+        with lib.f32_mode(self.f32):
+            return self._backward(cot, nsets, grad_base_set)
+
+    def _backward(self, cot, nsets, grad_base_set):
         assert cot.is_cuda and cot.dtype == torch.float32 and cot.is_contiguous()
         nb = cot.shape[0]
         assert nb % nsets == 0 and nb % self.nf == 0

@@ -30,7 +30,10 @@ def _up(n, m):
 
 
 class UNetCondEngine(UNetEngine):
-    def __init__(self, cfg: UNet2DConditionConfig, device="cuda"):
+    def __init__(self, cfg: UNet2DConditionConfig, device="cuda", dtype=torch.bfloat16):
+        if dtype != torch.bfloat16:
+            raise NotImplementedError("the f32 parity mode covers the UNet2DModel path; the SD UNet's transformer kernels "
+                                      "(LayerNorm, GEGLU, fused attention) have bf16 forms only")
         super().__init__(cfg, device)
         self.ctx = None
         # fused attention (csrc/flash_attn.hip) for the transformer blocks; False: batched GEMMs + row softmax with the
