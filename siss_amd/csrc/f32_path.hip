@@ -377,6 +377,120 @@ __global__ void weight_dgrad_f32_kernel(const float* __restrict__ flat, float* _
     }
 }
 
+// ---------------------------------------------------------------- token space (transformer.hip's kernels with f32 rows [rows][C])
+// LayerNorm over the last dim: one wave per row; mean / rstd saved
+__global__ __launch_bounds__(256) void layernorm_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd, long rows, int C,
+                                                                float eps) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    double a = 0.0, b = 0.0;
+    for (int c = lane; c < C; c += 64) { const double v = x[r * C + c]; a += v; b += v * v; }
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    const double m = a / C;
+    double var = b / C - m * m; var = var > 0 ? var : 0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps)), mf = (float)m;
+    if (lane == 0) { mean[r] = mf; rstd[r] = rs; }
+    for (int c = lane; c < C; c += 64) y[r * C + c] = (x[r * C + c] - mf) * rs * gamma[c] + beta[c];
+}
+// dx[r] = (accum[r] +) rstd (dy gamma - mean_c(dy gamma) - xhat mean_c(dy gamma xhat)); saved row = r % rows_x
+__global__ __launch_bounds__(256) void layernorm_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ accum,
+                                                                float* __restrict__ dx, long rows2, long rows_x, int C) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows2) return;
+    const long rx = r % rows_x;
+    const float mf = mean[rx], rs = rstd[rx];
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = lane; c < C; c += 64) {
+        const float dg = dy[r * C + c] * gamma[c], xh = (x[rx * C + c] - mf) * rs;
+        s1 += (double)dg; s2 += (double)dg * xh;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    const float m1 = (float)(s1 / C), m2 = (float)(s2 / C);
+    for (int c = lane; c < C; c += 64) {
+        const float dg = dy[r * C + c] * gamma[c], xh = (x[rx * C + c] - mf) * rs;
+        dx[r * C + c] = (accum ? accum[r * C + c] : 0.f) + rs * (dg - m1 - xh * m2);
+    }
+}
+// dgamma / dbeta[set][c] += column sums over the set's rows (one thread per (set, column))
+__global__ void layernorm_dgb_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                         long rows_x, long set_rows, long set_stride, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, set = blockIdx.y;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (long i = 0; i < set_rows; ++i) {
+        const long r = (long)set * set_rows + i, rx = r % rows_x;
+        const float d = dy[r * C + c];
+        dg += (double)d * ((x[rx * C + c] - mean[rx]) * rstd[rx]); db += (double)d;
+    }
+    dgamma[(long)set * set_stride + c] += (float)dg;
+    dbeta[(long)set * set_stride + c] += (float)db;
+}
+__device__ __forceinline__ float gelu_phi(float g) { return 0.5f * (1.f + erff(g * 0.70710678118654752f)); }
+// out[r][f] = h[r][f] gelu(h[r][F + f]);  dh[r][:F] = dout gelu(g), dh[r][F:] = dout a gelu'(g) (saved row = r % rows_x)
+__global__ void geglu_fwd_f32_kernel(const float* __restrict__ h, float* __restrict__ out, long rows, int F) {
+    FOR_ELEMS(rows * F) { const long r = i / F; const int f = i - r * F; const float g = h[r * 2 * F + F + f];
+        out[i] = h[r * 2 * F + f] * g * gelu_phi(g); }
+}
+__global__ void geglu_bwd_f32_kernel(const float* __restrict__ dout, const float* __restrict__ h, float* __restrict__ dh, long rows2,
+                                     long rows_x, int F) {
+    FOR_ELEMS(rows2 * F) { const long r = i / F; const int f = i - r * F; const long rx = r % rows_x;
+        const float a = h[rx * 2 * F + f], g = h[rx * 2 * F + F + f], d = dout[i];
+        const float Phi = gelu_phi(g), phi = 0.3989422804014327f * expf(-0.5f * g * g);
+        dh[r * 2 * F + f] = d * g * Phi;
+        dh[r * 2 * F + F + f] = d * a * (Phi + g * phi); }
+}
+// dst[(b H + h)][s][d] = src[b][s][h D + d] for s < S, d < D, zero in the padding; and back
+__global__ void head_split_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int S, int H, int D, int Sp, int Dp) {
+    FOR_ELEMS((long)B * H * Sp * Dp) { const int d = i % Dp; long t = i / Dp; const int s_ = t % Sp; t /= Sp; const int h = t % H;
+        const int b = t / H; dst[i] = (s_ < S && d < D) ? src[((long)b * S + s_) * H * D + h * D + d] : 0.f; }
+}
+__global__ void head_merge_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int S, int H, int D, int Sp, int Dp) {
+    FOR_ELEMS((long)B * S * H * D) { const int d = i % D; long t = i / D; const int h = t % H; t /= H; const int s_ = t % S;
+        const int b = t / S; dst[i] = src[(((long)b * H + h) * Sp + s_) * Dp + d]; }
+}
+// p[r][k] = softmax over the visible k < valid of s[r][k] (causal_period > 0: also k <= r % causal_period), 0 up to ld; and its backward
+__global__ __launch_bounds__(256) void softmax_rows_fwd_f32_kernel(const float* __restrict__ s, float* __restrict__ p, long rows,
+                                                                   int valid, int ld, int causal_period) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    int lim = valid;
+    if (causal_period > 0) { const int q = (int)(r % causal_period) + 1; lim = q < lim ? q : lim; }
+    float mx = -INFINITY;
+    for (int k = lane; k < lim; k += 64) mx = fmaxf(mx, s[r * ld + k]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int k = lane; k < lim; k += 64) sum += expf(s[r * ld + k] - mx);
+    sum = wave_sum(sum);
+    for (int k = lane; k < ld; k += 64) p[r * ld + k] = k < lim ? expf(s[r * ld + k] - mx) / sum : 0.f;
+}
+__global__ __launch_bounds__(256) void softmax_rows_bwd_f32_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                                   float* __restrict__ ds, long rows, long p_rows, int valid, int ld,
+                                                                   float scale) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* pr = p + (r % p_rows) * ld;
+    float dot = 0.f;
+    for (int k = lane; k < valid; k += 64) dot += pr[k] * dp[r * ld + k];
+    dot = wave_sum(dot);
+    for (int k = lane; k < ld; k += 64) ds[r * ld + k] = k < valid ? scale * pr[k] * (dp[r * ld + k] - dot) : 0.f;
+}
+// out[r] = <a[r], b[r % rows_b]> over D contiguous floats (one thread per row)
+__global__ void rowdot_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long rows,
+                                  long rows_b, int D) {
+    FOR_ELEMS(rows) { const float* x = a + i * D; const float* y = b + (i % rows_b) * D; float t = 0.f;
+        for (int d = 0; d < D; ++d) t = fmaf(x[d], y[d], t);
+        out[i] = t; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -532,6 +646,79 @@ int siss_copy_f32(const float* src, void* dst, long n, void* stream) {
 int siss_conv_weight_dgrad_multi_f32(const float* flat, void* wt_all, const void* jobs, int njobs, int total_tiles, void* stream) {
     SISS_CHECK_ARG(flat && wt_all && jobs && njobs > 0 && total_tiles > 0);
     weight_dgrad_f32_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>(flat, (float*)wt_all, (const WtJobF*)jobs, njobs);
+    SISS_LAUNCH_RET();
+}
+
+
+// ---- transformer.hip's launchers with f32 rows (the SD UNet's token space in the f32 parity mode: materialised attention path) ----
+int siss_layernorm_fwd_f32(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long rows, int C,
+                           float eps, void* stream) {
+    SISS_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0);
+    layernorm_fwd_f32_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>((const float*)x, gamma, beta, (float*)y, mean, rstd, rows, C, eps);
+    SISS_LAUNCH_RET();
+}
+int siss_layernorm_bwd_f32(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* accum,
+                           void* dx, float* dgamma, float* dbeta, long rows2, long rows_x, long set_rows, long set_stride, int C,
+                           void* stream) {
+    SISS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows2 > 0 && rows_x > 0 && set_rows > 0 && C > 0);
+    SISS_CHECK_ARG(rows2 % set_rows == 0 && (!dgamma || dbeta) && rows2 / set_rows <= 65535);
+    hipStream_t st = (hipStream_t)stream;
+    // (column sums first: dx may alias accum, never dy or x)
+    if (dgamma)
+        layernorm_dgb_f32_kernel<<<dim3(cdiv(C, 64), (unsigned)(rows2 / set_rows)), 64, 0, st>>>((const float*)dy, (const float*)x, mean, rstd,
+                                                                                                dgamma, dbeta, rows_x, set_rows, set_stride, C);
+    layernorm_bwd_f32_kernel<<<cdiv(rows2, 4), 256, 0, st>>>((const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)accum,
+                                                             (float*)dx, rows2, rows_x, C);
+    SISS_LAUNCH_RET();
+}
+int siss_geglu_fwd_f32(const void* h, void* out, long rows, int F, void* stream) {
+    SISS_CHECK_ARG(h && out && rows > 0 && F > 0);
+    geglu_fwd_f32_kernel<<<ew_grid(rows * F), 256, 0, (hipStream_t)stream>>>((const float*)h, (float*)out, rows, F);
+    SISS_LAUNCH_RET();
+}
+int siss_geglu_bwd_f32(const void* dout, const void* h, void* dh, long rows2, long rows_x, int F, void* stream) {
+    SISS_CHECK_ARG(dout && h && dh && rows2 > 0 && rows_x > 0 && F > 0);
+    geglu_bwd_f32_kernel<<<ew_grid(rows2 * F), 256, 0, (hipStream_t)stream>>>((const float*)dout, (const float*)h, (float*)dh, rows2, rows_x, F);
+    SISS_LAUNCH_RET();
+}
+int siss_head_split_f32(const void* src, void* dst, int B, int S, int H, int D, int Sp, int Dp, void* stream) {
+    SISS_CHECK_ARG(src && dst && B > 0 && S > 0 && H > 0 && D > 0 && Sp >= S && Dp >= D);
+    head_split_f32_kernel<<<ew_grid((long)B * H * Sp * Dp), 256, 0, (hipStream_t)stream>>>((const float*)src, (float*)dst, B, S, H, D, Sp, Dp);
+    SISS_LAUNCH_RET();
+}
+int siss_head_merge_f32(const void* src, void* dst, int B, int S, int H, int D, int Sp, int Dp, void* stream) {
+    SISS_CHECK_ARG(src && dst && B > 0 && S > 0 && H > 0 && D > 0 && Sp >= S && Dp >= D);
+    head_merge_f32_kernel<<<ew_grid((long)B * S * H * D), 256, 0, (hipStream_t)stream>>>((const float*)src, (float*)dst, B, S, H, D, Sp, Dp);
+    SISS_LAUNCH_RET();
+}
+int siss_softmax_rows_fwd_f32(const void* s, void* p, long rows, int valid, int ld, int causal_period, void* stream) {
+    SISS_CHECK_ARG(s && p && rows > 0 && valid > 0 && valid <= ld && causal_period >= 0);
+    softmax_rows_fwd_f32_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>((const float*)s, (float*)p, rows, valid, ld, causal_period);
+    SISS_LAUNCH_RET();
+}
+int siss_softmax_rows_bwd_f32(const void* p, const void* dp, void* ds, long rows, long p_rows, int valid, int ld, float scale,
+                              void* stream) {
+    SISS_CHECK_ARG(p && dp && ds && rows > 0 && p_rows > 0 && valid > 0 && valid <= ld);
+    softmax_rows_bwd_f32_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>((const float*)p, (const float*)dp, (float*)ds, rows, p_rows, valid, ld, scale);
+    SISS_LAUNCH_RET();
+}
+int siss_rowdot_f32(const void* a, const void* b, float* out, long rows, long rows_b, int D, void* stream) {
+    SISS_CHECK_ARG(a && b && out && rows > 0 && rows_b > 0 && D > 0);
+    rowdot_f32_kernel<<<ew_grid(rows), 256, 0, (hipStream_t)stream>>>((const float*)a, (const float*)b, out, rows, rows_b, D);
+    SISS_LAUNCH_RET();
+}
+// siss_gemm_nt_mulsub with f32 tensors: C = R o (alpha (acc - rowsub[row])) (the attention backward's dS from one product)
+int siss_gemm_nt_mulsub_f32(const void* A, long lda, const void* W, void* C, long ldc, const void* R, long ldr, const float* rowsub,
+                            int M, int N, int Kp, float alpha, int batch, long strideA, long strideW, long strideC, void* stream) {
+    SISS_CHECK_ARG(A && W && C && R && rowsub && M > 0 && N > 0 && Kp > 0 && Kp % 16 == 0 && batch >= 1 && batch <= 65535);
+    SISS_CHECK_ARG(lda % 4 == 0 && ((uintptr_t)A | (uintptr_t)W) % 16 == 0 && cdiv(M, 16) <= 65535);
+    NTF p;
+    p.A = (const float*)A; p.W = (const float*)W; p.C = (float*)C; p.bias = nullptr; p.rowbias = nullptr; p.R = (const float*)R;
+    p.rowsub = rowsub; p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldrb = 0; p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
+    p.M = M; p.N = N; p.Kp = Kp; p.npanels = 1; p.rows_per_image = 1; p.Hp = 0; p.Wp = 0; p.mul_r = 1; p.d2s = 0; p.alpha_cols = 0;
+    p.alpha = alpha;
+    for (int i = 0; i < kMaxPanelsF; ++i) { p.shift[i] = 0; p.coff[i] = 0; }
+    gemm_nt_f32_kernel<<<dim3(cdiv(N, 64), cdiv(M, 16), batch), 256, 0, (hipStream_t)stream>>>(p);
     SISS_LAUNCH_RET();
 }
 

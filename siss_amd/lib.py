@@ -105,7 +105,9 @@ F32_ENTRY = {n: n + "_f32" for n in (
     "siss_gemm_nt", "siss_gemm_tn", "siss_groupnorm_fwd_ld", "siss_groupnorm_bwd_ld", "siss_upsample2x", "siss_upsample2x_bwd",
     "siss_concat", "siss_concat_tail", "siss_concat_bwd", "siss_add_inplace", "siss_space_to_depth_ld", "siss_depth_to_space",
     "siss_pad_to_compact", "siss_compact_add_to_pad", "siss_im2col3x3", "siss_conv_out_fprop", "siss_mha_small_fwd",
-    "siss_mha_small_bwd", "siss_softmax_fwd", "siss_softmax_bwd")}
+    "siss_mha_small_bwd", "siss_softmax_fwd", "siss_softmax_bwd", "siss_softmax_rows_fwd", "siss_softmax_rows_bwd",
+    "siss_layernorm_fwd", "siss_layernorm_bwd", "siss_geglu_fwd", "siss_geglu_bwd", "siss_head_split", "siss_head_merge",
+    "siss_rowdot", "siss_gemm_nt_mulsub")}
 F32_ENTRY.update({"siss_transpose_bf16": "siss_transpose_f32", "siss_cast_f32_bf16": "siss_copy_f32",
                   "siss_conv_weight_dgrad_multi_bf16": "siss_conv_weight_dgrad_multi_f32"})
 F32_SAME = {"siss_timestep_sincos", "siss_linear_small_fwd", "siss_linear_small_bwd", "siss_linear_multi_fwd", "siss_linear_multi_bwd",
@@ -342,8 +344,8 @@ def call(name, *args):
         if name in F32_ENTRY:
             name = F32_ENTRY[name]
         elif name not in F32_SAME:
-            raise RuntimeError(f"{name} has no f32 form: the f32 parity mode covers the UNet2DModel path with the fused bf16 "
-                               "kernels switched off (csrc/f32_path.hip)")
+            raise RuntimeError(f"{name} has no f32 form: the f32 parity mode runs the engines with the fused bf16 kernels "
+                               "switched off (csrc/f32_path.hip)")
     fn = getattr(lib, name)
     conv = [ptr(a) if (torch.is_tensor(a) or a is None) else
             (C.cast(a, C.c_void_p) if isinstance(a, C.Array) and a._type_ is not C.c_int else a) for a in args]   # job tables

@@ -299,14 +299,15 @@ class DeleteSD(_DeleteBase):
         cfg = self.cfg
         self.load_front_end(device)
         path = cfg.get("pretrained_model_name_or_path")
+        dt = self.compute_dtype()                                # (the frozen VAE / text encoder front end stays on the bf16 path)
         if path and os.path.isdir(os.path.join(str(path), "unet")):
-            return UNet2DConditionModel.from_pretrained(path, subfolder="unet", device=device)   # delete_sd.py:458-462
+            return UNet2DConditionModel.from_pretrained(path, subfolder="unet", device=device, compute_dtype=dt)   # delete_sd.py:458-462
         if not cfg.get("allow_random_init"):                     # the reference hard-fails (from_pretrained, delete_sd.py:458-462)
             raise FileNotFoundError(
                 f"pretrained_model_name_or_path {path!r} has no unet/ directory on disk (no network: hub ids cannot be "
                 "fetched); pass allow_random_init=true to train random-init weights of the configured architecture instead")
         ucfg = {k: v for k, v in (cfg.get("unet") or {}).items() if not k.startswith("_")}
-        m = UNet2DConditionModel(UNet2DConditionConfig.from_dict(ucfg) if ucfg else self.default_unet(), device=device)
+        m = UNet2DConditionModel(UNet2DConditionConfig.from_dict(ucfg) if ucfg else self.default_unet(), device=device, compute_dtype=dt)
         m.engine.init_random(seed=self.seed())
         print(f"[siss_amd] allow_random_init: {path!r}/unet not on disk, RANDOM-INIT weights of the same architecture")
         return m

@@ -51,6 +51,9 @@ class VAEEncoder(UNetEngine):
         self.wT, self._wds, self._acts, self._bufs, self._pool = {}, {}, {}, {}, {}
         self.tape, self.gmap, self._uid = [], {}, 0
         self.on_early_grads_final = None
+        self.adt, self.f32 = torch.bfloat16, False         # (forward-only front end: the bf16 path)
+        self._wq, self._held, self._held_release = [], {}, []
+        self._wstream, self._sheld, self._side_open = None, {}, False
 
     # ------------------------------------------------------------------ parameters
     def _declare_enc_resnet(self, pre, cin, cout):
