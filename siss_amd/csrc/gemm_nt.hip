@@ -549,6 +549,16 @@ int siss_gemm_nt_d2s(const void* A, long lda, const void* W, void* C, long ldc, 
     return gemm_nt_dispatch(A, lda, W, C, ldc, nullptr, nullptr, N, R, ldr, M, N, Kp, npanels, shifts, coffs,
                             rows_per_image, Hp, Wp, 1.0f, 1, 0, 0, 0, nullptr, 0, stream, nullptr, nullptr, 1 + plane);
 }
+// The same with a bias (f32 [N], added before the one rounding): one PHASE of a sub-pixel upsample convolution -- the rows are the
+// LOW-resolution pixels, plane = 2 py + px is the phase, the panels its 2x2 taps (siss_upsample_phase_weights), and the epilogue
+// writes pixel (y, x) to (2y + py, 2x + px) of the high-resolution output.  Four launches cover every interior pixel of C once.
+int siss_gemm_nt_d2s_bias(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, int M, int N, int Kp,
+                          int npanels, const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, int plane,
+                          void* stream) {
+    SISS_CHECK_ARG(plane >= 0 && plane < 4);
+    return gemm_nt_dispatch(A, lda, W, C, ldc, bias, nullptr, N, nullptr, 0, M, N, Kp, npanels, shifts, coffs,
+                            rows_per_image, Hp, Wp, 1.0f, 1, 0, 0, 0, nullptr, 0, stream, nullptr, nullptr, 1 + plane);
+}
 
 // floats in the `qstats` buffer of a product with M rows and N output channels
 long siss_conv_qstats_words(long M, int N) {

@@ -30,6 +30,7 @@ struct TNParams {
     const bf16_t* Y; const bf16_t* X; float* dW; const bf16_t* zero_page;
     float* dbias; float* dbias2;          // optional: column sums of Y per set (bias gradients)
     long ldy, ldx, set_stride;
+    long bias_stride;                     // floats between the sets of dbias / dbias2 (= set_stride unless siss_gemm_tn_bs says otherwise)
     long x_set_rows;
     int N, C, npanels, nsets, nsplits, rmw;
     int rows_per_set, row_begin, row_end, rows_per_split;
@@ -447,8 +448,8 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wn * 64 + i * 16 + g * 4 + r;
                 if (n < p.N) {
-                    atomicAdd(p.dbias + (long)set * p.set_stride + n, bacc[i][r]);
-                    if (p.dbias2) atomicAdd(p.dbias2 + (long)set * p.set_stride + n, bacc[i][r]);
+                    atomicAdd(p.dbias + (long)set * p.bias_stride + n, bacc[i][r]);
+                    if (p.dbias2) atomicAdd(p.dbias2 + (long)set * p.bias_stride + n, bacc[i][r]);
                 }
             }
     }
@@ -566,7 +567,7 @@ static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW,
     SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set);
     p.Y = (const bf16_t*)Y; p.X = (const bf16_t*)X; p.dW = dW; p.zero_page = (const bf16_t*)zero_page;
     p.dbias = dbias; p.dbias2 = dbias ? dbias2 : nullptr;
-    p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.x_set_rows = x_set_rows;
+    p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.bias_stride = set_stride; p.x_set_rows = x_set_rows;
     p.N = N; p.C = C; p.npanels = npanels; p.nsets = nsets;
     p.rows_per_set = rows_per_set; p.row_begin = row_begin; p.row_end = row_end;
     for (int i = 0; i < kMaxPanels; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
@@ -682,6 +683,23 @@ int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, lo
     const int rc = tn_setup(Y, ldy, X, ldx, dW, set_stride, N, C, npanels, shifts, coffs, nsets, rows_per_set, x_set_rows,
                             row_begin, row_end, nsplits, zero_page, dbias, dbias2, false, p, fused3);
     if (rc != SISS_OK) return rc;
+    if (fused3) return launch_tn<3>(p, (hipStream_t)stream);
+    return launch_tn<1>(p, (hipStream_t)stream);
+}
+
+// siss_gemm_tn whose bias gradients have a set stride of their own: dbias[set * bias_set_stride + n] (dW keeps set_stride).  For a
+// product that accumulates into a SCRATCH with its own set stride while its bias gradient goes to the flat gradient buffer (the
+// phase weight gradients of a sub-pixel upsample convolution).
+int siss_gemm_tn_bs(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
+                    int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
+                    long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,
+                    float* dbias, float* dbias2, long bias_set_stride, void* stream) {
+    TNParams p;
+    bool fused3 = false;
+    const int rc = tn_setup(Y, ldy, X, ldx, dW, set_stride, N, C, npanels, shifts, coffs, nsets, rows_per_set, x_set_rows,
+                            row_begin, row_end, nsplits, zero_page, dbias, dbias2, false, p, fused3);
+    if (rc != SISS_OK) return rc;
+    p.bias_stride = bias_set_stride;
     if (fused3) return launch_tn<3>(p, (hipStream_t)stream);
     return launch_tn<1>(p, (hipStream_t)stream);
 }

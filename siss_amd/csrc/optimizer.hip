@@ -255,6 +255,48 @@ inline int grid_for(long n) {
     return (int)b;
 }
 
+// ---- sub-pixel form of Upsample2D (nearest 2x -> conv3x3; round 4).  Output pixel (2Y + py, 2X + px) reads the LOW-resolution rows
+// {Y - 1 + py, Y + py} and columns {X - 1 + px, X + px}: four 2x2-tap phase convolutions whose weights are sums of the 3x3 taps
+// (16 instead of 36 tap products per low-resolution pixel).  Phase tap a of plane row py collects filter rows: py = 0: a = 0 <- {0},
+// a = 1 <- {1, 2}; py = 1: a = 0 <- {0, 1}, a = 1 <- {2}; columns alike.  phase_tap(k, p) is that map (which 2-tap index filter
+// index k lands on in phase p).
+__device__ __host__ __forceinline__ int phase_tap(int k, int p) { return p == 0 ? (k >= 1) : (k >= 2); }
+
+// w [9][Co][Ci] f32 (master) -> wf [4 planes][4 taps][Co][Ci] bf16 (fprop operand) and wd [16 = plane * 4 + tap][Ci][Co] bf16 (dgrad
+// operand: the transposes): sums in f32, ONE rounding.
+__global__ void upsample_phase_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int Co, int Ci) {
+    const long total = (long)16 * Co * Ci;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = i % Ci; long t = i / Ci; const int co = t % Co; const int pt = t / Co;
+        const int plane = pt >> 2, tap = pt & 3, py = plane >> 1, px = plane & 1, a = tap >> 1, b = tap & 1;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                if (phase_tap(ky, py) == a && phase_tap(kx, px) == b) acc += w[((long)(ky * 3 + kx) * Co + co) * Ci + ci];
+        const bf16_t v = f2bf(acc);
+        wf[i] = v;
+        wd[((long)pt * Ci + ci) * Co + co] = v;
+    }
+}
+// dW[set][ky * 3 + kx][co][ci] += sum over the four planes of dW4[set][plane][phase tap of (ky, kx) in that plane][co][ci]
+__global__ void upsample_phase_wgrad_fold_kernel(const float* __restrict__ dW4, float* __restrict__ dW, long set_stride, int Co, int Ci) {
+    const long per = (long)Co * Ci, total = 9 * per;
+    const int set = blockIdx.y;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i / per; const long e = i - k * per;
+        const int ky = k / 3, kx = k - ky * 3;
+        float acc = 0.f;
+#pragma unroll
+        for (int plane = 0; plane < 4; ++plane) {
+            const int tap = phase_tap(ky, plane >> 1) * 2 + phase_tap(kx, plane & 1);
+            acc += dW4[(((long)set * 4 + plane) * 4 + tap) * per + e];
+        }
+        dW[(long)set * set_stride + i] += acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -340,6 +382,26 @@ int siss_conv_weight_dgrad_multi_bf16(const void* shadow, void* wt_all, const vo
     SISS_CHECK_ARG(((uintptr_t)shadow | (uintptr_t)wt_all) % 16 == 0);
     conv_weight_dgrad_multi_bf16_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>(
         reinterpret_cast<const bf16_t*>(shadow), reinterpret_cast<bf16_t*>(wt_all), reinterpret_cast<const WtJob*>(jobs), njobs);
+    SISS_LAUNCH_RET();
+}
+
+
+// Phase weights of a sub-pixel upsample convolution from its f32 master weights w [9][Co][Ci]: wf [4][4][Co][Ci] bf16 (plane-major:
+// the fprop operand of plane p is wf + p * 4 * Co * Ci, four panels) and wd [16][Ci][Co] bf16 (the dgrad operand, panel plane * 4 + tap).
+int siss_upsample_phase_weights(const float* w, void* wf, void* wd, int Co, int Ci, void* stream) {
+    SISS_CHECK_ARG(w && wf && wd && Co > 0 && Ci > 0);
+    long nb = ((long)16 * Co * Ci + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    upsample_phase_weights_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)wf, (bf16_t*)wd, Co, Ci);
+    SISS_LAUNCH_RET();
+}
+// The adjoint for the weight gradient: the 16 phase-tap gradients dW4 [nsets][4][4][Co][Ci] f32 folded onto the nine taps,
+// dW[set * set_stride + (tap * Co + co) * Ci + ci] += ...
+int siss_upsample_phase_wgrad_fold(const float* dW4, float* dW, long set_stride, int nsets, int Co, int Ci, void* stream) {
+    SISS_CHECK_ARG(dW4 && dW && nsets > 0 && nsets <= 65535 && Co > 0 && Ci > 0);
+    long nb = ((long)9 * Co * Ci + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    upsample_phase_wgrad_fold_kernel<<<dim3((int)nb, nsets), 256, 0, (hipStream_t)stream>>>(dW4, dW, set_stride, Co, Ci);
     SISS_LAUNCH_RET();
 }
 

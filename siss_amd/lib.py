@@ -41,6 +41,9 @@ SIGNATURES = {
     "siss_conv3x3_dgrad_sc_takes": [I, I, I, I, I, I, L, L, L, L],
     "siss_conv_qstats_words": [L, I],
     "siss_gemm_nt_d2s": [P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, I, P],
+    "siss_gemm_nt_d2s_bias": [P, L, P, P, L, P, I, I, I, I, IP, IP, I, I, I, I, P],
+    "siss_upsample_phase_weights": [P, P, P, I, I, P],
+    "siss_upsample_phase_wgrad_fold": [P, P, L, I, I, I, P],
     "siss_gemm_nt_set_workspace": [P, L],
     "siss_gemm_nt_set_c3p_blocks": [I],
     "siss_dispatch_count": [I],
@@ -48,6 +51,7 @@ SIGNATURES = {
     "siss_gemm_nt_mulsub": [P, L, P, P, L, P, L, P, I, I, I, F, I, L, L, L, P],
     "siss_rowdot": [P, P, P, L, L, I, P],
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
+    "siss_gemm_tn_bs": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, L, P],
     "siss_gemm_tn_grouped": [P, I, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_set_slab": [I],
@@ -361,6 +365,12 @@ def call(name, *args):
             a = args
             name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], a[5], None, a[9], a[6], a[7], a[8], a[9], a[10], 1,
                                           int_array([0]), int_array([0]), 1, 0, 0, a[11], 1, 0, 0, 0]
+        elif name == "siss_gemm_tn_bs":
+            name, args = "siss_gemm_tn", list(args[:20])
+        elif name == "siss_gemm_nt_d2s_bias":               # (A, lda, W, C, ldc, bias, M, N, Kp, npanels, shifts, coffs, rpi, Hp, Wp, plane)
+            a = args
+            name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], a[5], None, a[7], None, 0, a[6], a[7], a[8], a[9],
+                                          a[10], a[11], a[12], a[13], a[14], 1.0, 1, 0, 0, 0]
         elif name == "siss_gemm_nt_d2s":
             a = args
             name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], None, None, a[8], a[5], a[6], a[7], a[8], a[9], a[10],

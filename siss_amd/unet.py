@@ -160,6 +160,11 @@ class UNetEngine:
     d2s_epilogue = True    # downsample dgrad: depth-to-space in the plane GEMMs' epilogue (no dz tensor, no scatter pass)
     direct_cat = True      # convs that feed a concat write into the concat buffer directly (False: copy both parts)
     fold_shortcut = True   # a resnet's 1x1 conv_shortcut rides in its conv2's 3x3 product (False: own product + residual add)
+    subpixel_up = True     # Upsample2D as four 2x2-tap phase convolutions on the low-resolution input (False: upsample copy + 3x3 conv)
+    # ... at the sites of at least this many low-resolution pixels.  Same-box sweep (CelebA-HQ B = 16, ms per step): off 55.84 / 56.10,
+    # every site 55.68, from 32 x 32 up 55.29, from 64 x 64 up 55.84 / 55.61 -- below 32 x 32 the phase products are latency-bound
+    # launches that the grouped weight gradients and the slab GroupNorm of the literal form beat
+    subpixel_min_px = 1024
     # Weight gradients of all but the top-resolution layers (at most group_rows reduction rows per set: CelebA-HQ's 8x8 .. 128x128
     # levels) are not launched one by one -- each alone leaves CUs idle in its last round of blocks and pays a launch's fixed
     # ~10-40 us -- but queued and run as grouped launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).
@@ -344,6 +349,16 @@ class UNetEngine:
                      self._wt_tiles)
         for pre, (buf, idx) in self._wds.items():
             torch.index_select(self.wT[pre + ".conv.weight"], 0, idx, out=buf)
+        if self.subpixel_up and not self.f32:
+            if not hasattr(self, "_up_w"):
+                self._up_w = {}
+                for n, sp in ps.specs.items():
+                    if ".upsamplers." in n and n.endswith(".conv.weight"):
+                        _, co, ci = sp.native_shape
+                        self._up_w[n] = (torch.empty(4, 4, co, ci, dtype=torch.bfloat16, device=self.device),
+                                         torch.empty(16, ci, co, dtype=torch.bfloat16, device=self.device))
+            for n, (wf, wd) in self._up_w.items():        # phase weights from the f32 master: sums in f32, one rounding
+                lib.call("siss_upsample_phase_weights", ps.p(n), wf, wd, wf.shape[2], wf.shape[3])
         # conv_out dgrad operand: Wn^T, [Cin][K = 9*Cout padded to 64] bf16 (k = tap*Cout + co)
         w = ps.p("conv_out.weight")
         k = w.shape[0] * w.shape[1]
@@ -961,7 +976,75 @@ class UNetEngine:
         self.tape.append(bwd)
         return y
 
+    def _upsample_subpixel(self, x: Act, pre, cat_with=None):
+        """Upsample2D (nearest 2x -> conv3x3) in its SUB-PIXEL form: four 2x2-tap phase convolutions on the low-resolution input
+        (optimizer.hip siss_upsample_phase_weights: phase weights = f32 sums of the 3x3 taps, rounded once), 16 instead of 36 tap
+        products per low-resolution pixel, no upsampled tensor.  Forward: one product per phase whose epilogue scatters to the
+        high-resolution pixels (siss_gemm_nt_d2s_bias).  Backward: space-to-depth of the cotangent, then the dgrad as 16 (plane, tap)
+        panels of ONE accumulation (two 8-panel launches) and the weight gradient as four 4-panel products into a phase-tap
+        scratch that a fold kernel adds onto the nine taps.  Measured per site against upsample copy + persistent 3x3 kernel + fused
+        3-tap wgrad (tools/probes/subpixel_upsample.py): 128 -> 256 x 128 ch 1634 -> 1282 us, 64 -> 128 x 256 ch 1309 -> 999 us --
+        the flops saved outweigh the generic kernels' lower rate and the consumer GroupNorm's own statistics pass."""
+        ps = self.ps
+        C, B, lo_h, lo_w = x.c, x.n, x.h, x.w
+        H, W = 2 * lo_h, 2 * lo_w
+        wname = pre + ".conv.weight"
+        wf, wd = self._up_w[wname]
+        if cat_with is not None and self.direct_cat:
+            assert (cat_with.n, cat_with.h, cat_with.w) == (B, H, W)
+            if isinstance(cat_with, ActView):
+                assert cat_with.c0 == C and cat_with.base.c == C + cat_with.c
+                y = ActView(cat_with.base, 0, C)
+            else:
+                y = ActView(self._act(self._name("cat"), B, H, W, C + cat_with.c), 0, C)
+        else:
+            y = self._act(self._name(pre + ".conv"), B, H, W, C)
+        y.qstats = None
+        wp = x.wp
+        ldx = getattr(x, "ld", C)
+
+        def phase_shifts(plane):
+            py, px = plane >> 1, plane & 1
+            return [(a + py - 1) * wp + (b + px - 1) for a in range(2) for b in range(2)]
+        z4 = lib.int_array([0] * 4)
+        for plane in range(4):
+            lib.call("siss_gemm_nt_d2s_bias", x.data, ldx, wf[plane], y.data, getattr(y, "ld", C), ps.p(pre + ".conv.bias"),
+                     x.rows, C, C, 4, lib.int_array(phase_shifts(plane)), z4, x.rows_per_image, x.hp, x.wp, plane)
+
+        def bwd():
+            nb, gb = self.nb, self.gbase
+            dy = self._take(y)
+            z = self._get(nb, lo_h, lo_w, 4 * C)
+            lib.call("siss_space_to_depth", dy.data, z.data, nb, H, W, C)
+            self._put(dy)
+            # weight gradient: per plane, Y = the plane's columns of z, X = the four shifted low-resolution panels
+            dW4 = self._buf("up.dW4", (self.nsets, 4, 4, C, C))
+            dW4.zero_()
+            rows_per_set = self.set_images * z.rows_per_image
+            rb, re = z.wp + 1, rows_per_set - (z.wp + 1)
+            zp = ops.zero_page(self.device)
+            assert x.n in (nb, self.set_images)
+            for plane in range(4):                       # (siss_gemm_tn_bs: the scratch's set stride is 16 C^2, the bias gradient's the flat buffer's)
+                lib.call("siss_gemm_tn_bs", z.data[:, plane * C:], 4 * C, x.data, ldx, dW4[:, plane], dW4[0].numel(), C, C, 4,
+                         lib.int_array(phase_shifts(plane)), z4, self.nsets, rows_per_set, rows_per_set if x.n == nb else 0,
+                         rb, re, 0, zp, ps.g(pre + ".conv.bias", gb), None, ps.total)
+            lib.call("siss_upsample_phase_wgrad_fold", dW4, ps.grads[gb:, ps.specs[wname].off:], ps.total, self.nsets, C, C)
+            # dgrad: dx[Y, X] = sum over (plane, tap) of z_plane[Y - dy_tap, X - dx_tap] . W_plane,tap^T
+            dx = self._get(nb, lo_h, lo_w, C)
+            sh = [-s_ for plane in range(4) for s_ in phase_shifts(plane)]
+            co = [plane * C for plane in range(4) for _ in range(4)]
+            ops.gemm_nt(lib.ptr(z.data), 4 * C, wd[:8], lib.ptr(dx.data), C, z.rows, C, C, sh[:8], co[:8],
+                        rows_per_image=z.rows_per_image, hp=z.hp, wp=z.wp)
+            ops.gemm_nt(lib.ptr(z.data), 4 * C, wd[8:], lib.ptr(dx.data), C, z.rows, C, C, sh[8:], co[8:],
+                        res_ptr=lib.ptr(dx.data), ldr=C, rows_per_image=z.rows_per_image, hp=z.hp, wp=z.wp)
+            self._put(z)
+            self._give(x, dx)
+        self.tape.append(bwd)
+        return y
+
     def upsample(self, x: Act, pre, cat_with=None):
+        if self.subpixel_up and not self.f32 and x.h * x.w >= self.subpixel_min_px:
+            return self._upsample_subpixel(x, pre, cat_with)
         ps = self.ps
         C, B = x.c, x.n
         u = self._act(self._name(pre + ".u"), B, 2 * x.h, 2 * x.w, C)

@@ -604,3 +604,42 @@ def test_dgrad_weight_copy_kernel_on_odd_shapes():
         w = shadow[o:o + t * co * ci].view(t, co, ci)
         want = w.flip(0).permute(0, 2, 1).contiguous()
         assert torch.equal(out[o:o + t * co * ci].view(t, ci, co), want), (t, co, ci)
+
+
+def test_subpixel_upsample_equals_the_upsample_copy_form():
+    """Upsample2D as four 2x2-tap phase convolutions on the low-resolution input (UNetEngine.subpixel_up, the default) against the
+    literal form (nearest-2x copy, then the 3x3 convolution): same network, same weights and inputs -- prediction within bf16
+    rounding of each other, and the gradients of the upsampler's weight / bias (the fold of the 16 phase-tap gradients onto the nine
+    taps, the bias sums over the four planes) and of everything upstream of it (the phase dgrad) agree."""
+    from siss_amd.unet import UNetEngine
+    hc, _ = _cfgs()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 3, 16, 16, generator=g).cuda()
+    t = torch.tensor([999, 500, 3, 40]).cuda()
+    cot = torch.randn(8, 3, 16, 16, generator=g).cuda()
+    res = []
+    sd = None
+    for sub in (1, 0):
+        eng = UNetEngine(hc, "cuda:0")
+        eng.subpixel_up, eng.subpixel_min_px = sub, 0
+        if sd is None:
+            sd = eng.init_random(seed=9)
+        else:
+            eng.load_state_dict(sd)
+        pred = eng.forward(x, t).clone()
+        eng.zero_grad()
+        eng.backward(cot.contiguous(), nsets=2)
+        torch.cuda.synchronize()
+        res.append((pred, [eng.ps.grads_ref(s) for s in range(2)]))
+    (p1, g1), (p0, g0) = res
+    assert (p1 - p0).abs().max().item() <= 1e-2 * p0.abs().max().item()
+    for s in range(2):
+        tot = float(torch.sqrt(sum(v.square().sum() for v in g0[s].values())))
+        for n in g0[s]:
+            if n.endswith("to_k.bias") or float(g0[s][n].norm()) < 1e-6 * tot:   # (key biases: an identically zero gradient, bf16 noise)
+                continue
+            c = _cos(g1[s][n].float(), g0[s][n].float())
+            assert c >= (0.9995 if "upsamplers" in n else 0.995), (s, n, c)
+        for n in ("up_blocks.0.upsamplers.0.conv.weight", "up_blocks.0.upsamplers.0.conv.bias"):
+            rel = float((g1[s][n] - g0[s][n]).norm() / g0[s][n].norm())
+            assert rel <= 2e-2, (s, n, rel)
