@@ -6,7 +6,7 @@ namespace {
 
 constexpr int BN = 128, BK = 64;
 constexpr int kCRow = BN * 2 + 16;                       // bf16 epilogue row (256 B) + 16 B pad (bank spread, 16-B aligned)
-constexpr int kMaxPanels = 9;
+constexpr int kMaxPanels = 16;                           // (16: the (plane, tap) panels of a sub-pixel upsample convolution's dgrad)
 
 struct NTParams {
     const bf16_t* A; const bf16_t* W; bf16_t* C;

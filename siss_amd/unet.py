@@ -981,7 +981,7 @@ class UNetEngine:
         (optimizer.hip siss_upsample_phase_weights: phase weights = f32 sums of the 3x3 taps, rounded once), 16 instead of 36 tap
         products per low-resolution pixel, no upsampled tensor.  Forward: one product per phase whose epilogue scatters to the
         high-resolution pixels (siss_gemm_nt_d2s_bias).  Backward: space-to-depth of the cotangent, then the dgrad as 16 (plane, tap)
-        panels of ONE accumulation (two 8-panel launches) and the weight gradient as four 4-panel products into a phase-tap
+        panels of ONE product and the weight gradient as four 4-panel products into a phase-tap
         scratch that a fold kernel adds onto the nine taps.  Measured per site against upsample copy + persistent 3x3 kernel + fused
         3-tap wgrad (tools/probes/subpixel_upsample.py): 128 -> 256 x 128 ch 1634 -> 1282 us, 64 -> 128 x 256 ch 1309 -> 999 us --
         the flops saved outweigh the generic kernels' lower rate and the consumer GroupNorm's own statistics pass."""
@@ -1033,10 +1033,8 @@ class UNetEngine:
             dx = self._get(nb, lo_h, lo_w, C)
             sh = [-s_ for plane in range(4) for s_ in phase_shifts(plane)]
             co = [plane * C for plane in range(4) for _ in range(4)]
-            ops.gemm_nt(lib.ptr(z.data), 4 * C, wd[:8], lib.ptr(dx.data), C, z.rows, C, C, sh[:8], co[:8],
+            ops.gemm_nt(lib.ptr(z.data), 4 * C, wd, lib.ptr(dx.data), C, z.rows, C, C, sh, co,
                         rows_per_image=z.rows_per_image, hp=z.hp, wp=z.wp)
-            ops.gemm_nt(lib.ptr(z.data), 4 * C, wd[8:], lib.ptr(dx.data), C, z.rows, C, C, sh[8:], co[8:],
-                        res_ptr=lib.ptr(dx.data), ldr=C, rows_per_image=z.rows_per_image, hp=z.hp, wp=z.wp)
             self._put(z)
             self._give(x, dx)
         self.tape.append(bwd)
