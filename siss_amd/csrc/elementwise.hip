@@ -234,34 +234,96 @@ __global__ __launch_bounds__(kThreads) void colsum_kernel(const bf16_t* __restri
 // k = tap*Cin + ci (zero beyond); halo rows are written as zeros.
 // flip = 1 mirrors the tap offsets (k = tap*Cin + ci reads img[y - (ky-1), x - (kx-1)]): the im2col of a
 // COTANGENT image, which turns conv_out's dgrad / wgrad into plain one-panel GEMMs.
-template <bool BF16>
-__global__ void im2col3x3_kernel(const void* __restrict__ img, bf16_t* __restrict__ out, int N, int Cin, int H,
+template <bool BF16, int CIN>                                  // CIN: the channel count as a constant (1, 3, 4), or 0 = run-time Cin
+__global__ void im2col3x3_kernel(const void* __restrict__ img, bf16_t* __restrict__ out, int N, int Cin_rt, int H,
                                  int W, int K, int flip) {
-    const long total = (long)N * (H + 2) * (W + 2);
-    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (long)gridDim.x * blockDim.x) {
-        const int xp = r % (W + 2); long t = r / (W + 2);
-        const int yp = t % (H + 2); const int n = t / (H + 2);
-        bf16_t* dst = out + r * K;
+    const int Cin = CIN ? CIN : Cin_rt;                         // (a constant divisor: k / Cin is a multiply-shift, not a ~25-instruction divide)
+    // one thread per 16-B chunk (8 consecutive k of one row): the K / 8 lanes of a row write its K * 2 bytes contiguously, a wave
+    // writes 1 KiB in one piece per store instruction (round 4: one thread per ROW wrote eight 16-B chunks 128 B apart from its
+    // neighbours' -- 64 separate segments per store instruction, 1.2 TB/s; 350 us of the CelebA-HQ step for 408 MB)
+    // The grid carries (image, padded row): a thread decodes only (pixel, chunk) of its row, in 32 bits -- the flat 64-bit index this
+    // kernel used to split cost four 64-bit divisions (~100 instructions each) per 16-B store: 300 us of ALU for 408 MB.
+    const unsigned cpr = K >> 3;                                // chunks per row
+    const int n = blockIdx.z, yp = blockIdx.y;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)(W + 2) * cpr; idx += gridDim.x * blockDim.x) {
+        const int xp = idx / cpr, ch = idx - xp * cpr;
+        const long r = ((long)n * (H + 2) + yp) * (W + 2) + xp;
         const bool halo = xp == 0 || yp == 0 || xp == W + 1 || yp == H + 1;
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + e, tap = k / Cin, ci = k - tap * Cin;
-                float val = 0.f;
-                if (!halo && tap < 9) {
-                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                    const int y = yp - 1 + (flip ? -dy : dy), x = xp - 1 + (flip ? -dx : dx);
-                    if (y >= 0 && y < H && x >= 0 && x < W) {
-                        const long o = (((long)n * Cin + ci) * H + y) * W + x;
-                        val = BF16 ? bf2f(reinterpret_cast<const bf16_t*>(img)[o]) : reinterpret_cast<const float*>(img)[o];
-                    }
-                }
-                v[e] = val;
-            }
-            *reinterpret_cast<u32x4_t*>(dst + k0) = pack8(v);
+        if (halo || ch * 8 >= 9 * Cin) {                        // halo rows and the zero padding of K beyond 9 Cin: nothing to gather
+            *reinterpret_cast<u32x4_t*>(out + r * K + ch * 8) = u32x4_t{0u, 0u, 0u, 0u};
+            continue;
         }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e, tap = k / Cin, ci = k - tap * Cin;
+            float val = 0.f;
+            if (!halo && tap < 9) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const int y = yp - 1 + (flip ? -dy : dy), x = xp - 1 + (flip ? -dx : dx);
+                if (y >= 0 && y < H && x >= 0 && x < W) {
+                    const long o = (((long)n * Cin + ci) * H + y) * W + x;
+                    val = BF16 ? bf2f(reinterpret_cast<const bf16_t*>(img)[o]) : reinterpret_cast<const float*>(img)[o];
+                }
+            }
+            v[e] = val;
+        }
+        *reinterpret_cast<u32x4_t*>(out + r * K + ch * 8) = pack8(v);
     }
+}
+
+// Fast form for Cin in {1, 3, 4} with K = 64 (conv_in / conv_out of image-space UNets: 9 Cin <= 36 live columns): one thread gathers
+// ALL live columns of its row -- every (tap, channel) is a compile-time constant after unrolling, so an element costs one add of a
+// wave-uniform offset, a predicate and a load (the one-chunk-per-thread form above re-derived tap / channel / 64-bit address per
+// element with quarter-rate 32-bit multiplies: 270 us of the CelebA-HQ step for 408 MB) -- parks the row in LDS and the block
+// writes its 256 rows as one contiguous 32 KiB run of 16-B stores.
+template <bool BF16, int CIN>
+__global__ __launch_bounds__(kThreads) void im2col3x3_rows_kernel(const void* __restrict__ img, bf16_t* __restrict__ out, int H, int W,
+                                                                  int flip) {
+    constexpr int K = 64, NK = 9 * CIN, ROWB = 2 * K + 16;                 // LDS row: 128 B + 16 B pad (bank spread)
+    __shared__ __attribute__((aligned(16))) char tile[kThreads * ROWB];
+    const int n = blockIdx.y, Wp = W + 2, rpi = (H + 2) * Wp;
+    const int r0 = blockIdx.x * kThreads, rr = r0 + threadIdx.x;          // padded row within the image
+    const long hw = (long)H * W;
+    if (rr < rpi) {
+        const int yp = rr / Wp, xp = rr - yp * Wp;
+        const bool halo = xp == 0 || yp == 0 || xp == W + 1 || yp == H + 1;
+        float v[40];
+#pragma unroll
+        for (int k = 0; k < 40; ++k) v[k] = 0.f;
+        if (!halo) {
+            const int y0 = yp - 1, x0 = xp - 1;
+            const long base = (long)n * CIN * hw + (long)y0 * W + x0;
+            bool oky[3], okx[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int dd = flip ? 1 - d : d - 1;
+                oky[d] = y0 + dd >= 0 && y0 + dd < H; okx[d] = x0 + dd >= 0 && x0 + dd < W;
+            }
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int tap = k / CIN, ci = k - tap * CIN, ty = tap / 3, tx = tap - ty * 3;
+                const int dy = flip ? 1 - ty : ty - 1, dx = flip ? 1 - tx : tx - 1;
+                if (oky[ty] && okx[tx]) {
+                    const long o = base + ci * hw + dy * W + dx;
+                    v[k] = BF16 ? bf2f(reinterpret_cast<const bf16_t*>(img)[o]) : reinterpret_cast<const float*>(img)[o];
+                }
+            }
+        }
+        char* dst = tile + threadIdx.x * ROWB;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const float (&w8)[8] = *reinterpret_cast<const float (*)[8]>(&v[c * 8]);
+            *reinterpret_cast<u32x4_t*>(dst + c * 16) = pack8(w8);
+        }
+#pragma unroll
+        for (int c = 5; c < 8; ++c) *reinterpret_cast<u32x4_t*>(dst + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    const int nrows = rpi - r0 < kThreads ? rpi - r0 : kThreads;
+    bf16_t* gout = out + ((long)n * rpi + r0) * K;
+    for (int c = threadIdx.x; c < nrows * 8; c += kThreads)
+        *reinterpret_cast<u32x4_t*>(gout + (long)c * 8) = *reinterpret_cast<const u32x4_t*>(tile + (c >> 3) * ROWB + (c & 7) * 16);
 }
 
 // out[set][c] += sum over the set's images and pixels of img[n][c][:, :]   (f32 NCHW; conv_out bias gradient)
@@ -377,11 +439,20 @@ int siss_colsum(const void* y, long rows_per_set, int C, int nsets, long out_set
 int siss_im2col3x3(const void* img, int img_bf16, void* out, int N, int Cin, int H, int W, int K, int flip,
                    void* stream) {
     SISS_CHECK_ARG(img && out && N > 0 && Cin > 0 && H > 0 && W > 0 && K >= 9 * Cin && K % 8 == 0);
-    const long total = (long)N * (H + 2) * (W + 2);
-    if (img_bf16)
-        im2col3x3_kernel<true><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(img, (bf16_t*)out, N, Cin, H, W, K, flip);
-    else
-        im2col3x3_kernel<false><<<grid_for(total), kThreads, 0, (hipStream_t)stream>>>(img, (bf16_t*)out, N, Cin, H, W, K, flip);
+    SISS_CHECK_ARG(N <= 65535 && H + 2 <= 65535);
+    if (K == 64 && (Cin == 1 || Cin == 3 || Cin == 4)) {
+        const dim3 g2(cdiv((long)(H + 2) * (W + 2), kThreads), N);
+#define IM2ROWS(BF, CI) im2col3x3_rows_kernel<BF, CI><<<g2, kThreads, 0, (hipStream_t)stream>>>(img, (bf16_t*)out, H, W, flip)
+        if (img_bf16) { if (Cin == 3) IM2ROWS(true, 3); else if (Cin == 4) IM2ROWS(true, 4); else IM2ROWS(true, 1); }
+        else { if (Cin == 3) IM2ROWS(false, 3); else if (Cin == 4) IM2ROWS(false, 4); else IM2ROWS(false, 1); }
+#undef IM2ROWS
+        SISS_LAUNCH_RET();
+    }
+    const dim3 grid(cdiv((long)(W + 2) * (K / 8), kThreads), H + 2, N);
+#define IM2COL(BF, CI) im2col3x3_kernel<BF, CI><<<grid, kThreads, 0, (hipStream_t)stream>>>(img, (bf16_t*)out, N, Cin, H, W, K, flip)
+    if (img_bf16) { if (Cin == 3) IM2COL(true, 3); else if (Cin == 4) IM2COL(true, 4); else if (Cin == 1) IM2COL(true, 1); else IM2COL(true, 0); }
+    else { if (Cin == 3) IM2COL(false, 3); else if (Cin == 4) IM2COL(false, 4); else if (Cin == 1) IM2COL(false, 1); else IM2COL(false, 0); }
+#undef IM2COL
     SISS_LAUNCH_RET();
 }
 
@@ -389,8 +460,8 @@ int siss_im2col3x3(const void* img, int img_bf16, void* out, int N, int Cin, int
 int siss_nchw_channel_sums(const float* img, int nsets, int set_images, int C, long hw, long out_set_stride, float* out,
                            void* stream) {
     SISS_CHECK_ARG(img && out && nsets > 0 && set_images > 0 && C > 0 && hw > 0);
-    long nb = (hw + kThreads * 16 - 1) / (kThreads * 16);
-    if (nb > 64) nb = 64;
+    long nb = (hw + kThreads * 2 - 1) / (kThreads * 2);     // (round 4: 96 blocks walked the CelebA-HQ cotangent in 97 us; 25 MB)
+    if (nb > 128) nb = 128;
     dim3 grid((int)nb, C, nsets);
     nchw_channel_sums_kernel<<<grid, kThreads, 0, (hipStream_t)stream>>>(img, set_images, C, hw, out_set_stride, out);
     SISS_LAUNCH_RET();
