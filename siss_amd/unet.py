@@ -213,6 +213,7 @@ class UNetEngine:
         self.on_early_grads_final = None
         self._wq, self._held, self._held_release = [], {}, []
         self._wstream, self._sheld, self._side_open = None, {}, False
+        self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
     def _early_blocks(self):
@@ -349,16 +350,8 @@ class UNetEngine:
                      self._wt_tiles)
         for pre, (buf, idx) in self._wds.items():
             torch.index_select(self.wT[pre + ".conv.weight"], 0, idx, out=buf)
-        if self.subpixel_up and not self.f32:
-            if not hasattr(self, "_up_w"):
-                self._up_w = {}
-                for n, sp in ps.specs.items():
-                    if ".upsamplers." in n and n.endswith(".conv.weight"):
-                        _, co, ci = sp.native_shape
-                        self._up_w[n] = (torch.empty(4, 4, co, ci, dtype=torch.bfloat16, device=self.device),
-                                         torch.empty(16, ci, co, dtype=torch.bfloat16, device=self.device))
-            for n, (wf, wd) in self._up_w.items():        # phase weights from the f32 master: sums in f32, one rounding
-                lib.call("siss_upsample_phase_weights", ps.p(n), wf, wd, wf.shape[2], wf.shape[3])
+        for n, (wf, wd) in self._up_w.items():            # sub-pixel upsample sites: phase weights from the f32 master (f32 sums, one rounding)
+            lib.call("siss_upsample_phase_weights", ps.p(n), wf, wd, wf.shape[2], wf.shape[3])
         # conv_out dgrad operand: Wn^T, [Cin][K = 9*Cout padded to 64] bf16 (k = tap*Cout + co)
         w = ps.p("conv_out.weight")
         k = w.shape[0] * w.shape[1]
@@ -989,6 +982,11 @@ class UNetEngine:
         C, B, lo_h, lo_w = x.c, x.n, x.h, x.w
         H, W = 2 * lo_h, 2 * lo_w
         wname = pre + ".conv.weight"
+        if wname not in self._up_w:                     # phase-weight buffers of the sites that take this form (refresh_weights keeps them current)
+            _, co_, ci_ = ps.specs[wname].native_shape
+            self._up_w[wname] = (torch.empty(4, 4, co_, ci_, dtype=torch.bfloat16, device=self.device),
+                                 torch.empty(16, ci_, co_, dtype=torch.bfloat16, device=self.device))
+            lib.call("siss_upsample_phase_weights", ps.p(wname), *self._up_w[wname], co_, ci_)
         wf, wd = self._up_w[wname]
         if cat_with is not None and self.direct_cat:
             assert (cat_with.n, cat_with.h, cat_with.w) == (B, H, W)

@@ -54,6 +54,7 @@ class VAEEncoder(UNetEngine):
         self.adt, self.f32 = torch.bfloat16, False         # (forward-only front end: the bf16 path)
         self._wq, self._held, self._held_release = [], {}, []
         self._wstream, self._sheld, self._side_open = None, {}, False
+        self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
     def _declare_enc_resnet(self, pre, cin, cout):
