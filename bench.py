@@ -364,13 +364,11 @@ def main():
     if not a.no_kernel_timing:
         # every rank runs these steps (the step holds a collective when N>1); only rank 0 records events
         lib.PROF = [] if rank == 0 else None
-        side_stream, eng.wgrad_stream = eng.wgrad_stream, 0      # one stream: a launch's events then bracket that launch alone
         ksteps = min(a.steps, 3)
         for _ in range(ksteps):
             one_step()
         sync()
         prof, lib.PROF = lib.PROF, None
-        eng.wgrad_stream = side_stream
     if not a.no_kernel_timing and rank == 0:
         ksym = {}
         hbm = {}

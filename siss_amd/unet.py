@@ -174,13 +174,6 @@ class UNetEngine:
     group_rows = 280000
     group_max = 42
     group_attn = True      # ... the attention blocks' linears too
-    # Weight gradients on a SIDE STREAM (round 4).  Nothing in the backward waits for a weight gradient (they only feed the flat
-    # gradient buffer), so they need not sit in the dgrad -> GroupNorm-backward dependency chain: launched on a second HIP stream
-    # they run BESIDE it -- an MFMA-bound wgrad block (8 waves, 135 KiB of LDS) and the HBM-bound GroupNorm-backward blocks
-    # (4 waves, 16 KiB) fit on one CU together, and the latency-bound low-resolution chain leaves most CUs to them.  Their
-    # operands are kept out of the buffer pool's reach by events (_sheld), the streams join at the end of the backward (and
-    # before the data-parallel hook).  Captured into the step's hipGraph as a fork / join.  0 = everything on one stream.
-    wgrad_stream = 0
 
     def __init__(self, cfg: UNet2DConfig, device="cuda", dtype=torch.bfloat16):
         """dtype = torch.float32: the f32 PARITY MODE (`mixed_precision: null` of the reference's YAMLs; csrc/f32_path.hip) -- every
@@ -194,7 +187,7 @@ class UNetEngine:
         self.adt, self.f32 = dtype, dtype == torch.float32
         if self.f32:
             self.epi_stats = self.d2s_epilogue = self.fold_shortcut = False
-            self.group_rows = self.wgrad_stream = 0
+            self.group_rows = 0
         if self.device.type == "cuda":
             lib.ensure_workspace(self.device)
         self.ps = ParamStore()
@@ -212,7 +205,6 @@ class UNetEngine:
         self._uid = 0
         self.on_early_grads_final = None
         self._wq, self._held, self._held_release = [], {}, []
-        self._wstream, self._sheld, self._side_open = None, {}, False
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -418,52 +410,15 @@ class UNetEngine:
         return a
 
     def _wsync(self, a):
-        """`a` is about to be overwritten: a queued (grouped) wgrad that still reads it must run first, and one that runs on the
-        side stream must have finished (the current stream waits for its event)."""
-        if a is None:
-            return
-        key = id(getattr(a, "base", a).buf)
-        if self._held and key in self._held:
+        """`a` is about to be overwritten: a queued (grouped) wgrad that still reads it must run first."""
+        if a is not None and self._held and id(getattr(a, "base", a).buf) in self._held:
             self._flush_wgrads()
-        if self._sheld:
-            ev = self._sheld.pop(key, None)
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-
-    def _on_side(self, launch, operands):
-        """Run `launch()` (weight-gradient launches) on the side stream, after everything enqueued so far on the current one; the
-        operands' buffers are marked with the event that says the launches are done."""
-        main = torch.cuda.current_stream()
-        if self._wstream is None:
-            self._wstream = torch.cuda.Stream(device=self.device)
-        ws = self._wstream
-        ws.wait_stream(main)
-        with torch.cuda.stream(ws):
-            launch()
-            ev = torch.cuda.Event()
-            ev.record(ws)
-        for a in operands:
-            if a is not None:
-                self._sheld[id(getattr(a, "base", a).buf)] = ev
-        self._side_open = True
-
-    def _join_side(self):
-        """The current stream waits for every weight gradient launched on the side stream so far."""
-        if self._side_open:
-            torch.cuda.current_stream().wait_stream(self._wstream)
-            self._side_open = False
-        self._sheld = {}
 
     def _flush_wgrads(self):
         """Run the queued weight-gradient products as grouped launches and give their operands back to the pool."""
         if self._wq:
             jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
-            if self.wgrad_stream:
-                ops_ = [a for _, pair in self._wq for a in pair if isinstance(a, (Act, ActView))]
-                n = len(self._wq)
-                self._on_side(lambda: lib.call("siss_gemm_tn_grouped", jobs, n), ops_)
-            else:
-                lib.call("siss_gemm_tn_grouped", jobs, len(self._wq))
+            lib.call("siss_gemm_tn_grouped", jobs, len(self._wq))
             self._wq = []
         self._held = {}
         rel, self._held_release = self._held_release, []
@@ -674,13 +629,8 @@ class UNetEngine:
             if len(self._wq) >= self.group_max:
                 self._flush_wgrads()
             return
-        def launch():
-            lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or getattr(x, "ld", x.c), dW_view, ps.total, co, ci, t,
-                     sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2)
-        if self.wgrad_stream and isinstance(dy, Act):
-            self._on_side(launch, (dy, x if isinstance(x, (Act, ActView)) else None))
-        else:
-            launch()
+        lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or getattr(x, "ld", x.c), dW_view, ps.total, co, ci, t,
+                 sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2)
 
     # ------------------------------------------------------------------ time embedding
     def time_embed(self, t):
@@ -1106,7 +1056,6 @@ class UNetEngine:
         assert cin == cfg.in_channels
         self.tape, self.gmap, self._uid = [], {}, 0
         self._wq, self._held, self._held_release = [], {}, []
-        self._join_side()                               # (a backward that raised half-way: nothing of it may still run)
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
@@ -1247,8 +1196,6 @@ class UNetEngine:
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail
-                self._join_side()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
         self._flush_wgrads()
-        self._join_side()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"

@@ -53,7 +53,6 @@ class VAEEncoder(UNetEngine):
         self.on_early_grads_final = None
         self.adt, self.f32 = torch.bfloat16, False         # (forward-only front end: the bf16 path)
         self._wq, self._held, self._held_release = [], {}, []
-        self._wstream, self._sheld, self._side_open = None, {}, False
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
