@@ -5,6 +5,7 @@ non-zero status, a RuntimeError is raised.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -119,23 +120,21 @@ F32_SAME = {"siss_timestep_sincos", "siss_linear_small_fwd", "siss_linear_small_
             "siss_ddpm_step", "siss_grad_norms_scale", "siss_grad_norm_partials", "siss_grad_scalars", "siss_recombine_clip_adamw"}
 for _b, _f in F32_ENTRY.items():
     SIGNATURES[_f] = SIGNATURES[_b]
-_F32 = False
+_MODE = threading.local()        # per thread: autograd runs an engine's backward on its own device thread (siss_amd/model.py)
 
 
 class f32_mode:
-    """`with lib.f32_mode(engine.f32):` -- the launches inside go to the f32 entry points when the flag is set."""
+    """`with lib.f32_mode(engine.f32):` -- the launches of THIS thread inside the block go to the f32 entry points when the flag is set."""
 
     def __init__(self, on):
         self.on = bool(on)
 
     def __enter__(self):
-        global _F32
-        self.prev, _F32 = _F32, self.on
+        self.prev, _MODE.f32 = getattr(_MODE, "f32", False), self.on
         return self
 
     def __exit__(self, *exc):
-        global _F32
-        _F32 = self.prev
+        _MODE.f32 = self.prev
         return False
 
 
@@ -344,7 +343,7 @@ def kernel_symbol(name, a):
 def call(name, *args):
     """Call a launcher on torch's current stream; tensors are passed as raw pointers."""
     lib = load()
-    if _F32:
+    if getattr(_MODE, "f32", False):
         if name in F32_ENTRY:
             name = F32_ENTRY[name]
         elif name not in F32_SAME:
