@@ -144,6 +144,42 @@ def test_f32_mode_refuses_entry_points_without_an_f32_form():
             lib.call("siss_flash_attn_fwd_merged")
 
 
+@pytest.mark.parametrize("loss_fn", ["erasediff", "simple_neg_del", "naive_del", "subscore_bernoulli"])
+def test_f32_baseline_objectives_match_the_oracle_at_1e4(loss_fn):
+    """The four other objectives of the class surface (ddpm_deletion_loss.py:70-122) on the fused stepper in the f32 mode: EraseDiff
+    (two forwards, U[0, 1) target, s = -max(eta - <g_x, g_a> / |g_a|^2, 0)), NegGrad / naive (one backward, no split), Bernoulli
+    sub-score (row selection as per-sample weights) -- step scalars and the parameter update at the f32 bound."""
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    from parity_util import check_scalars, masked_update_cosine
+    eng, net, sd = _pair(CELEB_TOY, seed=9)
+    net = net.float()
+    ac = S.alphas_cumprod()
+    okw = dict(lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6)
+    opt = torch.optim.AdamW(net.parameters(), **okw)
+    g = torch.Generator().manual_seed(41)
+    mb = dict(x0=torch.rand(4, 3, 16, 16, generator=g) * 2 - 1, a0=(torch.rand(1, 3, 16, 16, generator=g) * 2 - 1).repeat(4, 1, 1, 1),
+              noise=torch.randn(4, 3, 16, 16, generator=g), t=torch.tensor([999, 400, 999, 50]), u=torch.tensor([0.9, 0.2, 0.7, 0.4]))
+    lp = {"lambd": 0.5} if loss_fn == "subscore_bernoulli" else ({"superfactor": 3.0} if loss_fn == "simple_neg_del" else {})
+    kw = dict(scaling_norm=5.0) if loss_fn != "erasediff" else dict(eta=1e-2)
+    st = SISSStepper(eng, ac, lambd=0.5, train_batch_size=4, loss_fn=loss_fn, mixed_precision=None, superfactor=3.0, inf_guard=True,
+                     **okw, **kw)
+    torch.manual_seed(99)                                     # erasediff: rand_like is the first draw in the oracle
+    ref, _, _, gfin = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), loss_fn, ac, [mb], train_batch_size=4,
+                                      scaling_norm=5.0, eta=1e-2, loss_params=lp, inf_guard=True)
+    torch.manual_seed(99)
+    target = torch.rand(mb["noise"].shape) if loss_fn == "erasediff" else None
+    st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"], erase_target=target)
+    got = st.stats()
+    keys = ("pre_clip_norm",) if loss_fn in ("simple_neg_del", "naive_del") else ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm")
+    check_scalars(ref, got, keys=keys, tol=2 * RTOL)
+    cos, frac = masked_update_cosine(sd, dict(net.named_parameters()), eng.state_dict(), gfin)
+    print(f"\n{loss_fn}: " + ", ".join(f"{k} {got[k]:.7g} / {getattr(ref, k):.7g}" for k in keys) + f"; masked update cosine {cos:.6f}")
+    assert cos >= 0.9999 and frac > 0.5, (cos, frac)
+
+
 # ---------------------------------------------------------------- the SD UNet (UNet2DConditionModel) in the f32 mode
 SD_CASES = {
     # one cross-attention level (head_dim 32) + one plain level; mid attention head_dim 64
