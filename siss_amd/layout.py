@@ -14,13 +14,14 @@ import torch
 class Act:
     """A padded NHWC bf16 activation living in one flat torch buffer."""
 
-    __slots__ = ("buf", "n", "h", "w", "c", "guard", "cat_parts", "cat_done", "qstats")
+    __slots__ = ("buf", "n", "h", "w", "c", "guard", "cat_parts", "cat_done", "qstats", "s2d_cot")
 
     def __init__(self, n, h, w, c, device="cuda", buf=None, dtype=torch.bfloat16):
         """dtype: bf16 (the product path) or f32 (the f32 parity mode: csrc/f32_path.hip)."""
         self.n, self.h, self.w, self.c = n, h, w, c
         self.cat_parts, self.cat_done = None, False
         self.qstats = None                            # GroupNorm statistics left by the producing conv (engine bookkeeping)
+        self.s2d_cot = False                          # its consumer wants its cotangent in space-to-depth layout (sub-pixel upsample)
         self.guard = (w + 2) + 2                      # rows of zero guard on each side
         rows = self.rows + 2 * self.guard
         if buf is None:
@@ -86,12 +87,13 @@ class ActView:
     to be concatenated writes straight into the concat buffer through one of these (GEMM epilogue with ldc = ld), so
     the concat only has to copy the other part."""
 
-    __slots__ = ("base", "c0", "n", "h", "w", "c", "ld", "cat_parts", "cat_done", "qstats")
+    __slots__ = ("base", "c0", "n", "h", "w", "c", "ld", "cat_parts", "cat_done", "qstats", "s2d_cot")
 
     def __init__(self, base, c0, c):
         assert 0 <= c0 and c0 + c <= base.c and c0 % 8 == 0 and c % 8 == 0
         self.base, self.c0, self.c, self.ld = base, c0, c, base.c
         self.qstats = None
+        self.s2d_cot = False
         self.n, self.h, self.w = base.n, base.h, base.w
         self.cat_parts, self.cat_done = None, False
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "siss_groupnorm_fwd_qs": [P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, F, I, I, I, P],
     "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],
     "siss_groupnorm_bwd_ld": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, I, P],
+    "siss_groupnorm_bwd_ld_s2d": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, I, P],
     "siss_upsample2x": [P, P, I, I, I, I, P],
     "siss_upsample2x_bwd": [P, P, I, I, I, I, P],
     "siss_concat": [P, P, P, I, I, I, I, I, P],
@@ -275,7 +276,7 @@ def hbm_bytes(name, a):
     result written once), for bench.py's GB/s-vs-HBM-peak figures.  None for the others."""
     if name in ("siss_groupnorm_fwd", "siss_groupnorm_fwd_ld"):            # read x + write y (bf16)
         return 2.0 * 2 * a[7] * a[8] * a[9] * a[10]
-    if name in ("siss_groupnorm_bwd", "siss_groupnorm_bwd_ld"):            # read x (nx samples), read dy + write dx (n2 samples) (+ accum reads)
+    if name in ("siss_groupnorm_bwd", "siss_groupnorm_bwd_ld", "siss_groupnorm_bwd_ld_s2d"):   # read x (nx samples), read dy + write dx (n2 samples) (+ accum reads)
         px = a[21] * a[22] * a[23]
         n2, nx = a[17], a[18]
         extra = (1 if a[7] is not None else 0) + (1 if a[8] is not None else 0)
@@ -301,7 +302,7 @@ def _shape_key(name, a):
         return ("N", a[6], "C", a[7], "panels", a[8], "sets", a[11], "rows", a[15] - a[14], "splits", a[16])
     if name in ("siss_groupnorm_fwd", "siss_groupnorm_fwd_ld"):
         return ("n", a[7], "H", a[8], "C", a[10])
-    if name in ("siss_groupnorm_bwd", "siss_groupnorm_bwd_ld"):
+    if name in ("siss_groupnorm_bwd", "siss_groupnorm_bwd_ld", "siss_groupnorm_bwd_ld_s2d"):
         return ("n2", a[17], "H", a[21], "C", a[23])
     if name == "siss_flash_attn_fwd":
         return ("BH", a[5], "Sq", a[6], "Sk", a[9], "D", a[8])
@@ -376,6 +377,8 @@ def call(name, *args):
                                           a[11], a[12], a[13], a[14], a[15], 1.0, 1, 0, 0, 0]
         elif name == "siss_groupnorm_fwd_qs":
             name, args = "siss_groupnorm_fwd_ld", list(args[:7]) + list(args[10:])
+        if name == "siss_groupnorm_bwd_ld_s2d":
+            name = "siss_groupnorm_bwd_ld"
         base = name[:-3] if name.endswith("_ld") else name          # row-stride variants count as their plain form
         if base.endswith("_merged"):
             base = base[:-7]

@@ -165,6 +165,7 @@ class UNetEngine:
     # every site 55.68, from 32 x 32 up 55.29, from 64 x 64 up 55.84 / 55.61 -- below 32 x 32 the phase products are latency-bound
     # launches that the grouped weight gradients and the slab GroupNorm of the literal form beat
     subpixel_min_px = 1024
+    s2d_from_gn = True     # ... and their cotangent arrives space-to-depth from the GroupNorm backward that forms it (no layout pass)
     # Weight gradients of all but the top-resolution layers (at most group_rows reduction rows per set: CelebA-HQ's 8x8 .. 128x128
     # levels) are not launched one by one -- each alone leaves CUs idle in its last round of blocks and pays a launch's fixed
     # ~10-40 us -- but queued and run as grouped launches (siss_gemm_tn_grouped: one job table, one launch per kernel variant).
@@ -497,15 +498,17 @@ class UNetEngine:
             held = accum is not None and self._held and id(accum.buf) in self._held
             if accum is not None and not held:
                 self._wsync(accum)                      # written in place
+            s2d = False
             if split is not None:
-                da, db, accb = split
-                dx, dx2p, split_c = da, db.data, da.c
+                da, db, accb = split[:3]
+                s2d = len(split) > 3 and bool(split[3])   # da is a half-resolution, 4x-channel Act: the first part in space-to-depth layout
+                dx, dx2p, split_c = da, db.data, (da.c // 4 if s2d else da.c)
                 self._wsync(db)
             else:
                 dx = accum if (accum is not None and not held) else self._get(nb, x.h, x.w, x.c)
                 dx2p, split_c, accb = None, 0, False
             dyp = dy.data if isinstance(dy, Act) else dy
-            lib.call("siss_groupnorm_bwd_ld", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
+            lib.call("siss_groupnorm_bwd_ld_s2d" if s2d else "siss_groupnorm_bwd_ld", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
                      dx.data, accum.data if accum is not None else None,
                      accum2.data if accum2 is not None else None, dx2p, split_c, int(accb),
                      ps.g(pre + ".weight", self.gbase), ps.g(pre + ".bias", self.gbase), colsum, colsum_ld,
@@ -719,10 +722,12 @@ class UNetEngine:
             if parts is not None:
                 # x = concat(a, b): norm1's backward writes d_a and d_b (+= the skip's running cotangent) directly
                 a, b = parts
-                da = self._get(nb, a.h, a.w, a.c)
+                # (a sub-pixel upsample's output takes its cotangent in space-to-depth layout straight from this kernel's store path)
+                s2d = bool(getattr(a, "s2d_cot", False)) and self.gmap.get(id(a)) is None
+                da = self._get(nb, a.h // 2, a.w // 2, 4 * a.c) if s2d else self._get(nb, a.h, a.w, a.c)
                 accb = self.gmap.get(id(b))
                 db = accb if accb is not None else self._get(nb, b.h, b.w, b.c)
-                gn1_b(da1, accum=acc, accum2=prior, split=(da, db, accb is not None))
+                gn1_b(da1, accum=acc, accum2=prior, split=(da, db, accb is not None, s2d))
                 self.gmap[id(b)] = db
                 self._put(acc)
                 self._give(a, da)
@@ -948,6 +953,7 @@ class UNetEngine:
         else:
             y = self._act(self._name(pre + ".conv"), B, H, W, C)
         y.qstats = None
+        y.s2d_cot = self.s2d_from_gn                    # the consuming resnet's norm1 backward may write the cotangent space-to-depth
         wp = x.wp
         ldx = getattr(x, "ld", C)
 
@@ -962,9 +968,12 @@ class UNetEngine:
         def bwd():
             nb, gb = self.nb, self.gbase
             dy = self._take(y)
-            z = self._get(nb, lo_h, lo_w, 4 * C)
-            lib.call("siss_space_to_depth", dy.data, z.data, nb, H, W, C)
-            self._put(dy)
+            if (dy.h, dy.w, dy.c) == (lo_h, lo_w, 4 * C):   # already space-to-depth (written so by the consumer's GroupNorm backward)
+                z = dy
+            else:
+                z = self._get(nb, lo_h, lo_w, 4 * C)
+                lib.call("siss_space_to_depth", dy.data, z.data, nb, H, W, C)
+                self._put(dy)
             # weight gradient: per plane, Y = the plane's columns of z, X = the four shifted low-resolution panels
             dW4 = self._buf("up.dW4", (self.nsets, 4, 4, C, C))
             dW4.zero_()

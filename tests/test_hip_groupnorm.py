@@ -193,3 +193,45 @@ def test_groupnorm_backward(dev, mode, B, sets, C, H, W, silu, cdy, acc, acc2, s
             assert torch.equal(runs[0], runs[1]), "dx must be bitwise deterministic (fixed-order folds)"
     finally:
         lib.query("siss_groupnorm_set_slab", -1)
+
+
+@pytest.mark.parametrize("B,C,H,W,split,acc", [(2, 256, 64, 64, 128, True), (1, 384, 40, 48, 256, False), (2, 96, 24, 36, 64, True)])
+def test_groupnorm_backward_space_to_depth_target_equals_the_layout_pass(dev, B, C, H, W, split, acc):
+    """siss_groupnorm_bwd_ld_s2d writes the FIRST part of a split target in space-to-depth layout (what a sub-pixel upsample
+    convolution's backward consumes): bit for bit the plain split output pushed through siss_space_to_depth; the second part, the
+    parameter gradients and the column sums are those of the plain launch."""
+    from siss_amd import lib
+    from siss_amd.layout import Act
+    g = torch.Generator().manual_seed(C + H + W)
+    x = _bf(torch.randn(B, C, H, W, generator=g) * 1.3 + 0.2)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    n2, nsets, eps, silu = 2 * B, 2, 1e-6, True
+    dy = _bf(torch.randn(n2, C, H, W, generator=g))
+    r1 = _bf(torch.randn(n2, C, H, W, generator=g)) if acc else None
+    r3 = _bf(torch.randn(n2, C - split, H, W, generator=g))
+    part = torch.zeros(lib.query("siss_gn_partial_words", n2, H, W, C, G), device=dev)
+    xa, ldxv, _, _, _, (mean, rstd) = _run_fwd(lib, dev, x, gamma, beta, eps, silu, False, 0, part)
+    dya = Act.from_nchw(dy, dev)
+    a1 = Act.from_nchw(r1, dev) if acc else None
+    P = 4096
+    outs = []
+    for entry in ("siss_groupnorm_bwd_ld", "siss_groupnorm_bwd_ld_s2d"):
+        grads = torch.zeros(nsets, P, device=dev)
+        cs = torch.zeros(n2, C + 8, device=dev)
+        s2d = entry.endswith("_s2d")
+        da = Act(n2, H // 2, W // 2, 4 * split, dev) if s2d else Act(n2, H, W, split, dev)
+        db = Act.from_nchw(r3, dev)
+        lib.call(entry, dya.data, xa.data, gamma.to(dev), beta.to(dev), mean, rstd, da.data, a1.data if acc else None, None, db.data,
+                 split, 1, grads[0, 64:], grads[0, 2048:], cs, C + 8, part, n2, B, n2 // nsets, P, H, W, C, G, int(silu), 0, ldxv)
+        torch.cuda.synchronize()
+        if not s2d:
+            z = Act(n2, H // 2, W // 2, 4 * split, dev)
+            lib.call("siss_space_to_depth", da.data, z.data, n2, H, W, split)
+            torch.cuda.synchronize()
+            da = z
+        assert da.halo_is_zero()
+        outs.append((da.buf.clone(), db.buf.clone(), cs.clone(), grads.clone()))
+    (z0, b0, c0, g0), (z1, b1, c1, g1) = outs
+    assert torch.equal(z0, z1), "space-to-depth first part"
+    assert torch.equal(b0, b1), "second part"
+    assert torch.allclose(c0, c1, rtol=1e-5, atol=1e-5) and torch.allclose(g0, g1, rtol=1e-4, atol=1e-4)   # (float atomics: order-dependent)
