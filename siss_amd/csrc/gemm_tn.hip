@@ -241,6 +241,9 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
         // block, same barrier) exposed it at the same time.
         constexpr int SB = C_::kStageBytes;
         bf16x8_t yf[2][4], xf[2][TAPS][CT];
+        // Static priority for the second-dispatched half of the block (waves 4-7 share their SIMDs with waves 0-3 and lose every
+        // issue arbitration by age: MI355X_MICROARCH.md, 'Two waves per SIMD', item 4)
+        if (w >= 4) __builtin_amdgcn_s_setprio(1);
         stage(0, 0);
         if (steps > 1) stage(1, 1);
         if (ILV && steps > 2) stage(2, 2);
