@@ -351,7 +351,9 @@ __global__ __launch_bounds__(kThreads) void gn_bwd_stats_kernel(
                         const float ex = __builtin_amdgcn_exp2f(xh * ga2[e] + be2[e]);
                         const float sg = __builtin_amdgcn_rcpf(1.f + ex);
                         const float z = xh * ga[e] + be[e];
-                        q1[e] = sg * (1.f + z * (ex * sg));
+                        // (1 - s) as a subtraction, not as e s: for z < -88.7 e overflows to +inf, s = 0 and inf * 0 would poison the
+                        // whole (sample, group) with NaN; 1 - 0 = 1 gives SiLU' = 0 * (1 + z) = 0 like dsilu_f of the apply pass
+                        q1[e] = sg * (1.f + z * (1.f - sg));
                     } else {
                         q1[e] = 1.f;
                     }

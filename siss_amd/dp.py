@@ -8,14 +8,26 @@ replicated.  (The reference's DDP only reduces the first of its two backward pas
 equivalence with the single-process step.)  Used by SISSStepper on RCCL and by the gloo CPU tests.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
 
+# TEST-ONLY switch: with one rank there is nothing to exchange and every collective is skipped.  SISS_DP_FORCE_COLLECTIVES=1 (or
+# dp.FORCE_COLLECTIVES = True) issues them anyway, so that a world-size-1 RCCL communicator on the ONE GPU of a build box exercises
+# the real code path -- library load, communicator init, stream ordering against the engine's kernels, the coalescing window, the
+# overlap hook -- with results that must equal the no-group step (a sum over one rank is the identity).  tests/test_hip_rccl.py.
+FORCE_COLLECTIVES = os.environ.get("SISS_DP_FORCE_COLLECTIVES") == "1"
+
+
+def active(group=None):
+    """True when a step has to run its collectives: a process group of more than one rank (or the test-only force switch)."""
+    return bool(dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES))
+
 
 def allreduce_flat_grads(flat_pair, group=None):
     """In-place sum over ranks of the [2, P] gradient buffer -- the only collective of a step."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         dist.all_reduce(flat_pair, op=dist.ReduceOp.SUM, group=group)
     return flat_pair
 
@@ -28,7 +40,7 @@ def allreduce_pieces(tensors, group=None, async_op=False):
     a coalescing window, which RCCL runs as one grouped launch (ncclGroupStart / End) -- the overlapped exchange is two
     such calls per step ([tail_x, tail_a] from inside the backward, [head_x, head_a] after it), not four all-reduces.
     Returns a handle with .wait() when async_op."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+    if not active(group):
         return None
     try:
         from torch.distributed.distributed_c10d import _coalescing_manager
@@ -57,7 +69,7 @@ class _Works:
 def can_shard(P, world, align=4):
     """The sharded update hands every rank the parameter range [r P / N, (r + 1) P / N): the ranges must be equal and start
     on 16-byte boundaries (the flat kernels take float4 accesses)."""
-    return world > 1 and P % world == 0 and (P // world) % align == 0
+    return (world > 1 or FORCE_COLLECTIVES) and P % world == 0 and (P // world) % align == 0
 
 
 def reduce_scatter_param_shards(flat_pair, group=None):

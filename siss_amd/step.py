@@ -20,6 +20,7 @@ the single-process step on the concatenated batch.
 import torch
 
 from . import lib
+from . import dp
 from .dp import EXCHANGES, allreduce_flat_grads, allreduce_pieces, can_shard
 from .loss import loss_bwd_seed, mixture_fwd, mse_bwd_seed
 from .optim import FlatAdamW
@@ -55,6 +56,8 @@ class SISSStepper:
             assert eta is not None, "erasediff needs eta (delete_celeb.py:740-742)"
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # the step runs its collectives: more than one rank (or dp.FORCE_COLLECTIVES, the test-only switch for a 1-rank RCCL group)
+        self.dp_on = process_group is not None and (self.world > 1 or dp.FORCE_COLLECTIVES)
         self.io_dtype = torch.bfloat16 if mixed_precision == "bf16" else torch.float32
         f32_engine = getattr(engine, "f32", False)
         if f32_engine and mixed_precision == "bf16":
@@ -81,7 +84,7 @@ class SISSStepper:
         self.exchange = os.environ.get("SISS_DP_EXCHANGE", "allreduce")      # serial mode: "allreduce" | "sharded"
         self._state_shard = None                # (lo, hi) while AdamW's moments are current on this rank's shard only
         assert self.exchange in EXCHANGES
-        self.set_overlap(self.pg is not None and self.world > 1 and engine.ps.split < engine.ps.total
+        self.set_overlap(self.dp_on and engine.ps.split < engine.ps.total
                          and os.environ.get("SISS_DP_OVERLAP", "1") != "0")
 
     def set_overlap(self, on, exchange=None):
@@ -115,7 +118,7 @@ class SISSStepper:
         """Measure, don't guess: the overlapped exchange shares the chip with the persistent one-block-per-CU GEMMs of
         the high-resolution backward, and whether RCCL's workgroups cost those kernels more than the overlap hides
         depends on the node.  Times `iters` steps each way (max over ranks) and keeps the faster setting."""
-        if self.pg is None or self.world <= 1 or self.e.ps.split >= self.e.ps.total:
+        if not self.dp_on or self.e.ps.split >= self.e.ps.total:
             return self.overlap
         import time
         dist = torch.distributed
@@ -289,11 +292,11 @@ class SISSStepper:
 
     def _sync_and_update(self):
         g = self.e.ps.grads
-        sharded = (self.pg is not None and self.world > 1 and self.exchange == "sharded" and not self.overlap
+        sharded = (self.dp_on and self.exchange == "sharded" and not self.overlap
                    and can_shard(g.shape[1], self.world))
         if not sharded:
             self._gather_optimizer_state()      # a replicated update after sharded ones: every rank needs the whole m / v
-        if self.pg is not None and self.world > 1 and not sharded:
+        if self.dp_on and not sharded:
             # the exchange of the step: sum of [g_x ; g_a] over ranks (RCCL over xGMI) -- one flat buffer; with
             # the overlap hook the early-final tail is already in flight and only the head remains
             if self.overlap and self._pending:

@@ -235,3 +235,43 @@ def test_groupnorm_backward_space_to_depth_target_equals_the_layout_pass(dev, B,
     assert torch.equal(z0, z1), "space-to-depth first part"
     assert torch.equal(b0, b1), "second part"
     assert torch.allclose(c0, c1, rtol=1e-5, atol=1e-5) and torch.allclose(g0, g1, rtol=1e-4, atol=1e-4)   # (float atomics: order-dependent)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["two_pass", "slab"])
+def test_groupnorm_backward_extreme_negative_preactivation_stays_finite(dev, mode):
+    """A pre-activation below about -88.7 makes exp(-z) overflow in f32: SiLU'(z) must come out as 0 there (torch's value), not as
+    inf * 0 = NaN -- one such element would poison the statistics of its (sample, group), hence dx of the whole group, dgamma / dbeta
+    and the gradient norm.  Channel 3 sits at beta = -150, channel 5 at gamma = 90 (both signs of a huge |z|)."""
+    from siss_amd import lib
+    from siss_amd.layout import Act
+    B, C, H, W, sets = 2, 128, 40, 40, 2
+    g = torch.Generator().manual_seed(11)
+    x = _bf(torch.randn(B, C, H, W, generator=g) * 1.7 + 0.4)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    beta[3], gamma[5] = -150.0, 90.0
+    eps, n2 = 1e-6, sets * B
+    dy = _bf(torch.randn(n2, C, H, W, generator=g))
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.silu(F.group_norm(xr, G, gr, br, eps))
+    assert (F.group_norm(x, G, gamma, beta, eps) < -90).any(), "the case must reach the overflow range"
+    dx_ref = torch.cat([torch.autograd.grad(y, xr, dy[k * B:(k + 1) * B], retain_graph=True)[0] for k in range(sets)])
+    dg_ref = torch.stack([torch.autograd.grad(y, gr, dy[k * B:(k + 1) * B], retain_graph=True)[0] for k in range(sets)])
+    db_ref = torch.stack([torch.autograd.grad(y, br, dy[k * B:(k + 1) * B], retain_graph=True)[0] for k in range(sets)])
+    part = torch.zeros(lib.query("siss_gn_partial_words", n2, H, W, C, G), device=dev)
+    assert lib.query("siss_groupnorm_set_slab", mode) == mode
+    try:
+        xa, ldxv, _, _, _, (mean, rstd) = _run_fwd(lib, dev, x, gamma, beta, eps, True, False, 0, part)
+        dya, dxa = Act.from_nchw(dy, dev), Act(n2, H, W, C, dev)
+        P = 4096
+        grads = torch.zeros(2, P, device=dev)
+        lib.call("siss_groupnorm_bwd_ld", dya.data, xa.data, gamma.to(dev), beta.to(dev), mean, rstd, dxa.data, None, None, None, 0, 0,
+                 grads[0, 64:], grads[0, 2048:], None, 0, part, n2, B, B, P, H, W, C, G, 1, 0, ldxv)
+        torch.cuda.synchronize()
+        got = dxa.to_nchw().cpu()
+        assert torch.isfinite(got).all() and torch.isfinite(grads).all(), "NaN / inf from an overflowing exp(-z)"
+        _close(got, dx_ref, 1.5e-2, "dx")
+        for k in range(2):
+            _close(grads[k, 64:64 + C].cpu(), dg_ref[k], 5e-3, f"dgamma set {k}")
+            _close(grads[k, 2048:2048 + C].cpu(), db_ref[k], 5e-3, f"dbeta set {k}")
+    finally:
+        lib.query("siss_groupnorm_set_slab", -1)

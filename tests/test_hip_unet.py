@@ -335,6 +335,48 @@ def test_mnist_tshirt_config_at_yaml_batch_64():
     _check_scalars(r, st.stats())
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_mnist_tshirt_config_at_baseline_batch_32(mode):
+    """BASELINE configs[0] at ITS batch: delete_tshirt.yaml's MNIST UNet, SISS, bs = 32, t ~ U{0..999} (delete_tshirt.py:504-557),
+    inf guard -- in the two REAL modes of the HIP path: bf16 engine + bf16 I/O (`mixed_precision: bf16`; oracle fed the same
+    bf16-rounded inputs, step scalars rel 5e-2) and the f32 engine (`mixed_precision: null`, what the reference's CPU path of this
+    config computes in; step scalars rel 2e-4, masked update cosine >= 0.9999)."""
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.step import SISSStepper
+    from siss_amd.unet import UNetEngine
+    from oracle import schedule as S
+    from oracle.loss import OracleDeletionLoss
+    from oracle.step import unlearning_step
+    from oracle.unet import OracleUNet2D, UNetConfig
+    from parity_util import check_scalars, masked_update_cosine
+    f32 = mode == "f32"
+    eng = UNetEngine(UNet2DConfig.mnist_tshirt(), "cuda:0", dtype=torch.float32 if f32 else torch.bfloat16)
+    sd = eng.init_random(seed=13)
+    net = OracleUNet2D(UNetConfig.mnist_tshirt())
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(46)               # delete_tshirt.yaml:11 random_seed
+    B = 32
+    ac = S.alphas_cumprod()
+    okw = dict(lr=5e-5, betas=(0.95, 0.999), weight_decay=1e-6)
+    opt = torch.optim.AdamW(net.parameters(), **okw)
+    st = SISSStepper(eng, ac, scaling_norm=5.0, lambd=0.5, train_batch_size=B, inf_guard=True,
+                     mixed_precision=None if f32 else "bf16", **okw)
+    mb = dict(x0=torch.rand(B, 1, 28, 28, generator=g) * 2 - 1, a0=torch.rand(B, 1, 28, 28, generator=g) * 2 - 1,
+              noise=torch.randn(B, 1, 28, 28, generator=g), t=torch.randint(0, 1000, (B,), generator=g),
+              u=torch.rand(B, generator=g))
+    rb = mb if f32 else {k: (v.to(torch.bfloat16).float() if v.dtype == torch.float32 and k != "u" else v) for k, v in mb.items()}
+    r, _, _, gfin = unlearning_step(net, opt, OracleDeletionLoss(*S.gamma_sigma(ac)), "importance_sampling_with_mixture", ac,
+                                    [rb], train_batch_size=B, scaling_norm=5.0, loss_params={"lambd": 0.5}, inf_guard=True)
+    cast = (lambda v: v) if f32 else (lambda v: v.to(torch.bfloat16))
+    st.step(cast(mb["x0"]), cast(mb["a0"]), cast(mb["noise"]), mb["t"].cuda(), mb["u"])
+    got = st.stats()
+    check_scalars(r, got, tol=2e-4 if f32 else 5e-2)
+    cos, frac = masked_update_cosine(sd, dict(net.named_parameters()), eng.state_dict(), gfin)
+    print(f"\nconfigs[0] B=32 {mode}: " + ", ".join(f"{k} {got[k]:.6g} / {getattr(r, k):.6g}" for k in
+          ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm")) + f"; masked update cosine {cos:.6f}")
+    assert cos >= (0.9999 if f32 else 0.99) and frac > 0.3, (cos, frac)
+
+
 @pytest.mark.parametrize("lambd,B", [(0.0, 4), (1.0, 4), (0.5, 1), (0.3, 3)])
 def test_siss_step_edge_cases_match_oracle(setup, lambd, B):
     """Edges of the defensive mixture: lambd = 0 (every row keeps; iw_x = 1, the forget term still carries

@@ -451,3 +451,35 @@ def test_delete_sd_schedule_args_noise_offset_and_refusals(monkeypatch):
                     ("prediction_type=v_prediction", "prediction_type"), ("use_8bit_adam=true", "use_8bit_adam")):
         with pytest.raises(NotImplementedError, match=pat):
             DeleteSD(H.compose("delete_sd", cfgdir, [ov])).check_supported()
+
+
+def test_forced_collectives_on_a_one_rank_group_are_identities(monkeypatch):
+    """The test-only switch dp.FORCE_COLLECTIVES (used by tests/test_hip_rccl.py for RCCL's world-size-1 first contact): with one
+    rank the collectives are normally skipped; forced, they run on the backend and must return their input (gloo here)."""
+    import torch.distributed as dist
+    from siss_amd import dp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        t = torch.arange(64, dtype=torch.float32).view(2, 32).clone()
+        want = t.clone()
+        calls = []
+        orig = dist.all_reduce
+        monkeypatch.setattr(dist, "all_reduce", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        monkeypatch.setattr(dp, "FORCE_COLLECTIVES", False)
+        assert not dp.active() and dp.allreduce_pieces([t[0], t[1]]) is None and not dp.can_shard(32, 1)
+        dp.allreduce_flat_grads(t)
+        assert not calls
+        monkeypatch.setattr(dp, "FORCE_COLLECTIVES", True)
+        assert dp.active() and dp.can_shard(32, 1)
+        dp.allreduce_flat_grads(t)
+        w = dp.allreduce_pieces([t[0, 16:], t[1, 16:]], async_op=True)
+        w.wait()
+        assert len(calls) == 3 and torch.equal(t, want)
+        gx, ga, lo, hi = dp.reduce_scatter_param_shards(t)
+        assert (lo, hi) == (0, 32) and torch.equal(gx, want[0]) and torch.equal(ga, want[1])
+        flat = want[0].clone()
+        dp.all_gather_params(flat, lo, hi)
+        assert torch.equal(flat, want[0])
+    finally:
+        dist.destroy_process_group()
