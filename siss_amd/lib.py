@@ -94,6 +94,9 @@ SIGNATURES = {
     "siss_flash_attn_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, P],
     "siss_flash_attn_fwd_merged": [P, L, P, L, P, L, P, L, P, I, I, I, I, I, F, I, P],
     "siss_flash_attn_bwd_merged": [P, L, P, L, P, L, P, L, P, L, P, P, P, L, P, L, P, L, I, I, I, I, I, I, F, I, P],
+    "siss_attn1h_takes": [I, I],
+    "siss_attn1h_fwd": [P, P, P, L, P, L, I, P, I, I, I, F, P],
+    "siss_attn1h_bwd": [P, P, P, L, P, L, P, L, I, P, P, P, P, P, L, I, I, I, I, F, P],
     "siss_softmax_rows_fwd": [P, P, L, I, I, I, P],
     "siss_quick_gelu": [P, P, L, P],
     "siss_softmax_rows_bwd": [P, P, P, L, L, I, I, F, P],
@@ -144,7 +147,8 @@ _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_sc
 
 # siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
 KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "flash_attn_fwd": 2, "flash_attn_bwd": 3,
-              "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8, "flash_dkdv_qsplit": 9}
+              "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8, "flash_dkdv_qsplit": 9,
+              "attn1h_fwd": 10, "attn1h_bwd": 11}
 
 
 def dispatch_counts(reset=False):

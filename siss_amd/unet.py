@@ -175,6 +175,10 @@ class UNetEngine:
     group_rows = 280000
     group_max = 42
     group_attn = True      # ... the attention blocks' linears too
+    # Single-head attention sites (attention_head_dim = None: CelebA-HQ's six) as ONE fused kernel forward and two backward
+    # (csrc/attn1h.hip) between a fused q / k / v projection and to_out as a 1x1 convolution on the padded layout -- 9 launches per
+    # site and step where the materialised form (False) takes 26
+    fused_attn = True
 
     def __init__(self, cfg: UNet2DConfig, device="cuda", dtype=torch.bfloat16):
         """dtype = torch.float32: the f32 PARITY MODE (`mixed_precision: null` of the reference's YAMLs; csrc/f32_path.hip) -- every
@@ -254,8 +258,13 @@ class UNetEngine:
     def _declare_attn(self, pre, ch):
         a = self.ps.add
         a(f"{pre}.group_norm.weight", "vec", (ch,)); a(f"{pre}.group_norm.bias", "vec", (ch,))
-        for nm in ("to_q", "to_k", "to_v", "to_out.0"):
-            a(f"{pre}.{nm}.weight", "mat", (ch, ch)); a(f"{pre}.{nm}.bias", "vec", (ch,))
+        # the three projections' weights lie back to back in the flat buffers (one [3C][C] operand: ONE fused q / k / v product, one
+        # weight-gradient job, one three-panel dgrad over consecutive transposed copies), and so do their biases
+        for nm in ("to_q", "to_k", "to_v"):
+            a(f"{pre}.{nm}.weight", "mat", (ch, ch))
+        for nm in ("to_q", "to_k", "to_v"):
+            a(f"{pre}.{nm}.bias", "vec", (ch,))
+        a(f"{pre}.to_out.0.weight", "mat", (ch, ch)); a(f"{pre}.to_out.0.bias", "vec", (ch,))
 
     def _declare_params(self):
         cfg, a = self.cfg, self.ps.add
@@ -747,6 +756,9 @@ class UNetEngine:
         ps = self.ps
         C, B, S = x.c, x.n, x.h * x.w
         D = self.cfg.head_dim(C)
+        if (self.fused_attn and not self.f32 and D == C and x.w % 4 == 0 and not isinstance(x, ActView)
+                and lib.query("siss_attn1h_takes", S, C)):
+            return self._attention_fused(x, pre)
         small = D != C
         assert not small or D in (8, 16, 32), f"attention_head_dim {D} is not covered by the HIP kernels"
         scale = D ** -0.5
@@ -854,6 +866,69 @@ class UNetEngine:
             assert wk.data_ptr() == wq.data_ptr() + esz * C * C and wv.data_ptr() == wk.data_ptr() + esz * C * C
             ops.gemm_nt(lib.ptr(dqkv), C, wq, lib.ptr(dhn), C, rows2, C, C, [0, rows2, 2 * rows2], [0, 0, 0])
             dx = gn_b(dhn, accum=dout)        # residual path: d_out passes straight through
+            self._give(x, dx)
+        self.tape.append(bwd)
+        return out
+
+    def _attention_fused(self, x: Act, pre):
+        """The single-head attention block on the fused kernels (csrc/attn1h.hip):
+            GroupNorm (compact rows) -> ONE q / k / v projection [rows, 3C] -> siss_attn1h_fwd (o in the padded layout, LSE kept)
+            -> to_out as a 1x1 convolution whose epilogue adds the residual x;
+        backward: to_out's dgrad (+ its queued wgrad) -> siss_attn1h_bwd (dq | dk | dv into ONE [rows2, 3C] buffer) -> one wgrad job
+        (N = 3C) + one three-panel dgrad -> GroupNorm backward with the residual cotangent.  No S x S matrix, transpose, pad <->
+        compact copy or f32 dK / dV scratch exists."""
+        ps = self.ps
+        C, B, S = x.c, x.n, x.h * x.w
+        scale = float(C) ** -0.5
+        rows = B * S
+        nm = self._name(pre)
+        hn, gn_b = self.gn(x, pre + ".group_norm", False, compact_out=True)
+        sq, sk, sv = (ps.specs[pre + n] for n in (".to_q.weight", ".to_k.weight", ".to_v.weight"))
+        bq, bk, bv = (ps.specs[pre + n] for n in (".to_q.bias", ".to_k.bias", ".to_v.bias"))
+        assert sk.off == sq.off + C * C and sv.off == sk.off + C * C and bk.off == bq.off + C and bv.off == bk.off + C
+        qkv = self._buf(nm + ".qkv", (rows, 3 * C), self.adt)
+        lse = self._buf(nm + ".lse", (rows,))
+        ops.gemm_nt(lib.ptr(hn), C, ps.sh(pre + ".to_q.weight"), lib.ptr(qkv), 3 * C, rows, 3 * C, C, [0], [0],
+                    bias=ps.p(pre + ".to_q.bias"))
+        o = self._act(nm + ".o", B, x.h, x.w, C)         # halo rows are never written: they keep their zeros
+        lib.call("siss_attn1h_fwd", qkv, qkv[:, C:], qkv[:, 2 * C:], 3 * C, o.data, C, x.w, lse, B, S, C, scale)
+        out, out_b = self.conv(o, pre + ".to_out.0", ksize=1, residual=x)
+
+        def bwd():
+            nb, gb, ns, si = self.nb, self.gbase, self.nsets, self.set_images
+            rows2 = nb * S
+            dout = self._take(out)
+            do = out_b(dout)                            # to_out: weight / bias gradient (queued) and dgrad
+            grouped = bool(self.group_attn and self.group_rows)
+            # (a queued wgrad reads its cotangent operand long after this closure has returned: a buffer of the site's own then)
+            dqkv = self._buf((nm + ".bwd" if grouped else "attn") + ".dqkv", (rows2, 3 * C), self.adt)
+            delta = self._buf("attn.delta", (rows2,))
+            lib.call("siss_attn1h_bwd", qkv, qkv[:, C:], qkv[:, 2 * C:], 3 * C, o.data, C, do.data, C, x.w, lse, delta,
+                     dqkv, dqkv[:, C:], dqkv[:, 2 * C:], 3 * C, nb, B, S, C, scale)
+            self._put(do)
+            # [dWq ; dWk ; dWv] = dqkv^T hn and the three bias gradients: ONE product with N = 3C
+            dW = ps.grads[gb:, sq.off:]
+            zp = ops.zero_page(self.device)
+            xsr = si * S if B == nb else 0
+            if grouped:
+                z9 = (lib.I * 9)(*([0] * 9))
+                self._wq.append((lib.TNJob(Y=dqkv.data_ptr(), ldy=3 * C, X=hn.data_ptr(), ldx=C, dW=dW.data_ptr(),
+                                           set_stride=ps.total, N=3 * C, C=C, npanels=1, nsets=ns, rows_per_set=si * S,
+                                           row_begin=0, row_end=si * S, nsplits=0, x_set_rows=xsr, zero_page=zp.data_ptr(),
+                                           dbias=ps.g(pre + ".to_q.bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
+                                 (dqkv, hn)))
+                if len(self._wq) >= self.group_max:
+                    self._flush_wgrads()
+            else:
+                lib.call("siss_gemm_tn", dqkv, 3 * C, hn, C, dW, ps.total, 3 * C, C, 1, lib.int_array([0]), lib.int_array([0]),
+                         ns, si * S, xsr, 0, si * S, 0, zp, ps.g(pre + ".to_q.bias", gb), None)
+            # dhn = dq Wq + dk Wk + dv Wv: three panels (column windows of dqkv) against the three consecutive transposed copies
+            wq, wk, wv = (self.wT[pre + n + ".weight"] for n in (".to_q", ".to_k", ".to_v"))
+            esz = wq.element_size()
+            assert wk.data_ptr() == wq.data_ptr() + esz * C * C and wv.data_ptr() == wk.data_ptr() + esz * C * C
+            dhn = self._buf("attn.dhn", (rows2, C), self.adt)
+            ops.gemm_nt(lib.ptr(dqkv), 3 * C, wq, lib.ptr(dhn), C, rows2, C, C, [0, 0, 0], [0, C, 2 * C])
+            dx = gn_b(dhn, accum=dout)                  # residual path: d_out passes straight through
             self._give(x, dx)
         self.tape.append(bwd)
         return out
