@@ -36,6 +36,7 @@
 namespace {
 
 constexpr int kThreadsA = 256;
+constexpr int kPipe = 8;                 // MFMAs per block of the software pipeline below
 
 // compile-time loop: the tile index selects the phase (which product, which register arrays), so every iteration is its own code
 template <int I, int N, typename F>
@@ -61,6 +62,28 @@ template <int D> struct AT {
     __device__ static __forceinline__ int swz(int row) { return (row & 7) << 1; }
     __device__ static __forceinline__ int off(int row, int chunk) { return row * RS + ((chunk ^ swz(row)) << 4); }
 };
+
+// N MFMAs whose LDS fragment (ld(i): one ds_read_b128 or two transposed reads) is fetched kPipe MFMAs AHEAD of its use: block b + 1's
+// reads are issued one behind each MFMA of block b, into the other half of a double fragment buffer, pinned by a scheduling fence
+// per pair.  A wave is alone on its SIMD here (one 4-wave block per CU): left to the compiler every MFMA waited for its own read
+// (ds_read; s_waitcnt lgkmcnt(0); v_mfma -- an LDS round trip of ~120 cycles per 16-cycle MFMA: measured 46 us per backward kernel
+// at S = 256, D = 512 where the MFMAs are 8 us).  i is a compile-time index (std::integral_constant).
+template <int N, typename Ld, typename Mm>
+__device__ __forceinline__ void pipe(Ld&& ld, Mm&& mm) {
+    constexpr int G = kPipe;
+    static_assert(N % G == 0, "whole blocks");
+    bf16x8_t f[2][G];
+    static_for<0, G>([&](auto ic) { f[0][decltype(ic)::value] = ld(ic); });
+    static_for<0, N / G>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        static_for<0, G>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            mm(std::integral_constant<int, b * G + i>{}, f[b & 1][i]);
+            if constexpr (b + 1 < N / G) f[(b + 1) & 1][i] = ld(std::integral_constant<int, (b + 1) * G + i>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+}
 
 // token s of image n -> row of the tensor: compact (wp == 0: n * S + s) or padded NHWC with a one-pixel halo
 struct RowMap { long rpi; int W, wp; };
@@ -195,10 +218,11 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_fwd_kernel(const bf16_t* __r
         if constexpr (t + 1 < 2 * NS)
             stage<D>(L, t + 1 < NS ? k : v, ld, cm, n, ((t + 1) % NS) * 64, S, lb, (t + 1) & 1, wave);
         if constexpr (t < NS) {
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                for (int ks = 0; ks < A::KS; ++ks) sT[t * 4 + sub] = mfma(frag_rm<D>(L, t & 1, sub, ks), qf[ks], sT[t * 4 + sub]);
+            pipe<4 * A::KS>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_rm<D>(L, t & 1, i / A::KS, i % A::KS); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                sT[t * 4 + i / A::KS] = mfma(f, qf[i % A::KS], sT[t * 4 + i / A::KS]);
+                            });
             if constexpr (t == NS - 1) {
                 float mx = -INFINITY;
 #pragma unroll
@@ -222,10 +246,11 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_fwd_kernel(const bf16_t* __r
             }
         } else {
             constexpr int c2 = t - NS;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int dt = 0; dt < A::DT; ++dt) oT[dt] = mfma(frag_tr<D>(L, t & 1, j, dt), pf[c2 * 2 + j], oT[dt]);
+            pipe<2 * A::DT>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_tr<D>(L, t & 1, i / A::DT, i % A::DT); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                oT[i % A::DT] = mfma(f, pf[c2 * 2 + i / A::DT], oT[i % A::DT]);
+                            });
         }
     });
     store_rows<D>(o + tok_row(om, n, qs, S) * ldo, oT, 1.f, lane);
@@ -273,10 +298,11 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_bwd_dq_kernel(const bf16_t* 
         }
         constexpr int c2 = t % NS;
         if constexpr (t < NS) {                       // S^T = K Q^T
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                for (int ks = 0; ks < A::KS; ++ks) sT[t * 4 + sub] = mfma(frag_rm<D>(L, t & 1, sub, ks), qf[ks], sT[t * 4 + sub]);
+            pipe<4 * A::KS>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_rm<D>(L, t & 1, i / A::KS, i % A::KS); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                sT[t * 4 + i / A::KS] = mfma(f, qf[i % A::KS], sT[t * 4 + i / A::KS]);
+                            });
             if constexpr (t == NS - 1) {
 #pragma unroll
                 for (int i = 0; i < NS * 4; ++i)
@@ -298,14 +324,18 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_bwd_dq_kernel(const bf16_t* 
                 dl = group_sum(dl);
                 if (lane < 16) delta[(long)z * S + qs] = dl;
             }
+            f32x4_t dp[4];
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                f32x4_t dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int sub = 0; sub < 4; ++sub) dp[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            pipe<4 * A::KS>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_rm<D>(L, t & 1, i / A::KS, i % A::KS); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                dp[i / A::KS] = mfma(f, dof[i % A::KS], dp[i / A::KS]);
+                            });
 #pragma unroll
-                for (int ks = 0; ks < A::KS; ++ks) dp = mfma(frag_rm<D>(L, t & 1, sub, ks), dof[ks], dp);
+            for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sT[c2 * 4 + sub][r] *= (dp[r] - dl) * scale;
-            }
+                for (int r = 0; r < 4; ++r) sT[c2 * 4 + sub][r] *= (dp[sub][r] - dl) * scale;
 #pragma unroll
             for (int j = 0; j < 2; ++j) dsf[c2 * 2 + j] = pack_pair(sT[c2 * 4 + 2 * j], sT[c2 * 4 + 2 * j + 1]);
         } else {                            // dQ^T += K^T dS^T
@@ -313,10 +343,11 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_bwd_dq_kernel(const bf16_t* 
 #pragma unroll
                 for (int i = 0; i < A::DT; ++i) dqT[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int dt = 0; dt < A::DT; ++dt) dqT[dt] = mfma(frag_tr<D>(L, t & 1, j, dt), dsf[c2 * 2 + j], dqT[dt]);
+            pipe<2 * A::DT>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_tr<D>(L, t & 1, i / A::DT, i % A::DT); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                dqT[i % A::DT] = mfma(f, dsf[c2 * 2 + i / A::DT], dqT[i % A::DT]);
+                            });
         }
     });
     store_rows<D>(dq + ((long)z * S + qs) * ldd, dqT, 1.f, lane);
@@ -362,16 +393,21 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_bwd_dkv_kernel(const bf16_t*
         }
         constexpr int c2 = t % NS;
         if constexpr (t < NS) {                       // S = Q K^T;  P = exp2(c S - lse[q])
-            f32x4_t p[4];
+            f32x4_t p[4], l4[4];
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-                f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < A::KS; ++ks) s = mfma(frag_rm<D>(L, t & 1, sub, ks), kv[ks], s);
-                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lrow + c2 * 64 + sub * 16);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[sub][r] = __builtin_amdgcn_exp2f(s[r] * c - l4[r]);
+                p[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                l4[sub] = *reinterpret_cast<const f32x4_t*>(lrow + c2 * 64 + sub * 16);
             }
+            pipe<4 * A::KS>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_rm<D>(L, t & 1, i / A::KS, i % A::KS); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                p[i / A::KS] = mfma(f, kv[i % A::KS], p[i / A::KS]);
+                            });
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[sub][r] = __builtin_amdgcn_exp2f(p[sub][r] * c - l4[sub][r]);
             pf[c2 * 2] = pack_pair(p[0], p[1]);
             pf[c2 * 2 + 1] = pack_pair(p[2], p[3]);
         } else if constexpr (t < 2 * NS) {            // dV^T += dO^T P;  dP = dO V^T;  dS = scale P o (dP - delta[q])
@@ -382,20 +418,27 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_bwd_dkv_kernel(const bf16_t*
 #pragma unroll
                 for (int i = 0; i < A::DT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int dt = 0; dt < A::DT; ++dt) acc[dt] = mfma(frag_tr<D>(L, t & 1, j, dt), pf[c2 * 2 + j], acc[dt]);
-            f32x4_t ds[4];
+            f32x4_t ds[4], d4[4];
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-                f32x4_t dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                ds[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                d4[sub] = *reinterpret_cast<const f32x4_t*>(drow + c2 * 64 + sub * 16);
+            }
+            pipe<2 * A::DT>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_tr<D>(L, t & 1, i / A::DT, i % A::DT); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                acc[i % A::DT] = mfma(f, pf[c2 * 2 + i / A::DT], acc[i % A::DT]);
+                            });
+            pipe<4 * A::KS>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_rm<D>(L, t & 1, i / A::KS, i % A::KS); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                ds[i / A::KS] = mfma(f, kv[i % A::KS], ds[i / A::KS]);
+                            });
 #pragma unroll
-                for (int ks = 0; ks < A::KS; ++ks) dp = mfma(frag_rm<D>(L, t & 1, sub, ks), kv[ks], dp);
-                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(drow + c2 * 64 + sub * 16);
+            for (int sub = 0; sub < 4; ++sub) {
                 const bf16x8_t pp = pf[c2 * 2 + (sub >> 1)];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ds[sub][r] = bf2f((bf16_t)pp[(sub & 1) * 4 + r]) * (dp[r] - d4[r]) * scale;
+                for (int r = 0; r < 4; ++r) ds[sub][r] = bf2f((bf16_t)pp[(sub & 1) * 4 + r]) * (ds[sub][r] - d4[sub][r]) * scale;
             }
             dsf[c2 * 2] = pack_pair(ds[0], ds[1]);
             dsf[c2 * 2 + 1] = pack_pair(ds[2], ds[3]);
@@ -405,10 +448,11 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_bwd_dkv_kernel(const bf16_t*
                 for (int i = 0; i < A::DT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
         } else {                            // dK^T += Q^T dS
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int dt = 0; dt < A::DT; ++dt) acc[dt] = mfma(frag_tr<D>(L, t & 1, j, dt), dsf[c2 * 2 + j], acc[dt]);
+            pipe<2 * A::DT>([&](auto ic) { constexpr int i = decltype(ic)::value; return frag_tr<D>(L, t & 1, i / A::DT, i % A::DT); },
+                            [&](auto ic, const bf16x8_t& f) {
+                                constexpr int i = decltype(ic)::value;
+                                acc[i % A::DT] = mfma(f, dsf[c2 * 2 + i / A::DT], acc[i % A::DT]);
+                            });
         }
     });
     store_rows<D>(dk + ((long)z * S + key) * ldd, acc, 1.f, lane);

@@ -69,11 +69,14 @@ struct TCfg {
 
 // The whole product of one block.  bid / nwg: the block's index and the block count of ITS launch -- or, in a grouped launch
 // (gemm_tn_grouped_kernel), of its job.
-template <int TAPS, bool ILV = false>
-__device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nwg, char* smem) {
+// tid: the thread's index within ITS (virtual) block -- threadIdx.x, or threadIdx.x & 255 for the one-tap halves of a 512-thread block of
+// the mixed kernel.  PAIRED (one-tap body only): two virtual blocks share a workgroup, hence its barriers -- every block then runs
+// the SAME number of barriers (the full split's step count; the steps it does not have are barrier-only) and never returns early.
+template <int TAPS, bool ILV = false, bool PAIRED = false>
+__device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nwg, char* smem, const int tid) {
     using C_ = TCfg<TAPS, ILV>;
     constexpr int NP = C_::kPieces, CT = C_::kCT;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = TAPS == 3 ? w >> 2 : w >> 1, wc = TAPS == 3 ? w & 3 : w & 1;   // wave tile 64(n) x (CT*16)(c)
     // Grid is 1-D.  Logical order: panel group fastest, then tile, then split, then set -- and each XCD
@@ -94,8 +97,8 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
     const int n0 = tn * BN, c0 = tc * BC;
     const int r0 = p.row_begin + split * p.rows_per_split;
     int r1 = r0 + p.rows_per_split; r1 = r1 < p.row_end ? r1 : p.row_end;
-    if (r0 >= r1) return;
-    const int steps = (r1 - r0 + BR - 1) / BR;
+    if (!PAIRED && r0 >= r1) return;
+    const int steps = r0 < r1 ? (r1 - r0 + BR - 1) / BR : 0;
 
     // staging: 4 pieces of 4 rows (256 B each) per wave and operand (+ one extra X piece on wave 0)
     const bf16_t* ysrc[NP];
@@ -437,10 +440,19 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
                 for (int t = 0; t < TAPS; ++t) mma_tap(yf, xf, t);
             }
         };
-        stage(0, 0);
+        if (steps > 0) stage(0, 0);
         for (int s = 0; s < steps; s += 2) {
             one(std::integral_constant<int, 0>{}, s);
             if (s + 1 < steps) one(std::integral_constant<int, 1>{}, s + 1);
+        }
+        if constexpr (PAIRED) {
+            // the other virtual block of this workgroup may have more steps (only the last split is short): keep its barriers company
+            const int all = p.rows_per_split / BR;
+            for (int s = steps; s < all; ++s) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (steps == 0) return;
         }
     }
 
@@ -506,7 +518,7 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
 template <int TAPS, bool ILV = false>
 __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_kernel(const TNParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    tn_body<TAPS, ILV>(p, blockIdx.x, gridDim.x, smem);
+    tn_body<TAPS, ILV>(p, blockIdx.x, gridDim.x, smem, threadIdx.x);
 }
 
 // Several independent products in ONE launch (the low-resolution weight gradients: each of them alone leaves most CUs idle
@@ -528,7 +540,30 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_grouped_kerne
     while (j + 1 < g.njobs && (int)blockIdx.x >= g.first[j + 1]) ++j;
     const int bid = blockIdx.x - g.first[j];
     if (bid >= g.nwg[j]) return;
-    tn_body<TAPS, TAPS == 3>(g.job[j], bid, g.nwg[j], smem);      // 3 taps: the interleaved variant (4-deep ring)
+    tn_body<TAPS, TAPS == 3>(g.job[j], bid, g.nwg[j], smem, threadIdx.x);      // 3 taps: the interleaved variant (4-deep ring)
+}
+
+// A fused 3-tap product and a one-tap product in ONE launch of one round of blocks (siss_gemm_tn_pair): blocks [0, n3) run the 3-tap
+// body, each of the nphys1 blocks behind them runs TWO virtual one-tap blocks (waves 0-3 and 4-7, a 64-KiB half of the LDS each:
+// the residency the one-tap kernel has on its own, two 256-thread blocks per CU).  Why: a one-tap weight gradient at 256 x 256
+// (a resnet's 1x1 conv_shortcut: 545 MB of cotangent + 545 MB of input for 140 GFLOP) is HBM-bound when launched alone (263 us
+// at 522 TF/s); beside MFMA-bound 3-tap blocks it streams while they compute.
+struct TNPair {
+    TNParams j3, j1;
+    int n3, nphys1;
+};
+static_assert(sizeof(TNPair) <= 4096, "kernel arguments are limited to 4 KiB");
+
+__global__ __launch_bounds__(TCfg<3>::kThreads, 2) void gemm_tn_mixed_kernel(const TNPair g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (b < g.n3) {
+        tn_body<3, true>(g.j3, b, g.n3, smem, threadIdx.x);
+    } else {
+        const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+        // virtual block index lb + half * nphys1: nphys1 and n3 are multiples of 8, so it keeps the physical block's XCD (index mod 8)
+        tn_body<1, false, true>(g.j1, (b - g.n3) + half * g.nphys1, 2 * g.nphys1, smem + half * TCfg<1>::kSmemBytes, threadIdx.x & 255);
+    }
 }
 
 template <int TAPS>
@@ -705,6 +740,69 @@ int siss_gemm_tn_bs(const void* Y, long ldy, const void* X, long ldx, float* dW,
     p.bias_stride = bias_set_stride;
     if (fused3) return launch_tn<3>(p, (hipStream_t)stream);
     return launch_tn<1>(p, (hipStream_t)stream);
+}
+
+// Balance of siss_gemm_tn_pair: relative cost of a 64-row K-step of a one-tap virtual block against a 3-tap block's (permille;
+// 0 = the built-in default).  A tuning knob for tools/probes and the A/B harness, per process.
+static int g_pair_cost_permille = 0;
+int siss_gemm_tn_set_pair_cost(int permille) {
+    if (permille >= 0) g_pair_cost_permille = permille;
+    return g_pair_cost_permille;
+}
+
+// ONE launch, ONE round of blocks for two weight-gradient products: `job3` whose panels are 3x3 filter rows (the fused 3-tap
+// kernel's shape) and `job1`, a one-panel (1x1 convolution / linear) product -- e.g. a resnet's conv2 and its conv_shortcut, which
+// reduce over the same cotangent.  Both are split over row ranges so that together they fill `max_blocks` workgroups (0: one per CU)
+// and end at about the same time; partial tiles are added with float atomics (dW must hold the running sum).  jobs: siss_tn_job
+// records (nsplits is ignored).  Returns 1 (bad argument) when the shapes are not (3-tap, one-panel): launch them separately then.
+int siss_gemm_tn_pair(const void* job3, const void* job1, int max_blocks, void* stream) {
+    SISS_CHECK_ARG(job3 && job1 && max_blocks >= 0);
+    const siss_tn_job& a = *(const siss_tn_job*)job3;
+    const siss_tn_job& b = *(const siss_tn_job*)job1;
+    SISS_CHECK_ARG(a.npanels % 3 == 0 && b.npanels == 1);
+    int maxb = max_blocks;
+    if (maxb == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return SISS_ERR_LAUNCH;
+        maxb = cus;
+    }
+    SISS_CHECK_ARG(maxb >= 16);
+    // blocks: 3-tap  base3 * s3 (rounded up to 8), one-tap ceil(base1 * s1 / 2) rounded up to 8; K-steps per block rows / (64 s)
+    const long base3 = (long)cdiv(a.N, BN) * cdiv(a.C, BC) * (a.npanels / 3) * a.nsets;
+    const long base1 = (long)cdiv(b.N, BN) * cdiv(b.C, BC) * b.nsets;
+    const int rows3 = a.row_end - a.row_begin, rows1 = b.row_end - b.row_begin;
+    SISS_CHECK_ARG(rows3 > 0 && rows1 > 0);
+    const double c1 = (g_pair_cost_permille ? g_pair_cost_permille : 600) / 1000.0;    // one-tap K-step (two virtual blocks per CU) / 3-tap K-step
+    double best = 1e30;
+    int s3 = 0, s1 = 0;
+    for (int t1 = 1; t1 <= 4096; ++t1) {
+        const long phys1 = ((base1 * t1 + 1) / 2 + 7) & ~7L;
+        if (phys1 >= maxb) break;
+        const long t3 = ((maxb - phys1) & ~7L) / base3;
+        if (t3 < 1) break;
+        const double cost = std::max((double)cdiv(cdiv(rows3, (int)t3), BR), c1 * cdiv(cdiv(rows1, t1), BR));
+        if (cost < best) { best = cost; s3 = (int)t3; s1 = t1; }
+    }
+    SISS_CHECK_ARG(s3 >= 1 && s1 >= 1);
+    TNPair g;
+    bool f3 = false, f1 = false;
+    int rc = tn_setup(a.Y, a.ldy, a.X, a.ldx, a.dW, a.set_stride, a.N, a.C, a.npanels, a.shifts, a.coffs, a.nsets, a.rows_per_set,
+                      a.x_set_rows, a.row_begin, a.row_end, s3, a.zero_page, a.dbias, a.dbias2, false, g.j3, f3);
+    if (rc != SISS_OK) return rc;
+    rc = tn_setup(b.Y, b.ldy, b.X, b.ldx, b.dW, b.set_stride, b.N, b.C, b.npanels, b.shifts, b.coffs, b.nsets, b.rows_per_set,
+                  b.x_set_rows, b.row_begin, b.row_end, s1, b.zero_page, b.dbias, b.dbias2, false, g.j1, f1);
+    if (rc != SISS_OK) return rc;
+    SISS_CHECK_ARG(f3 && !f1);
+    g.n3 = (int)((base3 * s3 + 7) & ~7L);
+    g.nphys1 = (int)(((base1 * s1 + 1) / 2 + 7) & ~7L);
+    static unsigned char attr_set[kMaxDevices];
+    constexpr int smem = TCfg<3, true>::kSmemBytes > 2 * TCfg<1>::kSmemBytes ? TCfg<3, true>::kSmemBytes : 2 * TCfg<1>::kSmemBytes;
+    if (siss_ensure_smem((const void*)gemm_tn_mixed_kernel, smem, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    siss_count_dispatch(SISS_K_TN3);
+    siss_count_dispatch(SISS_K_TN1);
+    siss_count_dispatch(SISS_K_TN_PAIR);
+    gemm_tn_mixed_kernel<<<dim3(g.n3 + g.nphys1), TCfg<3>::kThreads, smem, (hipStream_t)stream>>>(g);
+    SISS_LAUNCH_RET();
 }
 
 // The same product for `njobs` independent problems in ONE launch per kernel variant (job table passed by value as kernel

@@ -54,6 +54,8 @@ SIGNATURES = {
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gemm_tn_bs": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, L, P],
     "siss_gemm_tn_grouped": [P, I, P],
+    "siss_gemm_tn_pair": [P, P, I, P],
+    "siss_gemm_tn_set_pair_cost": [I],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_set_slab": [I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
@@ -148,7 +150,7 @@ _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_sc
 # siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
 KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "flash_attn_fwd": 2, "flash_attn_bwd": 3,
               "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8, "flash_dkdv_qsplit": 9,
-              "attn1h_fwd": 10, "attn1h_bwd": 11}
+              "attn1h_fwd": 10, "attn1h_bwd": 11, "gemm_tn_pair": 12}
 
 
 def dispatch_counts(reset=False):
@@ -262,6 +264,13 @@ def _work(name, a):
     if name == "siss_gemm_tn_grouped":
         return sum(_work("siss_gemm_tn", [None] * 6 + [j.N, j.C, j.npanels, None, None, j.nsets, j.rows_per_set, None,
                                                        j.row_begin, j.row_end]) for j in a[0])
+    if name == "siss_gemm_tn_pair":     # (byref(job3), byref(job1), max_blocks): both products
+        return sum(_work("siss_gemm_tn", [None] * 6 + [j.N, j.C, j.npanels, None, None, j.nsets, j.rows_per_set, None,
+                                                       j.row_begin, j.row_end]) for j in (a[0]._obj, a[1]._obj))
+    if name == "siss_attn1h_fwd":       # QK^T and PV: 2 products of 2 B S S D
+        return 2.0 * 2 * a[8] * a[9] * a[9] * a[10]
+    if name == "siss_attn1h_bwd":       # algorithmic: S, dP, dQ, dK, dV over the nb cotangent images (7 products run: S and dP twice)
+        return 2.0 * 5 * a[15] * a[17] * a[17] * a[18]
     if name == "siss_gemm_nt_mulsub":   # 2 * M * N * Kp * batch
         return 2.0 * a[8] * a[9] * a[10] * a[12]
     if name == "siss_flash_attn_fwd":   # QK^T and PV over the VALID keys (padded queries / head dim counted as laid out)
@@ -304,6 +313,11 @@ def _shape_key(name, a):
         return ("M", a[11], "N", a[12], "K", a[13], "panels", 9, "+1x1 N", a[10])
     if name == "siss_gemm_tn":
         return ("N", a[6], "C", a[7], "panels", a[8], "sets", a[11], "rows", a[15] - a[14], "splits", a[16])
+    if name == "siss_gemm_tn_pair":
+        j3, j1 = a[0]._obj, a[1]._obj
+        return ("N", j3.N, "C", j3.C, "panels", j3.npanels, "+ N", j1.N, "C", j1.C, "panels", j1.npanels, "rows", j3.row_end - j3.row_begin)
+    if name in ("siss_attn1h_fwd", "siss_attn1h_bwd"):
+        return ("B", a[8] if name.endswith("fwd") else a[15], "S", a[9] if name.endswith("fwd") else a[17], "D", a[10] if name.endswith("fwd") else a[18])
     if name in ("siss_groupnorm_fwd", "siss_groupnorm_fwd_ld"):
         return ("n", a[7], "H", a[8], "C", a[10])
     if name in ("siss_groupnorm_bwd", "siss_groupnorm_bwd_ld", "siss_groupnorm_bwd_ld_s2d"):
@@ -339,6 +353,8 @@ def kernel_symbol(name, a):
         return "gemm_nt_kernel"
     if name == "siss_gemm_tn_grouped":
         return "gemm_tn_grouped_kernel"
+    if name == "siss_gemm_tn_pair":
+        return "gemm_tn_mixed_kernel"
     if name == "siss_gemm_tn":
         rows = a[15] - a[14]
         return "gemm_tn_kernel<3>" if triples(a[9], a[10], a[8]) and (a[16] > 0 or rows >= 8192) else "gemm_tn_kernel<1>"

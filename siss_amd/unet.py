@@ -179,6 +179,11 @@ class UNetEngine:
     # (csrc/attn1h.hip) between a fused q / k / v projection and to_out as a 1x1 convolution on the padded layout -- 9 launches per
     # site and step where the materialised form (False) takes 26
     fused_attn = True
+    # One-panel weight gradients at the TOP resolution (a resnet's 1x1 conv_shortcut, conv_out, conv_in: HBM-bound launches at
+    # 200-520 TF/s) wait for the next fused 3-tap weight gradient and ride in ITS launch (siss_gemm_tn_pair: one round of blocks
+    # shared by the two products; the streaming one-tap blocks run beside MFMA-bound 3-tap blocks)
+    pair_top = True
+    pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
     def __init__(self, cfg: UNet2DConfig, device="cuda", dtype=torch.bfloat16):
         """dtype = torch.float32: the f32 PARITY MODE (`mixed_precision: null` of the reference's YAMLs; csrc/f32_path.hip) -- every
@@ -210,6 +215,7 @@ class UNetEngine:
         self._uid = 0
         self.on_early_grads_final = None
         self._wq, self._held, self._held_release = [], {}, []
+        self._pair1 = []
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -430,9 +436,24 @@ class UNetEngine:
             jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
             lib.call("siss_gemm_tn_grouped", jobs, len(self._wq))
             self._wq = []
+        for job, _ in self._pair1:                      # one-panel top-resolution products that found no 3-tap partner: on their own
+            self._launch_tn_job(job)
+        self._pair1 = []
         self._held = {}
         rel, self._held_release = self._held_release, []
         for a in rel:
+            self._put(a)
+
+    def _launch_tn_job(self, job):
+        lib.call("siss_gemm_tn", job.Y, job.ldy, job.X, job.ldx, job.dW, job.set_stride, job.N, job.C, job.npanels,
+                 lib.int_array(list(job.shifts)[:job.npanels]), lib.int_array(list(job.coffs)[:job.npanels]), job.nsets,
+                 job.rows_per_set, job.x_set_rows, job.row_begin, job.row_end, 0, job.zero_page, job.dbias, job.dbias2)
+
+    def _unhold(self, dy):
+        """A queued product that read `dy` has been launched: give the buffer back if its owner already released it."""
+        self._held.pop(id(dy.buf), None)
+        for a in [a for a in self._held_release if a.buf is dy.buf]:
+            self._held_release.remove(a)
             self._put(a)
 
     def _put(self, a):
@@ -581,14 +602,15 @@ class UNetEngine:
             else:
                 ops.conv_fprop(x, w, y, bias=ps.p(pre + ".bias"), rowbias=rowbias, residual=residual, ksize=ksize, ldrb=ldrb)
 
-        def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None, sc_dgrad=None):
+        def bwd(dy: Act, need_dx=True, accum: Act = None, bias_grad=True, bias_grad2=None, sc_dgrad=None, wgrad=True):
             """sc_dgrad = (pre2, c2, get_out2): also form the dgrad of the 1x1 convolution `pre2` (c2 input channels) over the SAME
             cotangent into get_out2() -- inside this 3x3 dgrad when its kernel takes it (returns (dx, out2)), else not at all (returns
-            (dx, None): the caller runs it, and no buffer was taken)."""
-            dW = ps.grads[self.gbase:, ps.specs[pre + ".weight"].off:]
-            # the bias gradient (column sums of dy) rides along in the wgrad GEMM as one more product
-            self._wgrad(dy, x, dW, co, x.c, ksize, dbias=ps.g(pre + ".bias", self.gbase) if bias_grad else None,
-                        dbias2=bias_grad2)
+            (dx, None): the caller runs it, and no buffer was taken).  wgrad=False: the weight gradient has been taken already."""
+            if wgrad:
+                dW = ps.grads[self.gbase:, ps.specs[pre + ".weight"].off:]
+                # the bias gradient (column sums of dy) rides along in the wgrad GEMM as one more product
+                self._wgrad(dy, x, dW, co, x.c, ksize, dbias=ps.g(pre + ".bias", self.gbase) if bias_grad else None,
+                            dbias2=bias_grad2)
             if not need_dx:
                 return None
             if accum is not None:
@@ -640,6 +662,23 @@ class UNetEngine:
             self._held[id(dy.buf)] = dy
             if len(self._wq) >= self.group_max:
                 self._flush_wgrads()
+            return
+        if (self.pair_top and not self.f32 and isinstance(dy, Act) and re - rb >= self.pair_min_rows
+                and (t == 1 or (ops.is_conv3_panels(shifts, coffs) and self._pair1))):
+            job = lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
+                            dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
+                            rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=0, x_set_rows=x_set_rows,
+                            zero_page=zp.data_ptr(), dbias=dbias.data_ptr() if dbias is not None else None,
+                            dbias2=dbias2.data_ptr() if dbias2 is not None else None,
+                            shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t))))
+            if t == 1:                                  # waits for the next 3-tap product (or the end of the backward pass)
+                self._pair1.append((job, dy))
+                self._held[id(dy.buf)] = dy
+                return
+            j1, dy1 = self._pair1.pop(0)
+            lib.call("siss_gemm_tn_pair", lib.C.byref(job), lib.C.byref(j1), 0)
+            if not any(d is dy1 for _, d in self._pair1):
+                self._unhold(dy1)
             return
         lib.call("siss_gemm_tn", dy.data, dy.c, x.data, ldx or getattr(x, "ld", x.c), dW_view, ps.total, co, ci, t,
                  sh, cf, nsets, rows_per_set, x_set_rows, rb, re, ns, zp, dbias, dbias2)
@@ -707,6 +746,9 @@ class UNetEngine:
             # (dout . W_sc, HBM-bound on its own) rides in conv2's 3x3 dgrad over the same cotangent where that kernel takes it
             acc_sc = None
             if has_sc:
+                # the shortcut's weight gradient first: it reduces over the same cotangent as conv2's, and at the top resolution it is
+                # queued for the NEXT 3-tap weight-gradient launch -- conv2's, two lines down (pair_top)
+                sc_b(dout, bias_grad=False, need_dx=False)
                 da2, acc_sc = c2_b(dout, bias_grad2=ps.g(pre + ".conv_shortcut.bias", gb),
                                    sc_dgrad=(pre + ".conv_shortcut", x.c, lambda: self._get(nb, x.h, x.w, x.c)))
             else:
@@ -719,11 +761,7 @@ class UNetEngine:
             self._put(dh)
             prior = self.gmap.pop(id(x), None)          # cotangent x already received from another consumer
             if has_sc:
-                if acc_sc is not None:
-                    sc_b(dout, bias_grad=False, need_dx=False)      # the shortcut's weight gradient only
-                    acc = acc_sc
-                else:
-                    acc = sc_b(dout, bias_grad=False)
+                acc = acc_sc if acc_sc is not None else sc_b(dout, bias_grad=False, wgrad=False)    # (dgrad only: see above)
                 self._put(dout)
             else:
                 acc = dout
@@ -1140,6 +1178,7 @@ class UNetEngine:
         assert cin == cfg.in_channels
         self.tape, self.gmap, self._uid = [], {}, 0
         self._wq, self._held, self._held_release = [], {}, []
+        self._pair1 = []
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
@@ -1243,9 +1282,19 @@ class UNetEngine:
             rows_per_set = self.set_images * col.rows_per_image
             rb, re = col.wp + 1, rows_per_set - (col.wp + 1)
             ns = ops._nsplits(1, 1, self.nsets, re - rb, False)
-            lib.call("siss_gemm_tn", col.data, kc, a.data, c0, ps.grads[gb:, ps.specs["conv_out.weight"].off:], ps.total,
-                     9 * co, c0, 1, lib.int_array([0]), lib.int_array([0]), self.nsets, rows_per_set,
-                     rows_per_set if a.n == nb else 0, rb, re, ns, ops.zero_page(self.device), None, None)
+            if self.pair_top and not self.f32 and re - rb >= self.pair_min_rows:
+                zp = ops.zero_page(self.device)
+                z9 = (lib.I * 9)(*([0] * 9))
+                self._pair1.append((lib.TNJob(Y=col.data.data_ptr(), ldy=kc, X=a.data.data_ptr(), ldx=c0,
+                                              dW=ps.grads[gb:, ps.specs["conv_out.weight"].off:].data_ptr(), set_stride=ps.total,
+                                              N=9 * co, C=c0, npanels=1, nsets=self.nsets, rows_per_set=rows_per_set, row_begin=rb,
+                                              row_end=re, nsplits=0, x_set_rows=rows_per_set if a.n == nb else 0,
+                                              zero_page=zp.data_ptr(), dbias=None, dbias2=None, shifts=z9, coffs=z9), col))
+                self._held[id(col.buf)] = col
+            else:
+                lib.call("siss_gemm_tn", col.data, kc, a.data, c0, ps.grads[gb:, ps.specs["conv_out.weight"].off:], ps.total,
+                         9 * co, c0, 1, lib.int_array([0]), lib.int_array([0]), self.nsets, rows_per_set,
+                         rows_per_set if a.n == nb else 0, rb, re, ns, ops.zero_page(self.device), None, None)
             da = self._get(nb, H, W, c0)
             ops.gemm_nt(lib.ptr(col.data), kc, self._wd_out, lib.ptr(da.data), c0, col.rows, c0, kc, [0], [0],
                         rows_per_image=col.rows_per_image, hp=col.hp, wp=col.wp)

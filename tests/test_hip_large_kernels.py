@@ -432,3 +432,56 @@ def test_grouped_weight_gradient_launch_equals_single_launches(dev):
     for grouped, single in outs:
         assert float(single.abs().max()) > 0
         _close(grouped.cpu(), single.cpu(), 1e-5, "grouped vs single")
+
+
+@pytest.mark.parametrize("n,hw,ci,co,c2,n1,blocks", [(4, 64, 128, 128, 256, 128, 0), (2, 48, 256, 128, 128, 27, 64), (3, 40, 128, 256, 64, 256, 40)])
+def test_paired_weight_gradient_launch_equals_single_launches(dev, n, hw, ci, co, c2, n1, blocks):
+    """siss_gemm_tn_pair: a 3x3 convolution's weight gradient (fused 3-tap body) and a ONE-PANEL product (a resnet's 1x1
+    conv_shortcut over the same cotangent; conv_out's 27-row product; a 64-column input) in one launch of one round of blocks --
+    3-tap blocks beside 512-thread blocks that each run two virtual one-tap blocks, uneven last splits, partial tiles -- against
+    the two products launched one by one with siss_gemm_tn.  Two cotangent sets, bias gradients; equal to f32 rounding."""
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act, conv3x3_panels
+    g = torch.Generator().manual_seed(n + hw + c2)
+    zp = ops.zero_page(dev)
+    nsets = 2
+    x3 = Act.from_nchw(_bf(torch.randn(n, ci, hw, hw, generator=g)), dev)
+    dy3 = Act.from_nchw(_bf(torch.randn(nsets * n, co, hw, hw, generator=g)), dev)
+    x1 = Act.from_nchw(_bf(torch.randn(n, c2, hw, hw, generator=g)), dev)
+    # the one-panel product's cotangent: conv2's own (the shortcut case) or another tensor (conv_out: 27 columns of a 64-wide matrix)
+    dy1 = dy3 if n1 == co else Act.from_nchw(_bf(torch.randn(nsets * n, 64, hw, hw, generator=g)), dev)
+    rps = n * dy3.rows_per_image
+    rb, re = dy3.wp + 1, rps - (dy3.wp + 1)
+    s3, c3 = conv3x3_panels(dy3.wp, ci)
+    outs = []
+    for which in range(2):
+        dW3 = torch.zeros(nsets, 9 * co * ci + co, device=dev)
+        dW1 = torch.zeros(nsets, n1 * c2 + n1, device=dev)
+        outs.append((dW3, dW1))
+        if which == 0:
+            j3 = lib.TNJob(Y=dy3.data.data_ptr(), ldy=co, X=x3.data.data_ptr(), ldx=ci, dW=dW3.data_ptr(), set_stride=dW3.shape[1], N=co, C=ci,
+                           npanels=9, nsets=nsets, rows_per_set=rps, row_begin=rb, row_end=re, nsplits=0, x_set_rows=0, zero_page=zp.data_ptr(),
+                           dbias=dW3[0, 9 * co * ci:].data_ptr(), dbias2=None, shifts=(lib.I * 9)(*s3), coffs=(lib.I * 9)(*c3))
+            z9 = (lib.I * 9)(*([0] * 9))
+            j1 = lib.TNJob(Y=dy1.data.data_ptr(), ldy=dy1.c, X=x1.data.data_ptr(), ldx=c2, dW=dW1.data_ptr(), set_stride=dW1.shape[1], N=n1, C=c2,
+                           npanels=1, nsets=nsets, rows_per_set=rps, row_begin=rb, row_end=re, nsplits=0, x_set_rows=0, zero_page=zp.data_ptr(),
+                           dbias=dW1[0, n1 * c2:].data_ptr(), dbias2=None, shifts=z9, coffs=z9)
+            lib.dispatch_counts(reset=True)
+            lib.call("siss_gemm_tn_pair", lib.C.byref(j3), lib.C.byref(j1), blocks)
+            torch.cuda.synchronize()
+            assert lib.dispatch_counts(reset=True)["gemm_tn_pair"] == 1
+        else:
+            lib.call("siss_gemm_tn", dy3.data, co, x3.data, ci, dW3, dW3.shape[1], co, ci, 9, lib.int_array(s3), lib.int_array(c3),
+                     nsets, rps, 0, rb, re, 0, zp, dW3[0, 9 * co * ci:], None)
+            lib.call("siss_gemm_tn", dy1.data, dy1.c, x1.data, c2, dW1, dW1.shape[1], n1, c2, 1, lib.int_array([0]), lib.int_array([0]),
+                     nsets, rps, 0, rb, re, 0, zp, dW1[0, n1 * c2:], None)
+            torch.cuda.synchronize()
+    (p3, p1), (q3, q1) = outs
+    assert float(q3.abs().max()) > 0 and float(q1.abs().max()) > 0
+    _close(p3.cpu(), q3.cpu(), 1e-5, "paired 3-tap product vs single")
+    _close(p1.cpu(), q1.cpu(), 1e-5, "paired one-panel product vs single")
+    # and the one-panel product against torch: dW[set][n][c] = sum over the set's pixels of dy[n] x[c]
+    dyf, xf = dy1.to_nchw()[:, :n1].cpu(), x1.to_nchw().cpu()
+    for k in range(nsets):
+        ref = torch.einsum("bnhw,bchw->nc", dyf[k * n:(k + 1) * n], xf)
+        _close(p1[k, :n1 * c2].view(n1, c2).cpu(), ref, 2e-3, f"one-panel product set {k} vs torch")
