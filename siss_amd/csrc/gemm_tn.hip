@@ -72,8 +72,10 @@ struct TCfg {
 // tid: the thread's index within ITS (virtual) block -- threadIdx.x, or threadIdx.x & 255 for the one-tap halves of a 512-thread block of
 // the mixed kernel.  PAIRED (one-tap body only): two virtual blocks share a workgroup, hence its barriers -- every block then runs
 // the SAME number of barriers (the full split's step count; the steps it does not have are barrier-only) and never returns early.
+// nvalid: the job's REAL block count when nwg was rounded up (the mixed kernel keeps block counts at multiples of 8 so that virtual
+// and physical blocks agree on their XCD); logical blocks past it have no work.
 template <int TAPS, bool ILV = false, bool PAIRED = false>
-__device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nwg, char* smem, const int tid) {
+__device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nwg, char* smem, const int tid, const int nvalid = 1 << 30) {
     using C_ = TCfg<TAPS, ILV>;
     constexpr int NP = C_::kPieces, CT = C_::kCT;
     const int lane = tid & 63;
@@ -89,6 +91,11 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    const bool dead = bid >= nvalid;                   // (a bijection of [0, nwg): the surplus of a rounded-up count decodes to no block)
+    if (dead) {
+        if (!PAIRED) return;
+        bid = 0;                                       // any valid decode: it runs no step, only the workgroup's barriers
+    }
     const int pn = (bid % ngroups) * TAPS; bid /= ngroups;
     const int tile = bid % (tiles_c * tiles_n); bid /= tiles_c * tiles_n;
     const int split = bid % p.nsplits;
@@ -98,7 +105,7 @@ __device__ __forceinline__ void tn_body(const TNParams& p, int bid, const int nw
     const int r0 = p.row_begin + split * p.rows_per_split;
     int r1 = r0 + p.rows_per_split; r1 = r1 < p.row_end ? r1 : p.row_end;
     if (!PAIRED && r0 >= r1) return;
-    const int steps = r0 < r1 ? (r1 - r0 + BR - 1) / BR : 0;
+    const int steps = (r0 < r1 && !dead) ? (r1 - r0 + BR - 1) / BR : 0;
 
     // staging: 4 pieces of 4 rows (256 B each) per wave and operand (+ one extra X piece on wave 0)
     const bf16_t* ysrc[NP];
@@ -550,7 +557,8 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_grouped_kerne
 // at 522 TF/s); beside MFMA-bound 3-tap blocks it streams while they compute.
 struct TNPair {
     TNParams j3, j1;
-    int n3, nphys1;
+    int n3, nphys1;          // physical blocks of the two products (multiples of 8)
+    int nv3, nv1;            // their real (virtual, for the one-tap product) block counts
 };
 static_assert(sizeof(TNPair) <= 4096, "kernel arguments are limited to 4 KiB");
 
@@ -558,11 +566,11 @@ __global__ __launch_bounds__(TCfg<3>::kThreads, 2) void gemm_tn_mixed_kernel(con
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
     if (b < g.n3) {
-        tn_body<3, true>(g.j3, b, g.n3, smem, threadIdx.x);
+        tn_body<3, true>(g.j3, b, g.n3, smem, threadIdx.x, g.nv3);
     } else {
         const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
         // virtual block index lb + half * nphys1: nphys1 and n3 are multiples of 8, so it keeps the physical block's XCD (index mod 8)
-        tn_body<1, false, true>(g.j1, (b - g.n3) + half * g.nphys1, 2 * g.nphys1, smem + half * TCfg<1>::kSmemBytes, threadIdx.x & 255);
+        tn_body<1, false, true>(g.j1, (b - g.n3) + half * g.nphys1, 2 * g.nphys1, smem + half * TCfg<1>::kSmemBytes, threadIdx.x & 255, g.nv1);
     }
 }
 
@@ -793,8 +801,10 @@ int siss_gemm_tn_pair(const void* job3, const void* job1, int max_blocks, void* 
                   b.x_set_rows, b.row_begin, b.row_end, s1, b.zero_page, b.dbias, b.dbias2, false, g.j1, f1);
     if (rc != SISS_OK) return rc;
     SISS_CHECK_ARG(f3 && !f1);
-    g.n3 = (int)((base3 * s3 + 7) & ~7L);
-    g.nphys1 = (int)(((base1 * s1 + 1) / 2 + 7) & ~7L);
+    g.nv3 = (int)(base3 * s3);
+    g.nv1 = (int)(base1 * s1);
+    g.n3 = (g.nv3 + 7) & ~7;
+    g.nphys1 = ((g.nv1 + 1) / 2 + 7) & ~7;
     static unsigned char attr_set[kMaxDevices];
     constexpr int smem = TCfg<3, true>::kSmemBytes > 2 * TCfg<1>::kSmemBytes ? TCfg<3, true>::kSmemBytes : 2 * TCfg<1>::kSmemBytes;
     if (siss_ensure_smem((const void*)gemm_tn_mixed_kernel, smem, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;

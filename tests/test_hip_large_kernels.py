@@ -434,7 +434,7 @@ def test_grouped_weight_gradient_launch_equals_single_launches(dev):
         _close(grouped.cpu(), single.cpu(), 1e-5, "grouped vs single")
 
 
-@pytest.mark.parametrize("n,hw,ci,co,c2,n1,blocks", [(4, 64, 128, 128, 256, 128, 0), (2, 48, 256, 128, 128, 27, 64), (3, 40, 128, 256, 64, 256, 40)])
+@pytest.mark.parametrize("n,hw,ci,co,c2,n1,blocks", [(4, 64, 128, 128, 256, 128, 0), (4, 64, 128, 128, 256, 128, 40), (2, 48, 256, 128, 128, 27, 64), (3, 40, 128, 256, 64, 256, 40)])
 def test_paired_weight_gradient_launch_equals_single_launches(dev, n, hw, ci, co, c2, n1, blocks):
     """siss_gemm_tn_pair: a 3x3 convolution's weight gradient (fused 3-tap body) and a ONE-PANEL product (a resnet's 1x1
     conv_shortcut over the same cotangent; conv_out's 27-row product; a 64-column input) in one launch of one round of blocks --
