@@ -168,6 +168,22 @@ __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ f32x4_t mfma(const bf16x8_t& x, const bf16x8_t& y, const f32x4_t& acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc, 0, 0, 0);
 }
+// 1-D grid -> (64-row tile x, image y) such that the NS tiles of an image -- and, in the backward, the cotangent images that share a
+// forward image (y, y + B, ...) where the batch allows -- run on ONE XCD (blocks b and b + 8 share an XCD and its 4-MiB L2): every
+// block of an image streams the same K / V (Q / dO) rows, 0.4-0.8 MB per image at D = 512.  Without it the 16 blocks of an XCD
+// touch 16 different images and the streams come from the Infinity Cache at about half the per-CU rate (measured: 38 us per
+// backward kernel at S = 256 where the streaming of 0.77 MB per block accounts for 12 us from L2).
+__device__ __forceinline__ void block_to_tile(int NS, int ny, int& x, int& y) {
+    const int lin = blockIdx.x;
+    if ((ny & 7) == 0) {
+        const int xcd = lin & 7, k = lin >> 3;
+        x = k % NS;
+        y = xcd + 8 * (k / NS);
+    } else {
+        x = lin % NS;
+        y = lin / NS;
+    }
+}
 // all of this wave's LDS-DMA pieces (and private loads) have landed, and -- behind the barrier -- everybody's
 __device__ __forceinline__ void tile_ready() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -187,12 +203,14 @@ __device__ __forceinline__ void store_rows(bf16_t* __restrict__ dst, const f32x4
 template <int D, int NS>
 __global__ __launch_bounds__(kThreadsA) void attn1h_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                 const bf16_t* __restrict__ v, long ld, bf16_t* __restrict__ o, long ldo,
-                                                                RowMap om, float* __restrict__ lse, float c) {
+                                                                RowMap om, float* __restrict__ lse, float c, int B) {
     using A = AT<D>;
     constexpr int S = 64 * NS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = blockIdx.y, s0 = blockIdx.x * 64;
+    int bx, n;
+    block_to_tile(NS, B, bx, n);
+    const int s0 = bx * 64;
     const RowMap cm{0, 0, 0};
     const unsigned lb = lds_addr(smem);
     Lanes<D> L;
@@ -263,12 +281,14 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_bwd_dq_kernel(const bf16_t* 
                                                                    const bf16_t* __restrict__ v, long ld, const bf16_t* __restrict__ o,
                                                                    long ldo, const bf16_t* __restrict__ dO, long lddo, RowMap pm,
                                                                    const float* __restrict__ lse, float* __restrict__ delta,
-                                                                   bf16_t* __restrict__ dq, long ldd, int B, float c, float scale) {
+                                                                   bf16_t* __restrict__ dq, long ldd, int B, int nb, float c, float scale) {
     using A = AT<D>;
     constexpr int S = 64 * NS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int z = blockIdx.y, n = z % B, s0 = blockIdx.x * 64;
+    int bx, z;
+    block_to_tile(NS, nb, bx, z);
+    const int n = z % B, s0 = bx * 64;
     const RowMap cm{0, 0, 0};
     const unsigned lb = lds_addr(smem);
     Lanes<D> L;
@@ -360,12 +380,14 @@ __global__ __launch_bounds__(kThreadsA) void attn1h_bwd_dkv_kernel(const bf16_t*
                                                                     const bf16_t* __restrict__ v, long ld, const bf16_t* __restrict__ dO,
                                                                     long lddo, RowMap pm, const float* __restrict__ lse,
                                                                     const float* __restrict__ delta, bf16_t* __restrict__ dk,
-                                                                    bf16_t* __restrict__ dv, long ldd, int B, float c, float scale) {
+                                                                    bf16_t* __restrict__ dv, long ldd, int B, int nb, float c, float scale) {
     using A = AT<D>;
     constexpr int S = 64 * NS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4;
-    const int z = blockIdx.y, n = z % B, s0 = blockIdx.x * 64;
+    int bx, z;
+    block_to_tile(NS, nb, bx, z);
+    const int n = z % B, s0 = bx * 64;
     const RowMap cm{0, 0, 0};
     const unsigned lb = lds_addr(smem);
     Lanes<D> L, Ld;                      // (Ld: the DMA offsets for dO's row stride; its read addresses are L's and fold away)
@@ -494,7 +516,7 @@ int siss_attn1h_takes(int S, int D) {
 // rows when W == 0; lse [B * S] f32 (base-2 log-sum-exp of the scaled scores, for the backward).
 int siss_attn1h_fwd(const void* q, const void* k, const void* v, long ld, void* o, long ldo, int W, float* lse, int B, int S,
                     int D, float scale, void* stream) {
-    SISS_CHECK_ARG(q && k && v && o && lse && B > 0 && B <= 65535 && siss_attn1h_takes(S, D));
+    SISS_CHECK_ARG(q && k && v && o && lse && B > 0 && B <= (1 << 20) && siss_attn1h_takes(S, D));
     SISS_CHECK_ARG(ld >= D && ldo >= D && ld % 8 == 0 && ldo % 4 == 0 && (W == 0 || (W > 0 && W % 4 == 0 && S % W == 0)));
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0);
     const RowMap om{W ? (long)(S / W + 2) * (W + 2) : 0, W, W ? W + 2 : 0};
@@ -504,7 +526,7 @@ int siss_attn1h_fwd(const void* q, const void* k, const void* v, long ld, void* 
         auto kern = attn1h_fwd_kernel<kD, kNS>;
         const int smem = 2 * AT<kD>::TILE;
         if (prep(kern, smem, g_smem_done[0][kNS - 1][kDi])) return SISS_ERR_LAUNCH;
-        kern<<<dim3(kNS, B), kThreadsA, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)o, ldo, om, lse, c);
+        kern<<<dim3(kNS * B), kThreadsA, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (bf16_t*)o, ldo, om, lse, c, B);
     });
     siss_count_dispatch(SISS_K_ATTN1H_FWD);
     SISS_LAUNCH_RET();
@@ -517,7 +539,7 @@ int siss_attn1h_fwd(const void* q, const void* k, const void* v, long ld, void* 
 int siss_attn1h_bwd(const void* q, const void* k, const void* v, long ld, const void* o, long ldo, const void* dO, long lddo, int W,
                     const float* lse, float* delta, void* dq, void* dk, void* dv, long ldd, int nb, int B, int S, int D, float scale,
                     void* stream) {
-    SISS_CHECK_ARG(q && k && v && o && dO && lse && delta && dq && dk && dv && B > 0 && nb > 0 && nb % B == 0 && nb <= 65535);
+    SISS_CHECK_ARG(q && k && v && o && dO && lse && delta && dq && dk && dv && B > 0 && nb > 0 && nb % B == 0 && nb <= (1 << 20));
     SISS_CHECK_ARG(siss_attn1h_takes(S, D) && ld >= D && ldo >= D && lddo >= D && ldd >= D);
     SISS_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0 && (W == 0 || (W > 0 && W % 4 == 0 && S % W == 0)));
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO) % 16 == 0);
@@ -530,10 +552,10 @@ int siss_attn1h_bwd(const void* q, const void* k, const void* v, long ld, const 
         auto kkv = attn1h_bwd_dkv_kernel<kD, kNS>;
         const int smem = 2 * AT<kD>::TILE;
         if (prep(kq, smem, g_smem_done[1][kNS - 1][kDi]) || prep(kkv, smem, g_smem_done[2][kNS - 1][kDi])) return SISS_ERR_LAUNCH;
-        kq<<<dim3(kNS, nb), kThreadsA, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (const bf16_t*)o, ldo,
-                                                   (const bf16_t*)dO, lddo, pm, lse, delta, (bf16_t*)dq, ldd, B, c, scale);
-        kkv<<<dim3(kNS, nb), kThreadsA, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (const bf16_t*)dO, lddo, pm,
-                                                    lse, delta, (bf16_t*)dk, (bf16_t*)dv, ldd, B, c, scale);
+        kq<<<dim3(kNS * nb), kThreadsA, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (const bf16_t*)o, ldo,
+                                                    (const bf16_t*)dO, lddo, pm, lse, delta, (bf16_t*)dq, ldd, B, nb, c, scale);
+        kkv<<<dim3(kNS * nb), kThreadsA, smem, st>>>((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ld, (const bf16_t*)dO, lddo, pm,
+                                                     lse, delta, (bf16_t*)dk, (bf16_t*)dv, ldd, B, nb, c, scale);
     });
     siss_count_dispatch(SISS_K_ATTN1H_BWD);
     SISS_LAUNCH_RET();

@@ -780,7 +780,11 @@ int siss_gemm_tn_pair(const void* job3, const void* job1, int max_blocks, void* 
     const long base1 = (long)cdiv(b.N, BN) * cdiv(b.C, BC) * b.nsets;
     const int rows3 = a.row_end - a.row_begin, rows1 = b.row_end - b.row_begin;
     SISS_CHECK_ARG(rows3 > 0 && rows1 > 0);
-    const double c1 = (g_pair_cost_permille ? g_pair_cost_permille : 600) / 1000.0;    // one-tap K-step (two virtual blocks per CU) / 3-tap K-step
+    // one-tap K-step (two virtual blocks per CU: one 32-KiB stage each in flight, i.e. bound by the latency of 64 KiB of HBM reads:
+    // ~1.4 us) against a 3-tap block's (1.25 us).  Swept at the 256 x 256 shapes (tools/probes/tn_pair.py, us per launch, apart ->
+    // paired at 1000 / 1300 / 1500 / 1800 permille): conv2 + conv_shortcut (N 128, C 128 | C 256) 809 -> 800 / 703 / 662 / 657; conv1
+    // (C 256) + shortcut 1140 -> 1046 / 1129 / 1084 / 1093; conv2 + conv_out (N 27) 590 -> 610 / 570 / 554 / 564
+    const double c1 = (g_pair_cost_permille ? g_pair_cost_permille : 1500) / 1000.0;
     double best = 1e30;
     int s3 = 0, s1 = 0;
     for (int t1 = 1; t1 <= 4096; ++t1) {

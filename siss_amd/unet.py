@@ -675,7 +675,9 @@ class UNetEngine:
                 self._pair1.append((job, dy))
                 self._held[id(dy.buf)] = dy
                 return
-            j1, dy1 = self._pair1.pop(0)
+            # the partner: a waiting product over the SAME cotangent (the resnet's own conv_shortcut: its Y tiles are in L2), else the oldest
+            same = [i for i, (_, d) in enumerate(self._pair1) if d is dy]
+            j1, dy1 = self._pair1.pop(same[0] if same else 0)
             lib.call("siss_gemm_tn_pair", lib.C.byref(job), lib.C.byref(j1), 0)
             if not any(d is dy1 for _, d in self._pair1):
                 self._unhold(dy1)
