@@ -550,6 +550,29 @@ __global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_grouped_kerne
     tn_body<TAPS, TAPS == 3>(g.job[j], bid, g.nwg[j], smem, threadIdx.x);      // 3 taps: the interleaved variant (4-deep ring)
 }
 
+// The same with a CAPPED grid (siss_gemm_tn_grouped_capped): fewer workgroups than blocks, each walking the block list with the
+// grid's stride (a multiple of 8: a workgroup's blocks keep its XCD) -- the launch then occupies at most that many CUs for its
+// whole duration and leaves the rest of the chip to whatever runs beside it on another stream.  (A kernel of its own: the loop
+// costs the 3-tap body registers -- 152 instead of 44 bytes of scratch per lane -- which the uncapped launches need not pay.)
+template <int TAPS>
+__global__ __launch_bounds__(TCfg<TAPS>::kThreads, 2) void gemm_tn_grouped_capped_kernel(const TNGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int total = g.first[g.njobs];
+    for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+        int j = 0;
+        while (j + 1 < g.njobs && vb >= g.first[j + 1]) ++j;
+        const int bid = vb - g.first[j];
+        if (bid < g.nwg[j])
+            tn_body<TAPS, TAPS == 3>(g.job[j], bid, g.nwg[j], smem, threadIdx.x);
+        if (vb + (int)gridDim.x < total) {
+            // the next block restages the LDS ring: every wave must be out of this block's reads (and its DMA landed) first
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (TAPS == 3) __builtin_amdgcn_s_setprio(0);
+        }
+    }
+}
+
 // A fused 3-tap product and a one-tap product in ONE launch of one round of blocks (siss_gemm_tn_pair): blocks [0, n3) run the 3-tap
 // body, each of the nphys1 blocks behind them runs TWO virtual one-tap blocks (waves 0-3 and 4-7, a 64-KiB half of the LDS each:
 // the residency the one-tap kernel has on its own, two 256-thread blocks per CU).  Why: a one-tap weight gradient at 256 x 256
@@ -680,7 +703,7 @@ static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW,
 }
 
 template <int TAPS>
-static int launch_tn_group(const TNParams* ps, int n, hipStream_t st) {
+static int launch_tn_group(const TNParams* ps, int n, hipStream_t st, int max_blocks = 0) {
     using C_ = TCfg<TAPS, TAPS == 3>;
     static unsigned char attr_set[kMaxDevices];
     if (siss_ensure_smem((const void*)gemm_tn_grouped_kernel<TAPS>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
@@ -706,7 +729,13 @@ static int launch_tn_group(const TNParams* ps, int n, hipStream_t st) {
             siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
         }
         g.first[g.njobs] = total;
-        gemm_tn_grouped_kernel<TAPS><<<dim3(total), C_::kThreads, C_::kSmemBytes, st>>>(g);
+        if (max_blocks > 0 && total > max_blocks) {
+            static unsigned char attr_capped[kMaxDevices];
+            if (siss_ensure_smem((const void*)gemm_tn_grouped_capped_kernel<TAPS>, C_::kSmemBytes, attr_capped) != SISS_OK) return SISS_ERR_LAUNCH;
+            gemm_tn_grouped_capped_kernel<TAPS><<<dim3(max_blocks), C_::kThreads, C_::kSmemBytes, st>>>(g);
+        } else {
+            gemm_tn_grouped_kernel<TAPS><<<dim3(total), C_::kThreads, C_::kSmemBytes, st>>>(g);
+        }
     }
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
@@ -823,7 +852,16 @@ int siss_gemm_tn_pair(const void* job3, const void* job1, int max_blocks, void* 
 // arguments: nothing is copied to the device, hipGraph-safe).  jobs: HOST array of siss_tn_job (the argument list of
 // siss_gemm_tn as a struct, shifts / coffs inline).  Meant for the low-resolution weight gradients: each of them alone leaves
 // most CUs idle and pays a launch's fixed latency.  All operands must stay valid until the launch has run.
-int siss_gemm_tn_grouped(const void* jobs, int njobs, void* stream) {
+static int tn_grouped(const void* jobs, int njobs, int max_blocks, void* stream);
+int siss_gemm_tn_grouped(const void* jobs, int njobs, void* stream) { return tn_grouped(jobs, njobs, 0, stream); }
+// The same with the launches' grids capped at max_blocks workgroups (a multiple of 8, >= 8; the 3-tap launches hold one CU per
+// workgroup, the one-tap launches half a CU): each workgroup walks several blocks.  For running the weight gradients on a side stream
+// beside kernels that leave most of the chip idle (the low-resolution part of the backward pass) without taking every CU from them.
+int siss_gemm_tn_grouped_capped(const void* jobs, int njobs, int max_blocks, void* stream) {
+    SISS_CHECK_ARG(max_blocks >= 8 && max_blocks % 8 == 0);
+    return tn_grouped(jobs, njobs, max_blocks, stream);
+}
+static int tn_grouped(const void* jobs, int njobs, int max_blocks, void* stream) {
     SISS_CHECK_ARG(jobs && njobs > 0 && njobs <= 256);
     const siss_tn_job* js = (const siss_tn_job*)jobs;
     TNParams p3[256], p1[256];
@@ -838,8 +876,8 @@ int siss_gemm_tn_grouped(const void* jobs, int njobs, void* stream) {
         if (rc != SISS_OK) return rc;
         if (fused3) p3[n3++] = p; else p1[n1++] = p;
     }
-    if (n3) { const int rc = launch_tn_group<3>(p3, n3, (hipStream_t)stream); if (rc != SISS_OK) return rc; }
-    if (n1) { const int rc = launch_tn_group<1>(p1, n1, (hipStream_t)stream); if (rc != SISS_OK) return rc; }
+    if (n3) { const int rc = launch_tn_group<3>(p3, n3, (hipStream_t)stream, max_blocks); if (rc != SISS_OK) return rc; }
+    if (n1) { const int rc = launch_tn_group<1>(p1, n1, (hipStream_t)stream, 2 * max_blocks); if (rc != SISS_OK) return rc; }
     return SISS_OK;
 }
 

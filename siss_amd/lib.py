@@ -54,6 +54,7 @@ SIGNATURES = {
     "siss_gemm_tn": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, P],
     "siss_gemm_tn_bs": [P, L, P, L, P, L, I, I, I, IP, IP, I, I, L, I, I, I, P, P, P, L, P],
     "siss_gemm_tn_grouped": [P, I, P],
+    "siss_gemm_tn_grouped_capped": [P, I, I, P],
     "siss_gemm_tn_pair": [P, P, I, P],
     "siss_gemm_tn_set_pair_cost": [I],
     "siss_gn_partial_words": [I, I, I, I, I],
@@ -261,7 +262,7 @@ def _work(name, a):
         if wp > 2 and rps % (wp * wp) == 0 and rows == rps - 2 * rb:
             rows = (rps // (wp * wp)) * (wp - 2) * (wp - 2)
         return 2.0 * a[6] * a[7] * a[8] * a[11] * rows
-    if name == "siss_gemm_tn_grouped":
+    if name in ("siss_gemm_tn_grouped", "siss_gemm_tn_grouped_capped"):
         return sum(_work("siss_gemm_tn", [None] * 6 + [j.N, j.C, j.npanels, None, None, j.nsets, j.rows_per_set, None,
                                                        j.row_begin, j.row_end]) for j in a[0])
     if name == "siss_gemm_tn_pair":     # (byref(job3), byref(job1), max_blocks): both products
@@ -351,7 +352,7 @@ def kernel_symbol(name, a):
         return "gemm_nt_c3p_kernel"
     if name == "siss_gemm_nt_mulsub":
         return "gemm_nt_kernel"
-    if name == "siss_gemm_tn_grouped":
+    if name in ("siss_gemm_tn_grouped", "siss_gemm_tn_grouped_capped"):
         return "gemm_tn_grouped_kernel"
     if name == "siss_gemm_tn_pair":
         return "gemm_tn_mixed_kernel"

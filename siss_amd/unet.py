@@ -182,6 +182,13 @@ class UNetEngine:
     # One-panel weight gradients at the TOP resolution (a resnet's 1x1 conv_shortcut, conv_out, conv_in: HBM-bound launches at
     # 200-520 TF/s) wait for the next fused 3-tap weight gradient and ride in ITS launch (siss_gemm_tn_pair: one round of blocks
     # shared by the two products; the streaming one-tap blocks run beside MFMA-bound 3-tap blocks)
+    # The low-resolution middle of the backward pass (up / mid / down blocks at <= side_max_px pixels: grids of 13-160 tiles that leave
+    # most CUs idle) runs BESIDE the weight gradients queued so far (the 32 x 32 .. 128 x 128 up blocks': ~3 ms of MFMA-bound work that
+    # nothing waits for): they go to a side stream as grouped launches capped at side_blocks workgroups (= CUs), and join at the end of
+    # the pass.  0 blocks = off.
+    wgrad_side = True
+    side_blocks = 192
+    side_max_px = 256
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
@@ -216,6 +223,7 @@ class UNetEngine:
         self.on_early_grads_final = None
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
+        self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -427,8 +435,50 @@ class UNetEngine:
 
     def _wsync(self, a):
         """`a` is about to be overwritten: a queued (grouped) wgrad that still reads it must run first."""
-        if a is not None and self._held and id(getattr(a, "base", a).buf) in self._held:
+        if a is None:
+            return
+        key = id(getattr(a, "base", a).buf)
+        if self._held and key in self._held:
             self._flush_wgrads()
+        if self._side_held and key in self._side_held:
+            self._join_side()
+
+    def _is_held(self, buf):
+        return bool((self._held and id(buf) in self._held) or (self._side_held and id(buf) in self._side_held))
+
+    def _join_side(self):
+        """The launches on the side stream have to be complete before what follows on this stream; their operands return to the pool."""
+        if not self._side_busy:
+            return
+        torch.cuda.current_stream().wait_stream(self._side)
+        self._side_busy, self._side_held = False, {}
+        rel, self._side_release = self._side_release, []
+        for a in rel:
+            self._put(a)
+
+    def _flush_wgrads_side(self):
+        """The queued weight-gradient products as CAPPED grouped launches on the side stream (behind everything issued so far)."""
+        if not self._wq:
+            return
+        if not (self.wgrad_side and self.side_blocks >= 8) or self.f32:
+            return self._flush_wgrads()
+        self._join_side()                                 # one batch at a time
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
+        with torch.cuda.stream(self._side):
+            lib.call("siss_gemm_tn_grouped_capped", jobs, len(self._wq), int(self.side_blocks) & ~7)
+        for _, (dy, _x) in self._wq:                     # their cotangent operands stay out of the pool until the join
+            buf = getattr(dy, "buf", None)
+            if buf is not None and id(buf) in self._held:
+                self._side_held[id(buf)] = self._held.pop(id(buf))
+        keep = []
+        for a in self._held_release:
+            (self._side_release if id(a.buf) in self._side_held else keep).append(a)
+        self._held_release = keep
+        self._wq = []
+        self._side_busy = True
 
     def _flush_wgrads(self):
         """Run the queued weight-gradient products as grouped launches and give their operands back to the pool."""
@@ -460,6 +510,9 @@ class UNetEngine:
         if a is not None:
             if self._held and id(a.buf) in self._held:   # still the operand of a queued wgrad: back to the pool after the flush
                 self._held_release.append(a)
+                return
+            if self._side_held and id(a.buf) in self._side_held:     # ... or of one running on the side stream: after the join
+                self._side_release.append(a)
                 return
             self._pool.setdefault((a.n, a.h, a.w, a.c), []).append(a)
 
@@ -525,7 +578,7 @@ class UNetEngine:
             split = (da, db, accumulate_b): x was concat(a, b) -- write the two halves straight into da / db."""
             nb = self.nb
             # accum is normally overwritten in place; not while a queued (grouped) wgrad still reads it: fresh output then
-            held = accum is not None and self._held and id(accum.buf) in self._held
+            held = accum is not None and self._is_held(accum.buf)
             if accum is not None and not held:
                 self._wsync(accum)                      # written in place
             s2d = False
@@ -1181,6 +1234,7 @@ class UNetEngine:
         self.tape, self.gmap, self._uid = [], {}, 0
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
+        self._side_mark = None
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
@@ -1205,6 +1259,8 @@ class UNetEngine:
         h = self.attention(h, "mid_block.attentions.0")
         h = self.resnet(h, "mid_block.resnets.1", cat_with=skips[-1])
         for (i, cout_b, attn, up, rs) in self.plan_up:
+            if self._side_mark is None and h.h * h.w > self.side_max_px:
+                self._side_mark = len(self.tape)       # the closures below this index are the low-resolution middle of the backward pass
             for j in range(len(rs)):
                 h = self.concat(h, skips.pop())
                 # a resnet whose output goes straight into the next concat (no attention / upsample in between)
@@ -1327,10 +1383,15 @@ class UNetEngine:
         self.dtp_all = self._buf("temb.dtp_all", (nb, self.temb_ntot))
         self.dtp_all.zero_()
         mark = getattr(self, "_early_mark", None)
+        side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32) else -1
         for idx in range(len(self.tape) - 1, -1, -1):
+            if idx == side_at:
+                self._flush_wgrads_side()               # the weight gradients queued so far run beside the low-resolution blocks
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail
+                self._join_side()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
         self._flush_wgrads()
+        self._join_side()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"

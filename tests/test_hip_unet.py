@@ -271,6 +271,53 @@ def test_bf16_io_mode_and_graph_replay(setup):
     assert rep["step"] == 1
 
 
+def test_side_stream_weight_gradients_equal_the_main_stream_schedule(setup):
+    """UNetEngine.wgrad_side: the weight gradients queued before the low-resolution middle of the backward pass run on a SIDE stream
+    as capped grouped launches (siss_gemm_tn_grouped_capped: 8 workgroups walking all blocks) beside it and join at the end.  Same
+    products, same operands: both gradient sets equal the one-stream schedule's to f32 rounding (float atomics) -- eagerly and
+    replayed from a hipGraph whose capture forks to the side stream and joins it.  (side_max_px lowered so that the toy network,
+    8 x 8 / 16 x 16, has a 'low-resolution middle' at all.)"""
+    eng, _, sd = _fresh(setup)
+    g = torch.Generator().manual_seed(21)
+    B = 4
+    x = torch.randn(B, 3, 16, 16, generator=g).cuda()
+    t = torch.tensor([999, 10, 700, 999]).cuda()
+    cot = torch.randn(2 * B, 3, 16, 16, generator=g).cuda().contiguous()
+
+    def run():
+        eng.forward(x, t)
+        eng.zero_grad()
+        eng.backward(cot, nsets=2)
+        torch.cuda.synchronize()
+        return eng.ps.grads.clone()
+    saved = (eng.wgrad_side, eng.side_max_px, eng.side_blocks)
+    try:
+        eng.wgrad_side = False
+        ref = run()
+        eng.wgrad_side, eng.side_max_px, eng.side_blocks = True, 64, 8
+        got = run()
+        assert eng._side is not None and eng._side_mark is not None, "the side stream must have been used"
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 1e-5 * scale
+        # ... and under capture: fork to the side stream, join before the capture ends
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            run()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=cap):
+                eng.forward(x, t)
+                eng.zero_grad()
+                eng.backward(cot, nsets=2)
+        torch.cuda.current_stream().wait_stream(cap)
+        eng.ps.grads.fill_(7.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert float((eng.ps.grads - ref).abs().max()) <= 1e-5 * scale
+    finally:
+        eng.wgrad_side, eng.side_max_px, eng.side_blocks = saved
+
+
 def test_mnist_tshirt_config_step_matches_oracle():
     """BASELINE config 1 on the HIP path: MNIST 28x28 UNet (64/128/256 channels, 16/32-head attention with
     head_dim 8, downsample_padding=1, flip_sin_to_cos), t ~ U{0..999}, inf guard (delete_tshirt.py)."""
