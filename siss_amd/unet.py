@@ -189,6 +189,7 @@ class UNetEngine:
     wgrad_side = True
     side_blocks = 192
     side_max_px = 256
+    side_budget = 2500         # GFLOP of queued weight-gradient work that may go to the side stream (largest jobs first; the rest stays queued)
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
@@ -224,6 +225,7 @@ class UNetEngine:
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
+        self._side_end, self._in_side_window = None, False
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -457,27 +459,41 @@ class UNetEngine:
             self._put(a)
 
     def _flush_wgrads_side(self):
-        """The queued weight-gradient products as CAPPED grouped launches on the side stream (behind everything issued so far)."""
+        """Queued weight-gradient products as CAPPED grouped launches on the side stream (behind everything issued so far): the
+        largest jobs first, up to side_budget GFLOP -- what the low-resolution window can absorb; the rest stays queued."""
         if not self._wq:
             return
         if not (self.wgrad_side and self.side_blocks >= 8) or self.f32:
-            return self._flush_wgrads()
+            return
         self._join_side()                                 # one batch at a time
+        gflop = lambda j: 2e-9 * j.N * j.C * j.npanels * j.nsets * (j.row_end - j.row_begin)
+        order = sorted(range(len(self._wq)), key=lambda i: -gflop(self._wq[i][0]))
+        take, spent = set(), 0.0
+        for i in order:
+            w = gflop(self._wq[i][0])
+            if spent + w <= self.side_budget:
+                take.add(i); spent += w
+        if not take:
+            return
+        mine = [self._wq[i] for i in range(len(self._wq)) if i in take]
+        self._wq = [self._wq[i] for i in range(len(self._wq)) if i not in take]
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         self._side.wait_stream(torch.cuda.current_stream())
-        jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
+        jobs = (lib.TNJob * len(mine))(*[j for j, _ in mine])
         with torch.cuda.stream(self._side):
-            lib.call("siss_gemm_tn_grouped_capped", jobs, len(self._wq), int(self.side_blocks) & ~7)
-        for _, (dy, _x) in self._wq:                     # their cotangent operands stay out of the pool until the join
+            lib.call("siss_gemm_tn_grouped_capped", jobs, len(mine), int(self.side_blocks) & ~7)
+        still = {id(getattr(dy, "buf", None)) for _, (dy, _x) in self._wq}
+        for _, (dy, _x) in mine:                          # their cotangent operands stay out of the pool until the join
             buf = getattr(dy, "buf", None)
             if buf is not None and id(buf) in self._held:
-                self._side_held[id(buf)] = self._held.pop(id(buf))
+                self._side_held[id(buf)] = self._held[id(buf)]
+                if id(buf) not in still:                  # (a job left in the queue may read the same cotangent: both hold it then)
+                    self._held.pop(id(buf))
         keep = []
         for a in self._held_release:
-            (self._side_release if id(a.buf) in self._side_held else keep).append(a)
+            (self._side_release if (id(a.buf) in self._side_held and id(a.buf) not in self._held) else keep).append(a)
         self._held_release = keep
-        self._wq = []
         self._side_busy = True
 
     def _flush_wgrads(self):
@@ -492,7 +508,7 @@ class UNetEngine:
         self._held = {}
         rel, self._held_release = self._held_release, []
         for a in rel:
-            self._put(a)
+            self._put(a)                                  # (one the side stream still reads goes to ITS release list: _put checks)
 
     def _launch_tn_job(self, job):
         lib.call("siss_gemm_tn", job.Y, job.ldy, job.X, job.ldx, job.dW, job.set_stride, job.N, job.C, job.npanels,
@@ -713,7 +729,7 @@ class UNetEngine:
                             shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t))))
             self._wq.append((job, (dy, x)))
             self._held[id(dy.buf)] = dy
-            if len(self._wq) >= self.group_max:
+            if len(self._wq) >= self.group_max and not self._in_side_window:
                 self._flush_wgrads()
             return
         if (self.pair_top and not self.f32 and isinstance(dy, Act) and re - rb >= self.pair_min_rows
@@ -1010,7 +1026,7 @@ class UNetEngine:
                                            row_begin=0, row_end=si * S, nsplits=0, x_set_rows=xsr, zero_page=zp.data_ptr(),
                                            dbias=ps.g(pre + ".to_q.bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
                                  (dqkv, hn)))
-                if len(self._wq) >= self.group_max:
+                if len(self._wq) >= self.group_max and not self._in_side_window:
                     self._flush_wgrads()
             else:
                 lib.call("siss_gemm_tn", dqkv, 3 * C, hn, C, dW, ps.total, 3 * C, C, 1, lib.int_array([0]), lib.int_array([0]),
@@ -1234,7 +1250,7 @@ class UNetEngine:
         self.tape, self.gmap, self._uid = [], {}, 0
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
-        self._side_mark = None
+        self._side_mark, self._side_end, self._in_side_window = None, None, False
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
@@ -1246,6 +1262,8 @@ class UNetEngine:
         for (i, cin_b, cout_b, attn, down) in self.plan_down:
             if self._early_mark is None and f"down_blocks.{i}." in early:
                 self._early_mark = len(self.tape)      # closures from here on belong to the early-final group
+            if self._side_end is None and h.h * h.w <= self.side_max_px:
+                self._side_end = len(self.tape)        # ... and from here up to _side_mark: the low-resolution middle (side-stream window)
             for j in range(cfg.layers_per_block):
                 # a conv-produced skip is written straight into the tail columns of the concat buffer it ends up in
                 h = self.resnet(h, f"down_blocks.{i}.resnets.{j}", skip_head=None if attn else heads[len(skips)])
@@ -1384,14 +1402,19 @@ class UNetEngine:
         self.dtp_all.zero_()
         mark = getattr(self, "_early_mark", None)
         side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32) else -1
+        side_end = (self._side_end or 0) - 1
         for idx in range(len(self.tape) - 1, -1, -1):
             if idx == side_at:
                 self._flush_wgrads_side()               # the weight gradients queued so far run beside the low-resolution blocks
+                self._in_side_window = self._side_busy  # (no grouped launch on THIS stream inside the window: it would take the CUs)
+            if idx == side_end:
+                self._in_side_window = False
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail
                 self._join_side()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
+        self._in_side_window = False
         self._flush_wgrads()
         self._join_side()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"
