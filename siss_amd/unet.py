@@ -182,14 +182,17 @@ class UNetEngine:
     # One-panel weight gradients at the TOP resolution (a resnet's 1x1 conv_shortcut, conv_out, conv_in: HBM-bound launches at
     # 200-520 TF/s) wait for the next fused 3-tap weight gradient and ride in ITS launch (siss_gemm_tn_pair: one round of blocks
     # shared by the two products; the streaming one-tap blocks run beside MFMA-bound 3-tap blocks)
-    # The low-resolution middle of the backward pass (up / mid / down blocks at <= side_max_px pixels: grids of 13-160 tiles that leave
-    # most CUs idle) runs BESIDE the weight gradients queued so far (the 32 x 32 .. 128 x 128 up blocks': ~3 ms of MFMA-bound work that
-    # nothing waits for): they go to a side stream as grouped launches capped at side_blocks workgroups (= CUs), and join at the end of
-    # the pass.  0 blocks = off.
+    # BACKGROUND WEIGHT GRADIENTS (round 5).  Nothing in the backward pass waits for a weight gradient (they only feed the flat gradient
+    # buffer), and the chain that IS serial -- dgrad convolutions (MFMA-bound), GroupNorm backward (HBM-bound: 10.7 ms of the step
+    # with the matrix cores idle), the low-resolution middle (grids of 13-160 tiles on a 256-CU chip) -- leaves matrix-core time on the
+    # table.  With wgrad_side every weight-gradient product of the backward pass (top-resolution ones too) is queued and streamed to a
+    # SIDE stream as grouped launches capped at side_blocks workgroups (siss_gemm_tn_grouped_capped: that many CUs for the side
+    # stream, the persistent 3x3 kernel of THIS stream sized to the rest), flushed every side_flush_gflop of queued work; their
+    # cotangent operands stay out of the buffer pool until the join at the end of the pass.  False / 0 blocks: the one-stream schedule.
     wgrad_side = True
-    side_blocks = 192
-    side_max_px = 256
-    side_budget = 2500         # GFLOP of queued weight-gradient work that may go to the side stream (largest jobs first; the rest stays queued)
+    side_blocks = 96
+    side_flush_gflop = 400
+    side_flush_jobs = 12
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
@@ -224,8 +227,8 @@ class UNetEngine:
         self.on_early_grads_final = None
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
-        self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
-        self._side_end, self._in_side_window = None, False
+        self._side, self._side_busy, self._side_held, self._side_release = None, False, {}, []
+        self._side_on, self._wq_gflop = False, 0.0
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -458,50 +461,26 @@ class UNetEngine:
         for a in rel:
             self._put(a)
 
-    def _flush_wgrads_side(self):
-        """Queued weight-gradient products as CAPPED grouped launches on the side stream (behind everything issued so far): the
-        largest jobs first, up to side_budget GFLOP -- what the low-resolution window can absorb; the rest stays queued."""
-        if not self._wq:
-            return
-        if not (self.wgrad_side and self.side_blocks >= 8) or self.f32:
-            return
-        self._join_side()                                 # one batch at a time
-        gflop = lambda j: 2e-9 * j.N * j.C * j.npanels * j.nsets * (j.row_end - j.row_begin)
-        order = sorted(range(len(self._wq)), key=lambda i: -gflop(self._wq[i][0]))
-        take, spent = set(), 0.0
-        for i in order:
-            w = gflop(self._wq[i][0])
-            if spent + w <= self.side_budget:
-                take.add(i); spent += w
-        if not take:
-            return
-        mine = [self._wq[i] for i in range(len(self._wq)) if i in take]
-        self._wq = [self._wq[i] for i in range(len(self._wq)) if i not in take]
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        self._side.wait_stream(torch.cuda.current_stream())
-        jobs = (lib.TNJob * len(mine))(*[j for j, _ in mine])
-        with torch.cuda.stream(self._side):
-            lib.call("siss_gemm_tn_grouped_capped", jobs, len(mine), int(self.side_blocks) & ~7)
-        still = {id(getattr(dy, "buf", None)) for _, (dy, _x) in self._wq}
-        for _, (dy, _x) in mine:                          # their cotangent operands stay out of the pool until the join
-            buf = getattr(dy, "buf", None)
-            if buf is not None and id(buf) in self._held:
-                self._side_held[id(buf)] = self._held[id(buf)]
-                if id(buf) not in still:                  # (a job left in the queue may read the same cotangent: both hold it then)
-                    self._held.pop(id(buf))
-        keep = []
-        for a in self._held_release:
-            (self._side_release if (id(a.buf) in self._side_held and id(a.buf) not in self._held) else keep).append(a)
-        self._held_release = keep
-        self._side_busy = True
-
     def _flush_wgrads(self):
-        """Run the queued weight-gradient products as grouped launches and give their operands back to the pool."""
+        """Run the queued weight-gradient products as grouped launches and give their operands back to the pool -- or, in a backward
+        pass with background weight gradients (wgrad_side), hand them to the side stream: capped grouped launches behind
+        everything this stream has issued so far; their operands return at the join."""
+        if self._wq and self._side_on:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(torch.cuda.current_stream())
+            jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
+            with torch.cuda.stream(self._side):
+                lib.call("siss_gemm_tn_grouped_capped", jobs, len(self._wq), int(self.side_blocks) & ~7)
+            self._wq, self._wq_gflop, self._side_busy = [], 0.0, True
+            self._side_held.update(self._held)
+            self._side_release += self._held_release
+            self._held, self._held_release = {}, []
+            return
         if self._wq:
             jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
             lib.call("siss_gemm_tn_grouped", jobs, len(self._wq))
-            self._wq = []
+            self._wq, self._wq_gflop = [], 0.0
         for job, _ in self._pair1:                      # one-panel top-resolution products that found no 3-tap partner: on their own
             self._launch_tn_job(job)
         self._pair1 = []
@@ -509,6 +488,14 @@ class UNetEngine:
         rel, self._held_release = self._held_release, []
         for a in rel:
             self._put(a)                                  # (one the side stream still reads goes to ITS release list: _put checks)
+
+    def _queue_side(self, job, dy, x):
+        self._wq.append((job, (dy, x)))
+        if getattr(dy, "buf", None) is not None:
+            self._held[id(dy.buf)] = dy
+        self._wq_gflop += 2e-9 * job.N * job.C * job.npanels * job.nsets * (job.row_end - job.row_begin)
+        if self._wq_gflop >= self.side_flush_gflop or len(self._wq) >= self.side_flush_jobs:
+            self._flush_wgrads()
 
     def _launch_tn_job(self, job):
         lib.call("siss_gemm_tn", job.Y, job.ldy, job.X, job.ldx, job.dW, job.set_stride, job.N, job.C, job.npanels,
@@ -720,6 +707,20 @@ class UNetEngine:
         ns = ops._nsplits(tiles, t, self.nsets, re - rb, ops.is_conv3_panels(shifts, coffs))
         sh, cf, zp = lib.int_array(shifts), lib.int_array(coffs), ops.zero_page(self.device)
         nsets = self.nsets
+        if self._side_on and isinstance(dy, Act):
+            # background weight gradients: every product is queued for the side stream.  Splits: one round of the side stream's
+            # workgroups per job (blocks of at least 16 K-steps) -- a capped launch walks its blocks job after job
+            base = tiles * (t // 3 if ops.is_conv3_panels(shifts, coffs) else t) * nsets
+            nsp = max(1, min(-(-(re - rb) // 1024), (int(self.side_blocks) & ~7) // base))
+            if re - rb <= 8192:
+                nsp = 0                                 # short reductions: the library's own choice (one split that owns its tile: no atomics)
+            self._queue_side(lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
+                                       dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
+                                       rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=nsp, x_set_rows=x_set_rows,
+                                       zero_page=zp.data_ptr(), dbias=dbias.data_ptr() if dbias is not None else None,
+                                       dbias2=dbias2.data_ptr() if dbias2 is not None else None,
+                                       shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t)))), dy, x)
+            return
         if self.group_rows and re - rb <= self.group_rows and isinstance(dy, Act):
             job = lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
                             dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
@@ -729,7 +730,7 @@ class UNetEngine:
                             shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t))))
             self._wq.append((job, (dy, x)))
             self._held[id(dy.buf)] = dy
-            if len(self._wq) >= self.group_max and not self._in_side_window:
+            if len(self._wq) >= self.group_max:
                 self._flush_wgrads()
             return
         if (self.pair_top and not self.f32 and isinstance(dy, Act) and re - rb >= self.pair_min_rows
@@ -1026,7 +1027,8 @@ class UNetEngine:
                                            row_begin=0, row_end=si * S, nsplits=0, x_set_rows=xsr, zero_page=zp.data_ptr(),
                                            dbias=ps.g(pre + ".to_q.bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
                                  (dqkv, hn)))
-                if len(self._wq) >= self.group_max and not self._in_side_window:
+                self._wq_gflop += 2e-9 * 3 * C * C * ns * si * S
+                if len(self._wq) >= self.group_max or (self._side_on and self._wq_gflop >= self.side_flush_gflop):
                     self._flush_wgrads()
             else:
                 lib.call("siss_gemm_tn", dqkv, 3 * C, hn, C, dW, ps.total, 3 * C, C, 1, lib.int_array([0]), lib.int_array([0]),
@@ -1250,7 +1252,7 @@ class UNetEngine:
         self.tape, self.gmap, self._uid = [], {}, 0
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
-        self._side_mark, self._side_end, self._in_side_window = None, None, False
+        self._wq_gflop = 0.0
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
@@ -1262,8 +1264,6 @@ class UNetEngine:
         for (i, cin_b, cout_b, attn, down) in self.plan_down:
             if self._early_mark is None and f"down_blocks.{i}." in early:
                 self._early_mark = len(self.tape)      # closures from here on belong to the early-final group
-            if self._side_end is None and h.h * h.w <= self.side_max_px:
-                self._side_end = len(self.tape)        # ... and from here up to _side_mark: the low-resolution middle (side-stream window)
             for j in range(cfg.layers_per_block):
                 # a conv-produced skip is written straight into the tail columns of the concat buffer it ends up in
                 h = self.resnet(h, f"down_blocks.{i}.resnets.{j}", skip_head=None if attn else heads[len(skips)])
@@ -1277,8 +1277,6 @@ class UNetEngine:
         h = self.attention(h, "mid_block.attentions.0")
         h = self.resnet(h, "mid_block.resnets.1", cat_with=skips[-1])
         for (i, cout_b, attn, up, rs) in self.plan_up:
-            if self._side_mark is None and h.h * h.w > self.side_max_px:
-                self._side_mark = len(self.tape)       # the closures below this index are the low-resolution middle of the backward pass
             for j in range(len(rs)):
                 h = self.concat(h, skips.pop())
                 # a resnet whose output goes straight into the next concat (no attention / upsample in between)
@@ -1358,7 +1356,16 @@ class UNetEngine:
             rows_per_set = self.set_images * col.rows_per_image
             rb, re = col.wp + 1, rows_per_set - (col.wp + 1)
             ns = ops._nsplits(1, 1, self.nsets, re - rb, False)
-            if self.pair_top and not self.f32 and re - rb >= self.pair_min_rows:
+            if self._side_on:
+                zp = ops.zero_page(self.device)
+                z9 = (lib.I * 9)(*([0] * 9))
+                nsp = max(1, min(-(-(re - rb) // 1024), (int(self.side_blocks) & ~7) // self.nsets))
+                self._queue_side(lib.TNJob(Y=col.data.data_ptr(), ldy=kc, X=a.data.data_ptr(), ldx=c0,
+                                           dW=ps.grads[gb:, ps.specs["conv_out.weight"].off:].data_ptr(), set_stride=ps.total,
+                                           N=9 * co, C=c0, npanels=1, nsets=self.nsets, rows_per_set=rows_per_set, row_begin=rb,
+                                           row_end=re, nsplits=nsp, x_set_rows=rows_per_set if a.n == nb else 0,
+                                           zero_page=zp.data_ptr(), dbias=None, dbias2=None, shifts=z9, coffs=z9), col, a)
+            elif self.pair_top and not self.f32 and re - rb >= self.pair_min_rows:
                 zp = ops.zero_page(self.device)
                 z9 = (lib.I * 9)(*([0] * 9))
                 self._pair1.append((lib.TNJob(Y=col.data.data_ptr(), ldy=kc, X=a.data.data_ptr(), ldx=c0,
@@ -1401,20 +1408,25 @@ class UNetEngine:
         self.dtp_all = self._buf("temb.dtp_all", (nb, self.temb_ntot))
         self.dtp_all.zero_()
         mark = getattr(self, "_early_mark", None)
-        side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32) else -1
-        side_end = (self._side_end or 0) - 1
+        # background weight gradients: the side stream takes side_blocks CUs for the whole pass, the persistent 3x3 kernel of this
+        # stream is sized to the rest (its grid is one block per CU with a static tile map: blocks that had to wait for a CU the side
+        # stream holds would finish a round late)
+        cap = int(self.side_blocks) & ~7
+        self._side_on = bool(self.wgrad_side and not self.f32 and cap >= 8 and self.device.type == "cuda")
+        if self._side_on:
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            self._side_on = cap + 8 <= ncu
+        if self._side_on:
+            lib.query("siss_gemm_nt_set_c3p_blocks", (ncu - cap) & ~7)
         for idx in range(len(self.tape) - 1, -1, -1):
-            if idx == side_at:
-                self._flush_wgrads_side()               # the weight gradients queued so far run beside the low-resolution blocks
-                self._in_side_window = self._side_busy  # (no grouped launch on THIS stream inside the window: it would take the CUs)
-            if idx == side_end:
-                self._in_side_window = False
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail
                 self._join_side()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
-        self._in_side_window = False
         self._flush_wgrads()
+        if self._side_on:
+            lib.query("siss_gemm_nt_set_c3p_blocks", 0)
+            self._side_on = False
         self._join_side()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"
