@@ -272,10 +272,11 @@ def test_bf16_io_mode_and_graph_replay(setup):
 
 
 def test_background_weight_gradients_equal_the_one_stream_schedule(setup):
-    """UNetEngine.wgrad_side: every weight gradient of the backward pass is queued and streamed to a SIDE stream as capped grouped
-    launches (siss_gemm_tn_grouped_capped: here 8 workgroups walking all blocks, a flush per ~2 jobs) beside the dgrad / GroupNorm
-    chain, joined at the end of the pass.  Same products, same operands: both gradient sets equal the one-stream schedule's to f32
-    rounding (float atomics) -- eagerly, and replayed from a hipGraph whose capture forks to the side stream and joins it."""
+    """UNetEngine.wgrad_side: the weight gradients are queued, and in front of every GroupNorm-backward launch a slice of the queue
+    (ROW RANGES of the oldest jobs: here 2048 rows at a time, so that jobs are cut into several slices that add up through float
+    atomics) runs on a SIDE stream as a capped grouped launch (8 workgroups walking all blocks) beside it; the rest at the end of
+    the pass.  Same products, same operands: both gradient sets equal the one-stream schedule's to f32 rounding -- eagerly, and
+    replayed from a hipGraph whose capture forks to the side stream and joins it at every window."""
     eng, _, sd = _fresh(setup)
     g = torch.Generator().manual_seed(21)
     B = 4
@@ -289,12 +290,11 @@ def test_background_weight_gradients_equal_the_one_stream_schedule(setup):
         eng.backward(cot, nsets=2)
         torch.cuda.synchronize()
         return eng.ps.grads.clone()
-    saved = (eng.wgrad_side, eng.side_blocks, eng.side_flush_jobs)
+    saved = (eng.wgrad_side, eng.side_blocks, eng.side_min_us)
     try:
         eng.wgrad_side = False
         ref = run()
-        assert not eng._side_busy
-        eng.wgrad_side, eng.side_blocks, eng.side_flush_jobs = True, 8, 2
+        eng.wgrad_side, eng.side_blocks, eng.side_min_us = True, 8, 0
         got = run()
         assert eng._side is not None, "the side stream must have been used"
         scale = float(ref.abs().max())
@@ -315,7 +315,7 @@ def test_background_weight_gradients_equal_the_one_stream_schedule(setup):
         torch.cuda.synchronize()
         assert float((eng.ps.grads - ref).abs().max()) <= 1e-5 * scale
     finally:
-        eng.wgrad_side, eng.side_blocks, eng.side_flush_jobs = saved
+        eng.wgrad_side, eng.side_blocks, eng.side_min_us = saved
 
 
 def test_mnist_tshirt_config_step_matches_oracle():
