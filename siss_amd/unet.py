@@ -182,17 +182,13 @@ class UNetEngine:
     # One-panel weight gradients at the TOP resolution (a resnet's 1x1 conv_shortcut, conv_out, conv_in: HBM-bound launches at
     # 200-520 TF/s) wait for the next fused 3-tap weight gradient and ride in ITS launch (siss_gemm_tn_pair: one round of blocks
     # shared by the two products; the streaming one-tap blocks run beside MFMA-bound 3-tap blocks)
-    # WEIGHT GRADIENTS BESIDE THE GROUPNORM BACKWARD (round 5).  The GroupNorm-backward launches are HBM-bound -- 10.7 ms of the step
-    # with the matrix cores idle -- and nothing in the backward pass waits for a weight gradient (they only feed the flat gradient
-    # buffer).  With wgrad_side every weight-gradient product is QUEUED; in front of each GroupNorm-backward launch a slice of the
-    # queue sized to that launch's duration (row ranges of the oldest jobs: side_rate GFLOP per us and CU x side_blocks CUs x the
-    # launch's estimated us) goes to a SIDE stream as a grouped launch capped at side_blocks workgroups and runs beside it; this
-    # stream waits for it behind the GroupNorm launch, so MFMA-bound kernels never share the chip.  What the windows do not absorb is
-    # launched at the end of the pass as before.  False / 0 blocks: the one-stream schedule.
+    # The low-resolution middle of the backward pass (up / mid / down blocks at <= side_max_px pixels: grids of 13-160 tiles that leave
+    # most CUs idle) runs BESIDE the weight gradients queued so far (the 32 x 32 .. 128 x 128 up blocks': ~3 ms of MFMA-bound work that
+    # nothing waits for): they go to a side stream as grouped launches capped at side_blocks workgroups (= CUs), and join at the end of
+    # the pass.  0 blocks = off.
     wgrad_side = True
-    side_blocks = 128
-    side_rate = 4.0            # MFLOP per us and CU a capped weight-gradient launch sustains beside a GroupNorm launch (x 1e-3: GFLOP)
-    side_min_us = 50           # GroupNorm launches shorter than this get no slice
+    side_blocks = 96
+    side_max_px = 256
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
@@ -227,8 +223,7 @@ class UNetEngine:
         self.on_early_grads_final = None
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
-        self._side, self._side_busy, self._side_held, self._side_release = None, False, {}, []
-        self._side_on, self._wq_gflop = False, 0.0
+        self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -461,18 +456,32 @@ class UNetEngine:
         for a in rel:
             self._put(a)
 
+    def _flush_wgrads_side(self):
+        """The queued weight-gradient products as CAPPED grouped launches on the side stream (behind everything issued so far)."""
+        if not self._wq:
+            return
+        if not (self.wgrad_side and self.side_blocks >= 8) or self.f32:
+            return self._flush_wgrads()
+        self._join_side()                                 # one batch at a time
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
+        with torch.cuda.stream(self._side):
+            lib.call("siss_gemm_tn_grouped_capped", jobs, len(self._wq), int(self.side_blocks) & ~7)
+        for _, (dy, _x) in self._wq:                     # their cotangent operands stay out of the pool until the join
+            buf = getattr(dy, "buf", None)
+            if buf is not None and id(buf) in self._held:
+                self._side_held[id(buf)] = self._held.pop(id(buf))
+        keep = []
+        for a in self._held_release:
+            (self._side_release if id(a.buf) in self._side_held else keep).append(a)
+        self._held_release = keep
+        self._wq = []
+        self._side_busy = True
+
     def _flush_wgrads(self):
-        """Run the queued weight-gradient products (grouped launches) and give their operands back to the pool."""
-        if self._wq and self._side_on:
-            # what the GroupNorm windows did not absorb: top-resolution jobs (their remaining rows) as launches of their own -- one
-            # round of blocks each --, the others grouped
-            big = [e for e in self._wq if self.group_rows and e[0].row_end - e[0].row_begin > self.group_rows]
-            self._wq = [e for e in self._wq if not (self.group_rows and e[0].row_end - e[0].row_begin > self.group_rows)]
-            for job, _ in big:
-                job.nsplits = 0
-                self._launch_tn_job(job)
-            for job, _ in self._wq:
-                job.nsplits = 0
+        """Run the queued weight-gradient products as grouped launches and give their operands back to the pool."""
         if self._wq:
             jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
             lib.call("siss_gemm_tn_grouped", jobs, len(self._wq))
@@ -483,61 +492,7 @@ class UNetEngine:
         self._held = {}
         rel, self._held_release = self._held_release, []
         for a in rel:
-            self._put(a)                                  # (one the side stream still reads goes to ITS release list: _put checks)
-
-    def _queue_side(self, job, dy, x):
-        self._wq.append((job, (dy, x)))
-        if getattr(dy, "buf", None) is not None:
-            self._held[id(dy.buf)] = dy
-
-    def _side_window(self, us):
-        """A launch that leaves the matrix cores idle for ~`us` microseconds is about to be issued on this stream: send that much of
-        the queued weight-gradient work (row ranges of the oldest jobs) to the side stream, capped at side_blocks CUs.  Returns
-        the jobs it finished (their operands may be released once this stream has waited for the side stream: _side_done)."""
-        if not (self._side_on and self._wq) or us < self.side_min_us:
-            return None
-        cap = int(self.side_blocks) & ~7
-        budget = us * cap * self.side_rate * 1e-3                 # GFLOP
-        chunks, finished = [], []
-        while self._wq and budget > 0 and len(chunks) < 14:
-            job, ops_ = self._wq[0]
-            per_row = 2e-9 * job.N * job.C * job.npanels * job.nsets
-            left = job.row_end - job.row_begin
-            take = min(left, max(2048, int(budget / per_row) // 64 * 64))
-            if left - take < 2048:
-                take = left                                      # no crumbs
-            if take * per_row > 1.5 * budget and chunks:
-                break
-            ch = lib.TNJob.from_buffer_copy(job)
-            ch.row_end = job.row_begin + take
-            fused3 = job.npanels % 3 == 0 and ops.is_conv3_panels(list(job.shifts)[:job.npanels], list(job.coffs)[:job.npanels])
-            base = (-(-job.N // 128)) * (-(-job.C // 128)) * (job.npanels // 3 if fused3 else job.npanels) * job.nsets
-            ch.nsplits = max(1, min(-(-take // 1024), cap // base)) if take > 8192 else 0
-            if ch.row_begin > job.row_begin or take < left:
-                ch.nsplits = max(1, ch.nsplits)                  # a partial range ADDS to what other slices leave: atomics, never overwrite
-            chunks.append(ch)
-            budget -= take * per_row
-            job.row_begin += take
-            if take == left:
-                finished.append(self._wq.pop(0))
-        if not chunks:
-            return None
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        self._side.wait_stream(torch.cuda.current_stream())
-        arr = (lib.TNJob * len(chunks))(*chunks)
-        with torch.cuda.stream(self._side):
-            lib.call("siss_gemm_tn_grouped_capped", arr, len(chunks), cap)
-        return finished
-
-    def _side_done(self, finished):
-        """This stream waits for the side stream's slice (issued behind the launch it ran beside); finished jobs release their operands."""
-        if finished is None:
-            return
-        torch.cuda.current_stream().wait_stream(self._side)
-        for _, (dy, _x) in finished:
-            if getattr(dy, "buf", None) is not None and not any(e[1][0] is dy for e in self._wq):
-                self._unhold(dy)
+            self._put(a)
 
     def _launch_tn_job(self, job):
         lib.call("siss_gemm_tn", job.Y, job.ldy, job.X, job.ldx, job.dW, job.set_stride, job.N, job.C, job.npanels,
@@ -636,15 +591,12 @@ class UNetEngine:
                 dx = accum if (accum is not None and not held) else self._get(nb, x.h, x.w, x.c)
                 dx2p, split_c, accb = None, 0, False
             dyp = dy.data if isinstance(dy, Act) else dy
-            # this launch streams 2 (x + dy) + dx through HBM with the matrix cores idle: a slice of the queued weight gradients runs beside it
-            fin = self._side_window(x.h * x.w * x.c * 2e-6 * (2 * (nb + x.n) + nb) / 4.6) if self._side_on else None
             lib.call("siss_groupnorm_bwd_ld_s2d" if s2d else "siss_groupnorm_bwd_ld", dyp, x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), mean, rstd,
                      dx.data, accum.data if accum is not None else None,
                      accum2.data if accum2 is not None else None, dx2p, split_c, int(accb),
                      ps.g(pre + ".weight", self.gbase), ps.g(pre + ".bias", self.gbase), colsum, colsum_ld,
                      self._gn_partial(nb, x.h, x.w, x.c), nb, x.n, self.set_images, ps.total,
                      x.h, x.w, x.c, G, int(silu), int(not isinstance(dy, Act)), 0 if ldx == x.c else ldx)
-            self._side_done(fin)
             if held and split is None:
                 self._put(accum)                        # read only here: released once the queued wgrad has run
             return dx
@@ -752,14 +704,6 @@ class UNetEngine:
         ns = ops._nsplits(tiles, t, self.nsets, re - rb, ops.is_conv3_panels(shifts, coffs))
         sh, cf, zp = lib.int_array(shifts), lib.int_array(coffs), ops.zero_page(self.device)
         nsets = self.nsets
-        if self._side_on and isinstance(dy, Act):
-            self._queue_side(lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
-                                       dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
-                                       rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=0, x_set_rows=x_set_rows,
-                                       zero_page=zp.data_ptr(), dbias=dbias.data_ptr() if dbias is not None else None,
-                                       dbias2=dbias2.data_ptr() if dbias2 is not None else None,
-                                       shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t)))), dy, x)
-            return
         if self.group_rows and re - rb <= self.group_rows and isinstance(dy, Act):
             job = lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
                             dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
@@ -1066,7 +1010,7 @@ class UNetEngine:
                                            row_begin=0, row_end=si * S, nsplits=0, x_set_rows=xsr, zero_page=zp.data_ptr(),
                                            dbias=ps.g(pre + ".to_q.bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
                                  (dqkv, hn)))
-                if len(self._wq) >= self.group_max and not self._side_on:
+                if len(self._wq) >= self.group_max:
                     self._flush_wgrads()
             else:
                 lib.call("siss_gemm_tn", dqkv, 3 * C, hn, C, dW, ps.total, 3 * C, C, 1, lib.int_array([0]), lib.int_array([0]),
@@ -1290,7 +1234,7 @@ class UNetEngine:
         self.tape, self.gmap, self._uid = [], {}, 0
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
-        self._wq_gflop = 0.0
+        self._side_mark = None
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
         self.time_embed(t)
@@ -1315,6 +1259,8 @@ class UNetEngine:
         h = self.attention(h, "mid_block.attentions.0")
         h = self.resnet(h, "mid_block.resnets.1", cat_with=skips[-1])
         for (i, cout_b, attn, up, rs) in self.plan_up:
+            if self._side_mark is None and h.h * h.w > self.side_max_px:
+                self._side_mark = len(self.tape)       # the closures below this index are the low-resolution middle of the backward pass
             for j in range(len(rs)):
                 h = self.concat(h, skips.pop())
                 # a resnet whose output goes straight into the next concat (no attention / upsample in between)
@@ -1394,15 +1340,7 @@ class UNetEngine:
             rows_per_set = self.set_images * col.rows_per_image
             rb, re = col.wp + 1, rows_per_set - (col.wp + 1)
             ns = ops._nsplits(1, 1, self.nsets, re - rb, False)
-            if self._side_on:
-                zp = ops.zero_page(self.device)
-                z9 = (lib.I * 9)(*([0] * 9))
-                self._queue_side(lib.TNJob(Y=col.data.data_ptr(), ldy=kc, X=a.data.data_ptr(), ldx=c0,
-                                           dW=ps.grads[gb:, ps.specs["conv_out.weight"].off:].data_ptr(), set_stride=ps.total,
-                                           N=9 * co, C=c0, npanels=1, nsets=self.nsets, rows_per_set=rows_per_set, row_begin=rb,
-                                           row_end=re, nsplits=0, x_set_rows=rows_per_set if a.n == nb else 0,
-                                           zero_page=zp.data_ptr(), dbias=None, dbias2=None, shifts=z9, coffs=z9), col, a)
-            elif self.pair_top and not self.f32 and re - rb >= self.pair_min_rows:
+            if self.pair_top and not self.f32 and re - rb >= self.pair_min_rows:
                 zp = ops.zero_page(self.device)
                 z9 = (lib.I * 9)(*([0] * 9))
                 self._pair1.append((lib.TNJob(Y=col.data.data_ptr(), ldy=kc, X=a.data.data_ptr(), ldx=c0,
@@ -1445,13 +1383,15 @@ class UNetEngine:
         self.dtp_all = self._buf("temb.dtp_all", (nb, self.temb_ntot))
         self.dtp_all.zero_()
         mark = getattr(self, "_early_mark", None)
-        cap = int(self.side_blocks) & ~7
-        self._side_on = bool(self.wgrad_side and not self.f32 and cap >= 8 and self.device.type == "cuda")
+        side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32) else -1
         for idx in range(len(self.tape) - 1, -1, -1):
+            if idx == side_at:
+                self._flush_wgrads_side()               # the weight gradients queued so far run beside the low-resolution blocks
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail
+                self._join_side()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
         self._flush_wgrads()
-        self._side_on = False
+        self._join_side()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"

@@ -143,7 +143,7 @@ class UNetCondEngine(UNetEngine):
                                        zero_page=zp.data_ptr(),
                                        dbias=ps.g(wname + ".bias", gb).data_ptr() if bias else None, dbias2=None,
                                        shifts=z9, coffs=z9), (dy, xin)))
-            if len(self._wq) >= self.group_max and not self._side_on:
+            if len(self._wq) >= self.group_max:
                 self._flush_wgrads()
         else:
             lib.call("siss_gemm_tn", dy, n_out, xin, k_in, dW, ps.total, n_out, k_in, 1, lib.int_array([0]),

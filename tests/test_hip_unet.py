@@ -271,12 +271,12 @@ def test_bf16_io_mode_and_graph_replay(setup):
     assert rep["step"] == 1
 
 
-def test_background_weight_gradients_equal_the_one_stream_schedule(setup):
-    """UNetEngine.wgrad_side: the weight gradients are queued, and in front of every GroupNorm-backward launch a slice of the queue
-    (ROW RANGES of the oldest jobs: here 2048 rows at a time, so that jobs are cut into several slices that add up through float
-    atomics) runs on a SIDE stream as a capped grouped launch (8 workgroups walking all blocks) beside it; the rest at the end of
-    the pass.  Same products, same operands: both gradient sets equal the one-stream schedule's to f32 rounding -- eagerly, and
-    replayed from a hipGraph whose capture forks to the side stream and joins it at every window."""
+def test_side_stream_weight_gradients_equal_the_main_stream_schedule(setup):
+    """UNetEngine.wgrad_side: the weight gradients queued before the low-resolution middle of the backward pass run on a SIDE stream
+    as capped grouped launches (siss_gemm_tn_grouped_capped: 8 workgroups walking all blocks) beside it and join at the end.  Same
+    products, same operands: both gradient sets equal the one-stream schedule's to f32 rounding (float atomics) -- eagerly and
+    replayed from a hipGraph whose capture forks to the side stream and joins it.  (side_max_px lowered so that the toy network,
+    8 x 8 / 16 x 16, has a 'low-resolution middle' at all.)"""
     eng, _, sd = _fresh(setup)
     g = torch.Generator().manual_seed(21)
     B = 4
@@ -290,13 +290,13 @@ def test_background_weight_gradients_equal_the_one_stream_schedule(setup):
         eng.backward(cot, nsets=2)
         torch.cuda.synchronize()
         return eng.ps.grads.clone()
-    saved = (eng.wgrad_side, eng.side_blocks, eng.side_min_us)
+    saved = (eng.wgrad_side, eng.side_max_px, eng.side_blocks)
     try:
         eng.wgrad_side = False
         ref = run()
-        eng.wgrad_side, eng.side_blocks, eng.side_min_us = True, 8, 0
+        eng.wgrad_side, eng.side_max_px, eng.side_blocks = True, 64, 8
         got = run()
-        assert eng._side is not None, "the side stream must have been used"
+        assert eng._side is not None and eng._side_mark is not None, "the side stream must have been used"
         scale = float(ref.abs().max())
         assert float((got - ref).abs().max()) <= 1e-5 * scale
         # ... and under capture: fork to the side stream, join before the capture ends
@@ -315,7 +315,7 @@ def test_background_weight_gradients_equal_the_one_stream_schedule(setup):
         torch.cuda.synchronize()
         assert float((eng.ps.grads - ref).abs().max()) <= 1e-5 * scale
     finally:
-        eng.wgrad_side, eng.side_blocks, eng.side_min_us = saved
+        eng.wgrad_side, eng.side_max_px, eng.side_blocks = saved
 
 
 def test_mnist_tshirt_config_step_matches_oracle():
