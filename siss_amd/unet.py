@@ -189,6 +189,7 @@ class UNetEngine:
     wgrad_side = True
     side_blocks = 96
     side_max_px = 256
+    side_follow = 0            # 1: the grouped launches that fill up AFTER that batch go to the side stream too (behind it)
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
@@ -462,7 +463,6 @@ class UNetEngine:
             return
         if not (self.wgrad_side and self.side_blocks >= 8) or self.f32:
             return self._flush_wgrads()
-        self._join_side()                                 # one batch at a time
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         self._side.wait_stream(torch.cuda.current_stream())
@@ -714,7 +714,7 @@ class UNetEngine:
             self._wq.append((job, (dy, x)))
             self._held[id(dy.buf)] = dy
             if len(self._wq) >= self.group_max:
-                self._flush_wgrads()
+                self._flush_wgrads_side() if (self._side_busy and self.side_follow) else self._flush_wgrads()
             return
         if (self.pair_top and not self.f32 and isinstance(dy, Act) and re - rb >= self.pair_min_rows
                 and (t == 1 or (ops.is_conv3_panels(shifts, coffs) and self._pair1))):
@@ -1011,7 +1011,7 @@ class UNetEngine:
                                            dbias=ps.g(pre + ".to_q.bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
                                  (dqkv, hn)))
                 if len(self._wq) >= self.group_max:
-                    self._flush_wgrads()
+                    self._flush_wgrads_side() if (self._side_busy and self.side_follow) else self._flush_wgrads()
             else:
                 lib.call("siss_gemm_tn", dqkv, 3 * C, hn, C, dW, ps.total, 3 * C, C, 1, lib.int_array([0]), lib.int_array([0]),
                          ns, si * S, xsr, 0, si * S, 0, zp, ps.g(pre + ".to_q.bias", gb), None)
