@@ -182,14 +182,22 @@ class UNetEngine:
     # One-panel weight gradients at the TOP resolution (a resnet's 1x1 conv_shortcut, conv_out, conv_in: HBM-bound launches at
     # 200-520 TF/s) wait for the next fused 3-tap weight gradient and ride in ITS launch (siss_gemm_tn_pair: one round of blocks
     # shared by the two products; the streaming one-tap blocks run beside MFMA-bound 3-tap blocks)
-    # The low-resolution middle of the backward pass (up / mid / down blocks at <= side_max_px pixels: grids of 13-160 tiles that leave
-    # most CUs idle) runs BESIDE the weight gradients queued so far (the 32 x 32 .. 128 x 128 up blocks': ~3 ms of MFMA-bound work that
-    # nothing waits for): they go to a side stream as grouped launches capped at side_blocks workgroups (= CUs), and join at the end of
-    # the pass.  0 blocks = off.
+    # WEIGHT GRADIENTS ON A SIDE STREAM (round 5).  Nothing in the backward pass waits for a weight gradient (they only feed the flat
+    # gradient buffer), and the low-resolution middle of the pass (up / mid / down blocks at <= side_max_px pixels: grids of 13-160
+    # tiles on a 256-CU chip, GroupNorm slabs, attention) leaves most CUs idle.  When the pass enters it, the grouped launches queued
+    # so far (the 32 x 32 .. 128 x 128 up blocks': ~3 ms of MFMA-bound work) go to a SIDE stream, capped at side_blocks workgroups
+    # (siss_gemm_tn_grouped_capped: that many CUs, the rest stays with this stream), and the grouped launches that fill up later follow
+    # them there (side_follow); everything joins at the end of the pass; the cotangent operands stay out of the buffer pool until then.
+    # Same-box sweeps (CelebA-HQ B = 16, ms per step; one-stream schedule 54.05-54.15): first batch only, 72 / 96 / 120 blocks:
+    # 53.74 / 53.35 / 53.39; with side_follow 64 / 96 / 112 / 128 / 144 / 160 / 192 / 224 blocks: 54.60 / 53.37 / 53.01 / 52.79-52.82 /
+    # 53.04 / 53.22 / 53.47 / 53.97; entering at 32 x 32 (side_max_px 1024): 53.09; smaller batches (group_max 24): 54.0.
+    # What did NOT pay (docs/experiments.md, round 5): every weight gradient streamed to the side stream for the whole pass with the
+    # persistent 3x3 kernel sized to the remaining CUs (59-71 ms), and slices of the queue beside each GroupNorm-backward launch
+    # (54.2-56.0 ms: those launches are bound by what their resident waves keep in flight, i.e. by the CUs they lose).
     wgrad_side = True
-    side_blocks = 96
+    side_blocks = 128
     side_max_px = 256
-    side_follow = 0            # 1: the grouped launches that fill up AFTER that batch go to the side stream too (behind it)
+    side_follow = 1            # the grouped launches that fill up AFTER the first batch go to the side stream too (behind it)
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 

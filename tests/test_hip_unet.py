@@ -276,7 +276,8 @@ def test_side_stream_weight_gradients_equal_the_main_stream_schedule(setup):
     as capped grouped launches (siss_gemm_tn_grouped_capped: 8 workgroups walking all blocks) beside it and join at the end.  Same
     products, same operands: both gradient sets equal the one-stream schedule's to f32 rounding (float atomics) -- eagerly and
     replayed from a hipGraph whose capture forks to the side stream and joins it.  (side_max_px lowered so that the toy network,
-    8 x 8 / 16 x 16, has a 'low-resolution middle' at all.)"""
+    8 x 8 / 16 x 16, has a 'low-resolution middle' at all; group_max lowered so that several later batches FOLLOW the first one to
+    the side stream: side_follow.)"""
     eng, _, sd = _fresh(setup)
     g = torch.Generator().manual_seed(21)
     B = 4
@@ -290,11 +291,11 @@ def test_side_stream_weight_gradients_equal_the_main_stream_schedule(setup):
         eng.backward(cot, nsets=2)
         torch.cuda.synchronize()
         return eng.ps.grads.clone()
-    saved = (eng.wgrad_side, eng.side_max_px, eng.side_blocks)
+    saved = (eng.wgrad_side, eng.side_max_px, eng.side_blocks, eng.group_max, eng.side_follow)
     try:
         eng.wgrad_side = False
         ref = run()
-        eng.wgrad_side, eng.side_max_px, eng.side_blocks = True, 64, 8
+        eng.wgrad_side, eng.side_max_px, eng.side_blocks, eng.group_max, eng.side_follow = True, 64, 8, 3, 1
         got = run()
         assert eng._side is not None and eng._side_mark is not None, "the side stream must have been used"
         scale = float(ref.abs().max())
@@ -315,7 +316,7 @@ def test_side_stream_weight_gradients_equal_the_main_stream_schedule(setup):
         torch.cuda.synchronize()
         assert float((eng.ps.grads - ref).abs().max()) <= 1e-5 * scale
     finally:
-        eng.wgrad_side, eng.side_max_px, eng.side_blocks = saved
+        eng.wgrad_side, eng.side_max_px, eng.side_blocks, eng.group_max, eng.side_follow = saved
 
 
 def test_mnist_tshirt_config_step_matches_oracle():
