@@ -233,6 +233,7 @@ class UNetEngine:
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
+        self._side_phase = False
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -722,7 +723,7 @@ class UNetEngine:
             self._wq.append((job, (dy, x)))
             self._held[id(dy.buf)] = dy
             if len(self._wq) >= self.group_max:
-                self._flush_wgrads_side() if (self._side_busy and self.side_follow) else self._flush_wgrads()
+                self._flush_wgrads_side() if (self._side_phase and self.side_follow) else self._flush_wgrads()
             return
         if (self.pair_top and not self.f32 and isinstance(dy, Act) and re - rb >= self.pair_min_rows
                 and (t == 1 or (ops.is_conv3_panels(shifts, coffs) and self._pair1))):
@@ -1019,7 +1020,7 @@ class UNetEngine:
                                            dbias=ps.g(pre + ".to_q.bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
                                  (dqkv, hn)))
                 if len(self._wq) >= self.group_max:
-                    self._flush_wgrads_side() if (self._side_busy and self.side_follow) else self._flush_wgrads()
+                    self._flush_wgrads_side() if (self._side_phase and self.side_follow) else self._flush_wgrads()
             else:
                 lib.call("siss_gemm_tn", dqkv, 3 * C, hn, C, dW, ps.total, 3 * C, C, 1, lib.int_array([0]), lib.int_array([0]),
                          ns, si * S, xsr, 0, si * S, 0, zp, ps.g(pre + ".to_q.bias", gb), None)
@@ -1394,12 +1395,14 @@ class UNetEngine:
         side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32) else -1
         for idx in range(len(self.tape) - 1, -1, -1):
             if idx == side_at:
+                self._side_phase = True
                 self._flush_wgrads_side()               # the weight gradients queued so far run beside the low-resolution blocks
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail
                 self._join_side()
                 self.on_early_grads_final()         # grads[:, ps.split:] are complete (data-parallel overlap hook)
+        self._side_phase = False
         self._flush_wgrads()
         self._join_side()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"

@@ -55,6 +55,7 @@ class VAEEncoder(UNetEngine):
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
+        self._side_phase = False
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
