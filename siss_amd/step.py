@@ -191,7 +191,7 @@ class SISSStepper:
         e = self.e
         cond = dict(conditioning or {})
         if self._micro == 0:
-            e.zero_grad()
+            e.zero_grad(beside_forward=True)           # (909 MB of HBM writes beside the forward pass; joined by the backward pass)
         x0, a0, noise = (v.to(device=e.device, dtype=self.io_dtype).contiguous() for v in (x0, a0, noise))
         B = x0.shape[0]
         scale = 1.0 / (self.train_batch_size * self.world * self.ga)
@@ -323,7 +323,7 @@ class SISSStepper:
             self.e.refresh_weights(cast_shadow=True)
             return
         self.opt.launch(g, **okw)
-        self.e.refresh_weights()
+        self.e.refresh_weights(lazy=True)               # (the dgrad weight copies: beside the next forward pass)
 
     def step(self, x0, a0, noise, t, u, conditioning=None, erase_target=None):
         """GA=1 convenience."""

@@ -198,6 +198,10 @@ class UNetEngine:
     side_blocks = 128
     side_max_px = 256
     side_follow = 1            # the grouped launches that fill up AFTER the first batch go to the side stream too (behind it)
+    # The step's preparation work that only the BACKWARD pass needs -- zeroing the 909-MB gradient pair, the transposed dgrad weight
+    # copies -- runs on the side stream beside the forward pass (HBM-bound fills and copies beside MFMA-bound convolutions) and is
+    # joined at the start of the backward pass (SISSStepper asks for it: zero_grad(beside_forward=True), refresh_weights(lazy=True))
+    prep_side = True
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
@@ -234,6 +238,7 @@ class UNetEngine:
         self._pair1 = []
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._side_phase = False
+        self._prep_pending, self._wT_stale = False, False
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -362,12 +367,28 @@ class UNetEngine:
     def state_dict(self):
         return self.ps.state_dict()
 
-    def refresh_weights(self, cast_shadow=False):
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def refresh_weights(self, cast_shadow=False, lazy=False):
         """bf16 operand copies derived from the f32 master: the fprop shadow (optionally; the fused
-        AdamW kernel already refreshes it) and the transposed/flipped dgrad copies."""
+        AdamW kernel already refreshes it) and the transposed/flipped dgrad copies.  lazy: the copies only the BACKWARD pass reads
+        (dgrad weights) are refreshed by the next forward() on the side stream, beside it (prep_side)."""
         ps = self.ps
         if cast_shadow and not self.f32:                 # (f32 mode: the operand copy IS the master)
             lib.call("siss_cast_f32_bf16", ps.flat, ps.shadow, ps.total)
+        for n, (wf, wd) in self._up_w.items():            # sub-pixel upsample sites: phase weights from the f32 master (f32 sums, one rounding)
+            lib.call("siss_upsample_phase_weights", ps.p(n), wf, wd, wf.shape[2], wf.shape[3])
+        if lazy and self.prep_side and self.wT and self.device.type == "cuda":
+            self._wT_stale = True
+            return
+        self._refresh_dgrad_copies()
+
+    def _refresh_dgrad_copies(self):
+        ps = self.ps
+        self._wT_stale = False
         if not self.wT:
             self._build_wt_jobs()
         # (from the bf16 shadow, which holds the rounded master at this point: cast above, or refreshed by the fused AdamW launch)
@@ -376,8 +397,6 @@ class UNetEngine:
                      self._wt_tiles)
         for pre, (buf, idx) in self._wds.items():
             torch.index_select(self.wT[pre + ".conv.weight"], 0, idx, out=buf)
-        for n, (wf, wd) in self._up_w.items():            # sub-pixel upsample sites: phase weights from the f32 master (f32 sums, one rounding)
-            lib.call("siss_upsample_phase_weights", ps.p(n), wf, wd, wf.shape[2], wf.shape[3])
         # conv_out dgrad operand: Wn^T, [Cin][K = 9*Cout padded to 64] bf16 (k = tap*Cout + co)
         w = ps.p("conv_out.weight")
         k = w.shape[0] * w.shape[1]
@@ -1243,6 +1262,12 @@ class UNetEngine:
         self.tape, self.gmap, self._uid = [], {}, 0
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
+        if self._wT_stale:                             # the dgrad weight copies of the last optimizer step: beside this forward pass
+            st = self._side_stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                self._refresh_dgrad_copies()
+            self._prep_pending = True
         self._side_mark = None
         self.nf = N
         t = t.to(device=self.device, dtype=torch.int64).contiguous()
@@ -1372,7 +1397,15 @@ class UNetEngine:
         self.tape.append(head_bwd)
         return pred
 
-    def zero_grad(self):
+    def zero_grad(self, beside_forward=False):
+        """beside_forward: the fill runs on the side stream (behind everything issued so far) and is joined by the next backward()."""
+        if beside_forward and self.prep_side and self.device.type == "cuda":
+            st = self._side_stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                self.ps.grads.zero_()
+            self._prep_pending = True
+            return
         self.ps.grads.zero_()
 
     def backward(self, cot, nsets=2, grad_base_set=0):
@@ -1387,6 +1420,11 @@ class UNetEngine:
         nb = cot.shape[0]
         assert nb % nsets == 0 and nb % self.nf == 0
         self.nb, self.nsets, self.set_images, self.gbase, self.cot = nb, nsets, nb // nsets, grad_base_set, cot
+        if self._wT_stale:                             # (a backward pass without a forward since the last lazy refresh)
+            self._refresh_dgrad_copies()
+        if self._prep_pending:                         # the gradient fill / dgrad weight copies issued beside the forward pass
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._prep_pending = False
         d_s = self._buf("temb.d_s", (nb, self.temb_dim))
         d_s.zero_()
         self.dtp_all = self._buf("temb.dtp_all", (nb, self.temb_ntot))
