@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int kMaxPanelsF = 9;
+constexpr int kMaxPanelsF = 16;           // (16: the (plane, tap) panels of a sub-pixel upsample convolution's dgrad)
 
 struct NTF {
     const float* A; const float* W; float* C;
@@ -31,7 +31,7 @@ struct NTF {
 // lane group q is k0 + 4 q + j on BOTH operands: any bijection onto the 16 k of a step gives the same sum).
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const NTF p) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int tn = blockIdx.x * 4 + wv, tm = blockIdx.y, bz = blockIdx.z;
+    const int tn = blockIdx.y * 4 + wv, tm = blockIdx.x, bz = blockIdx.z;          // (M tiles on grid.x: no 65535-tile limit on the rows)
     if (tn * 16 >= p.N) return;
     const int m0 = tm * 16, n0 = tn * 16;
     const int li = lane & 15, q = lane >> 4;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const NTF p) {
 
 struct TNF {
     const float* Y; const float* X; float* dW; float* dbias; float* dbias2;
-    long ldy, ldx, set_stride, x_set_rows;
+    long ldy, ldx, set_stride, x_set_rows, bias_stride;
     int N, C, npanels, nsets, rows_per_set, row_begin, row_end, overwrite;
     int shift[kMaxPanelsF], coff[kMaxPanelsF];
 };
@@ -127,8 +127,8 @@ __global__ void tn_bias_f32_kernel(const TNF p) {
     const float* Y = p.Y + ((long)set * p.rows_per_set) * p.ldy + n;
     double a = 0.0;
     for (int r = p.row_begin; r < p.row_end; ++r) a += (double)Y[(long)r * p.ldy];
-    p.dbias[(long)set * p.set_stride + n] += (float)a;
-    if (p.dbias2) p.dbias2[(long)set * p.set_stride + n] += (float)a;
+    p.dbias[(long)set * p.bias_stride + n] += (float)a;
+    if (p.dbias2) p.dbias2[(long)set * p.bias_stride + n] += (float)a;
 }
 
 // ---------------------------------------------------------------- GroupNorm (+ SiLU), one block per (sample, group)
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kGT) void gn_bwd_f32_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx, const float* __restrict__ accum,
     const float* __restrict__ accum2, float* __restrict__ dx2, int split_c, int accumulate2, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ colsum, long colsum_ld, int nsets_per_x, int nx, int set_images, long set_stride,
-    int H, int W, int C, int G, int silu, int dy_compact, long ldx) {
+    int H, int W, int C, int G, int silu, int dy_compact, long ldx, int s2d) {
     __shared__ double sh[kGT / 64];
     const int n = blockIdx.y, g = blockIdx.x, cpg = C / G, c0 = g * cpg;
     const int items = H * W * cpg;
@@ -229,6 +229,12 @@ __global__ __launch_bounds__(kGT) void gn_bwd_f32_kernel(
             if (dx2 && c >= split_c) {
                 float* dst = dx2 + prow * (C - split_c) + (c - split_c);
                 *dst = accumulate2 ? *dst + o : o;
+            } else if (s2d) {
+                // the first part of a split target in space-to-depth layout (groupnorm.hip S2D): pixel (y, x) -> pixel (y / 2, x / 2) of a
+                // half-resolution padded tensor of 4 split_c channels, column plane * split_c + c, plane = 2 (y & 1) + (x & 1)
+                const int y = pi / W, xx = pi - y * W;
+                const long hrow = ((long)n2 * (H / 2 + 2) + y / 2 + 1) * (W / 2 + 2) + xx / 2 + 1;
+                dx[hrow * (4 * split_c) + (2 * (y & 1) + (xx & 1)) * split_c + c] = o;
             } else {
                 dx[prow * (dx2 ? split_c : C) + c] = o;
             }
@@ -510,8 +516,8 @@ int siss_gemm_nt_f32(const void* A, long lda, const void* W, void* C, long ldc, 
     p.mul_r = 0; p.d2s = 0; p.alpha_cols = 0; p.alpha = alpha;
     for (int i = 0; i < kMaxPanelsF; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
     for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 4 == 0);
-    SISS_CHECK_ARG(cdiv(M, 16) <= 65535);
-    gemm_nt_f32_kernel<<<dim3(cdiv(N, 64), cdiv(M, 16), batch), 256, 0, (hipStream_t)stream>>>(p);
+    SISS_CHECK_ARG(cdiv(N, 64) <= 65535);
+    gemm_nt_f32_kernel<<<dim3(cdiv(M, 16), cdiv(N, 64), batch), 256, 0, (hipStream_t)stream>>>(p);
     SISS_LAUNCH_RET();
 }
 
@@ -525,7 +531,7 @@ int siss_gemm_tn_f32(const void* Y, long ldy, const void* X, long ldx, float* dW
     SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set && (long)npanels * nsets <= 65535);
     TNF p;
     p.Y = (const float*)Y; p.X = (const float*)X; p.dW = dW; p.dbias = dbias; p.dbias2 = dbias ? dbias2 : nullptr;
-    p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.x_set_rows = x_set_rows; p.N = N; p.C = C; p.npanels = npanels;
+    p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.bias_stride = set_stride; p.x_set_rows = x_set_rows; p.N = N; p.C = C; p.npanels = npanels;
     p.nsets = nsets; p.rows_per_set = rows_per_set; p.row_begin = row_begin; p.row_end = row_end; p.overwrite = nsplits == -1;
     for (int i = 0; i < kMaxPanelsF; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
     hipStream_t st = (hipStream_t)stream;
@@ -560,7 +566,7 @@ int siss_groupnorm_bwd_ld_f32(const void* dy, const void* x, const float* gamma,
     gn_bwd_f32_kernel<<<dim3(G, nx), kGT, 0, (hipStream_t)stream>>>(
         (const float*)dy, (const float*)x, gamma, beta, mean, rstd, (float*)dx, (const float*)accum, (const float*)accum2, (float*)dx2,
         split_c, accumulate2, dgamma, dbeta, colsum, colsum_ld, n2 / nx, nx, set_images, set_stride, H, W, C, G, silu, dy_compact,
-        ldx ? ldx : C);
+        ldx ? ldx : C, 0);
     SISS_LAUNCH_RET();
 }
 
@@ -711,14 +717,133 @@ int siss_rowdot_f32(const void* a, const void* b, float* out, long rows, long ro
 int siss_gemm_nt_mulsub_f32(const void* A, long lda, const void* W, void* C, long ldc, const void* R, long ldr, const float* rowsub,
                             int M, int N, int Kp, float alpha, int batch, long strideA, long strideW, long strideC, void* stream) {
     SISS_CHECK_ARG(A && W && C && R && rowsub && M > 0 && N > 0 && Kp > 0 && Kp % 16 == 0 && batch >= 1 && batch <= 65535);
-    SISS_CHECK_ARG(lda % 4 == 0 && ((uintptr_t)A | (uintptr_t)W) % 16 == 0 && cdiv(M, 16) <= 65535);
+    SISS_CHECK_ARG(lda % 4 == 0 && ((uintptr_t)A | (uintptr_t)W) % 16 == 0 && cdiv(N, 64) <= 65535);
     NTF p;
     p.A = (const float*)A; p.W = (const float*)W; p.C = (float*)C; p.bias = nullptr; p.rowbias = nullptr; p.R = (const float*)R;
     p.rowsub = rowsub; p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldrb = 0; p.strideA = strideA; p.strideW = strideW; p.strideC = strideC;
     p.M = M; p.N = N; p.Kp = Kp; p.npanels = 1; p.rows_per_image = 1; p.Hp = 0; p.Wp = 0; p.mul_r = 1; p.d2s = 0; p.alpha_cols = 0;
     p.alpha = alpha;
     for (int i = 0; i < kMaxPanelsF; ++i) { p.shift[i] = 0; p.coff[i] = 0; }
-    gemm_nt_f32_kernel<<<dim3(cdiv(N, 64), cdiv(M, 16), batch), 256, 0, (hipStream_t)stream>>>(p);
+    gemm_nt_f32_kernel<<<dim3(cdiv(M, 16), cdiv(N, 64), batch), 256, 0, (hipStream_t)stream>>>(p);
+    SISS_LAUNCH_RET();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// f32 forms of the SCHEDULE SWITCHES of the bf16 engine (round 5): folded 1x1 shortcut (forward and dgrad), depth-to-space epilogue,
+// sub-pixel upsample pieces, grouped weight gradients.  Same argument lists as the bf16 launchers; each is the same arithmetic on
+// the simple f32 kernels above (a fold = one accumulation of two products = the second launch adds onto the first's result), so that
+// UNetEngine(dtype=float32, f32_fused=True) runs the schedule bench.py runs and is held against the fp32 oracle at 1e-4.
+static int nt_f32(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const float* rowbias, long ldrb,
+                  const void* R, long ldr, int M, int N, int Kp, int npanels, const int* shifts, const int* coffs, int rows_per_image,
+                  int Hp, int Wp, int d2s, void* stream) {
+    SISS_CHECK_ARG(A && W && C && shifts && coffs && M > 0 && N > 0 && Kp > 0 && Kp % 16 == 0);
+    SISS_CHECK_ARG(npanels >= 1 && npanels <= kMaxPanelsF && rows_per_image > 0);
+    SISS_CHECK_ARG(lda % 4 == 0 && ((uintptr_t)A | (uintptr_t)W) % 16 == 0 && (Hp == 0 || (long)Hp * Wp == rows_per_image));
+    NTF p;
+    p.A = (const float*)A; p.W = (const float*)W; p.C = (float*)C; p.bias = bias; p.rowbias = rowbias; p.R = (const float*)R;
+    p.rowsub = nullptr; p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.ldrb = ldrb; p.strideA = 0; p.strideW = 0; p.strideC = 0;
+    p.M = M; p.N = N; p.Kp = Kp; p.npanels = npanels; p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp;
+    p.mul_r = 0; p.d2s = d2s; p.alpha_cols = 0; p.alpha = 1.f;
+    for (int i = 0; i < kMaxPanelsF; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
+    for (int i = 0; i < npanels; ++i) SISS_CHECK_ARG(p.coff[i] % 4 == 0);
+    SISS_CHECK_ARG(cdiv(N, 64) <= 65535);
+    gemm_nt_f32_kernel<<<dim3(cdiv(M, 16), cdiv(N, 64), 1), 256, 0, (hipStream_t)stream>>>(p);
+    SISS_LAUNCH_RET();
+}
+
+// siss_gemm_nt_d2s / siss_gemm_nt_d2s_bias with f32 tensors
+int siss_gemm_nt_d2s_f32(const void* A, long lda, const void* W, void* C, long ldc, const void* R, long ldr, int M, int N, int Kp,
+                         int npanels, const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, int plane, void* stream) {
+    SISS_CHECK_ARG(plane >= 0 && plane < 4 && Hp > 2 && Wp > 2);
+    return nt_f32(A, lda, W, C, ldc, nullptr, nullptr, 0, R, ldr, M, N, Kp, npanels, shifts, coffs, rows_per_image, Hp, Wp, 1 + plane, stream);
+}
+int siss_gemm_nt_d2s_bias_f32(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, int M, int N, int Kp,
+                              int npanels, const int* shifts, const int* coffs, int rows_per_image, int Hp, int Wp, int plane,
+                              void* stream) {
+    SISS_CHECK_ARG(plane >= 0 && plane < 4 && Hp > 2 && Wp > 2);
+    return nt_f32(A, lda, W, C, ldc, bias, nullptr, 0, nullptr, 0, M, N, Kp, npanels, shifts, coffs, rows_per_image, Hp, Wp, 1 + plane, stream);
+}
+
+// siss_conv3x3_sc with f32 tensors: C = conv1x1(A2; W2) + bias2 first, then C = conv3x3(A; W) + bias + rowbias + C.  No statistics
+// (`written` reports 0: the consuming GroupNorm makes its own pass).
+int siss_conv3x3_sc_f32(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const float* rowbias, long ldrb,
+                        const void* A2, long lda2, const void* W2, int K2, const float* bias2, int M, int N, int Kp, const int* shifts,
+                        const int* coffs, int rows_per_image, int Hp, int Wp, float* qstats, int* written, void* stream) {
+    (void)qstats;
+    if (written) *written = 0;
+    SISS_CHECK_ARG(A2 && W2 && K2 > 0);
+    const int z = 0;
+    int rc = nt_f32(A2, lda2, W2, C, ldc, bias2, nullptr, 0, nullptr, 0, M, N, K2, 1, &z, &z, rows_per_image, Hp, Wp, 0, stream);
+    if (rc != SISS_OK) return rc;
+    return nt_f32(A, lda, W, C, ldc, bias, rowbias, ldrb, C, ldc, M, N, Kp, 9, shifts, coffs, rows_per_image, Hp, Wp, 0, stream);
+}
+// siss_conv3x3_dgrad_sc with f32 tensors: C = conv3x3^T(A; W) (+ R) and Cx = conv1x1^T(A; Wx), two launches over the same cotangent
+int siss_conv3x3_dgrad_sc_f32(const void* A, long lda, const void* W, void* C, long ldc, const void* R, long ldr, const void* Wx,
+                              void* Cx, long ldcx, int Nx, int M, int N, int Kp, const int* shifts, const int* coffs, int rows_per_image,
+                              int Hp, int Wp, void* stream) {
+    SISS_CHECK_ARG(Wx && Cx && Nx > 0);
+    int rc = nt_f32(A, lda, W, C, ldc, nullptr, nullptr, 0, R, ldr, M, N, Kp, 9, shifts, coffs, rows_per_image, Hp, Wp, 0, stream);
+    if (rc != SISS_OK) return rc;
+    const int z = 0;
+    return nt_f32(A, lda, Wx, Cx, ldcx, nullptr, nullptr, 0, nullptr, 0, M, Nx, Kp, 1, &z, &z, rows_per_image, Hp, Wp, 0, stream);
+}
+
+// siss_gemm_tn_bs with f32 operands (bias gradients with a set stride of their own)
+int siss_gemm_tn_bs_f32(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C, int npanels,
+                        const int* shifts, const int* coffs, int nsets, int rows_per_set, long x_set_rows, int row_begin, int row_end,
+                        int nsplits, const void* zero_page, float* dbias, float* dbias2, long bias_set_stride, void* stream) {
+    (void)zero_page;
+    SISS_CHECK_ARG(Y && X && dW && shifts && coffs && N > 0 && C > 0 && npanels >= 1 && npanels <= kMaxPanelsF && nsets >= 1);
+    SISS_CHECK_ARG(row_begin >= 0 && row_end > row_begin && row_end <= rows_per_set && (long)npanels * nsets <= 65535);
+    TNF p;
+    p.Y = (const float*)Y; p.X = (const float*)X; p.dW = dW; p.dbias = dbias; p.dbias2 = dbias ? dbias2 : nullptr;
+    p.ldy = ldy; p.ldx = ldx; p.set_stride = set_stride; p.bias_stride = bias_set_stride; p.x_set_rows = x_set_rows; p.N = N; p.C = C;
+    p.npanels = npanels; p.nsets = nsets; p.rows_per_set = rows_per_set; p.row_begin = row_begin; p.row_end = row_end;
+    p.overwrite = nsplits == -1;
+    for (int i = 0; i < kMaxPanelsF; ++i) { p.shift[i] = i < npanels ? shifts[i] : 0; p.coff[i] = i < npanels ? coffs[i] : 0; }
+    hipStream_t st = (hipStream_t)stream;
+    gemm_tn_f32_kernel<<<dim3(cdiv(C, 64), cdiv(N, 16), npanels * nsets), 256, 0, st>>>(p);
+    if (dbias) tn_bias_f32_kernel<<<dim3(cdiv(N, 64), nsets), 64, 0, st>>>(p);
+    SISS_LAUNCH_RET();
+}
+
+// siss_gemm_tn_grouped with f32 operands: the job table walked on the host, one siss_gemm_tn_f32 per job (what the engine's wgrad
+// QUEUE -- deferred launches, held operands -- needs in the f32 mode; there is nothing to group for an instrument)
+struct siss_tn_job_f32 {
+    const void* Y; long ldy; const void* X; long ldx; float* dW; long set_stride;
+    int N, C, npanels, nsets, rows_per_set, row_begin, row_end, nsplits;
+    long x_set_rows;
+    const void* zero_page; float* dbias; float* dbias2;
+    int shifts[9]; int coffs[9];
+};
+int siss_gemm_tn_grouped_f32(const void* jobs, int njobs, void* stream) {
+    SISS_CHECK_ARG(jobs && njobs > 0 && njobs <= 256);
+    const siss_tn_job_f32* js = (const siss_tn_job_f32*)jobs;
+    for (int i = 0; i < njobs; ++i) {
+        const siss_tn_job_f32& j = js[i];
+        const int rc = siss_gemm_tn_f32(j.Y, j.ldy, j.X, j.ldx, j.dW, j.set_stride, j.N, j.C, j.npanels, j.shifts, j.coffs, j.nsets,
+                                        j.rows_per_set, j.x_set_rows, j.row_begin, j.row_end, j.nsplits, j.zero_page, j.dbias, j.dbias2,
+                                        stream);
+        if (rc != SISS_OK) return rc;
+    }
+    return SISS_OK;
+}
+
+// siss_groupnorm_bwd_ld_s2d with f32 tensors
+int siss_groupnorm_bwd_ld_s2d_f32(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                                  const float* rstd, void* dx, const void* accum, const void* accum2, void* dx2, int split_c,
+                                  int accumulate2, float* dgamma, float* dbeta, float* colsum, long colsum_ld, float* partial, int n2,
+                                  int nx, int set_images, long set_stride, int H, int W, int C, int G, int silu, int dy_compact, int ldx,
+                                  void* stream) {
+    (void)partial;
+    SISS_CHECK_ARG(dy && x && gamma && beta && mean && rstd && dx && dx2 && dgamma && dbeta);
+    SISS_CHECK_ARG(n2 > 0 && nx > 0 && set_images > 0 && n2 % set_images == 0 && n2 % nx == 0 && C % G == 0 && nx <= 65535);
+    SISS_CHECK_ARG(split_c > 0 && split_c < C && H % 2 == 0 && W % 2 == 0 && (ldx == 0 || ldx >= C));
+    gn_bwd_f32_kernel<<<dim3(G, nx), kGT, 0, (hipStream_t)stream>>>(
+        (const float*)dy, (const float*)x, gamma, beta, mean, rstd, (float*)dx, (const float*)accum, (const float*)accum2, (float*)dx2,
+        split_c, accumulate2, dgamma, dbeta, colsum, colsum_ld, n2 / nx, nx, set_images, set_stride, H, W, C, G, silu, dy_compact,
+        ldx ? ldx : C, 1);
     SISS_LAUNCH_RET();
 }
 

@@ -264,7 +264,8 @@ __device__ __host__ __forceinline__ int phase_tap(int k, int p) { return p == 0 
 
 // w [9][Co][Ci] f32 (master) -> wf [4 planes][4 taps][Co][Ci] bf16 (fprop operand) and wd [16 = plane * 4 + tap][Ci][Co] bf16 (dgrad
 // operand: the transposes): sums in f32, ONE rounding.
-__global__ void upsample_phase_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int Co, int Ci) {
+template <typename T>
+__global__ void upsample_phase_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Co, int Ci) {
     const long total = (long)16 * Co * Ci;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ci = i % Ci; long t = i / Ci; const int co = t % Co; const int pt = t / Co;
@@ -275,7 +276,7 @@ __global__ void upsample_phase_weights_kernel(const float* __restrict__ w, bf16_
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
                 if (phase_tap(ky, py) == a && phase_tap(kx, px) == b) acc += w[((long)(ky * 3 + kx) * Co + co) * Ci + ci];
-        const bf16_t v = f2bf(acc);
+        const T v = from_f<T>(acc);
         wf[i] = v;
         wd[((long)pt * Ci + ci) * Co + co] = v;
     }
@@ -392,7 +393,15 @@ int siss_upsample_phase_weights(const float* w, void* wf, void* wd, int Co, int 
     SISS_CHECK_ARG(w && wf && wd && Co > 0 && Ci > 0);
     long nb = ((long)16 * Co * Ci + 255) / 256;
     if (nb > 4096) nb = 4096;
-    upsample_phase_weights_kernel<<<(int)nb, 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)wf, (bf16_t*)wd, Co, Ci);
+    upsample_phase_weights_kernel<bf16_t><<<(int)nb, 256, 0, (hipStream_t)stream>>>(w, (bf16_t*)wf, (bf16_t*)wd, Co, Ci);
+    SISS_LAUNCH_RET();
+}
+// The same with f32 phase weights (the f32 parity mode: no rounding at all)
+int siss_upsample_phase_weights_f32(const float* w, void* wf, void* wd, int Co, int Ci, void* stream) {
+    SISS_CHECK_ARG(w && wf && wd && Co > 0 && Ci > 0);
+    long nb = ((long)16 * Co * Ci + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    upsample_phase_weights_kernel<float><<<(int)nb, 256, 0, (hipStream_t)stream>>>(w, (float*)wf, (float*)wd, Co, Ci);
     SISS_LAUNCH_RET();
 }
 // The adjoint for the weight gradient: the 16 phase-tap gradients dW4 [nsets][4][4][Co][Ci] f32 folded onto the nine taps,

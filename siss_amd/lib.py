@@ -122,12 +122,21 @@ F32_ENTRY = {n: n + "_f32" for n in (
     "siss_rowdot", "siss_gemm_nt_mulsub")}
 F32_ENTRY.update({"siss_transpose_bf16": "siss_transpose_f32", "siss_cast_f32_bf16": "siss_copy_f32",
                   "siss_conv_weight_dgrad_multi_bf16": "siss_conv_weight_dgrad_multi_f32"})
-F32_SAME = {"siss_timestep_sincos", "siss_linear_small_fwd", "siss_linear_small_bwd", "siss_linear_multi_fwd", "siss_linear_multi_bwd",
+# round 5: f32 forms of the engine's SCHEDULE SWITCHES (folded shortcut, depth-to-space epilogue, sub-pixel upsample, grouped wgrads),
+# so that UNetEngine(dtype=float32, f32_fused=True) runs the fused schedule against the fp32 oracle
+F32_ENTRY.update({n: n + "_f32" for n in ("siss_gemm_nt_d2s", "siss_gemm_nt_d2s_bias", "siss_conv3x3_sc", "siss_conv3x3_dgrad_sc",
+                                          "siss_gemm_tn_bs", "siss_gemm_tn_grouped", "siss_groupnorm_bwd_ld_s2d",
+                                          "siss_upsample_phase_weights")})
+F32_SAME = {"siss_upsample_phase_wgrad_fold", "siss_timestep_sincos", "siss_linear_small_fwd", "siss_linear_small_bwd", "siss_linear_multi_fwd", "siss_linear_multi_bwd",
             "siss_nchw_channel_sums", "siss_mixture_fwd", "siss_mixture_select", "siss_loss_bwd_seed", "siss_mse_bwd_seed",
             "siss_ddpm_step", "siss_grad_norms_scale", "siss_grad_norm_partials", "siss_grad_scalars", "siss_recombine_clip_adamw"}
 for _b, _f in F32_ENTRY.items():
     SIGNATURES[_f] = SIGNATURES[_b]
 _MODE = threading.local()        # per thread: autograd runs an engine's backward on its own device thread (siss_amd/model.py)
+
+
+def in_f32_mode():
+    return bool(getattr(_MODE, "f32", False))
 
 
 class f32_mode:

@@ -96,6 +96,8 @@ def conv_fprop_qstats(x: Act, w_bf16, out: Act, qstats, **kw):
 
 def conv3x3_sc_takes(x: Act, co, out, x2: Act):
     """Whether conv_fprop_sc can fold the 1x1 shortcut over `x2` into the 3x3 product over `x` (the persistent kernel takes it)."""
+    if lib.in_f32_mode():                       # the f32 form (two launches, one accumulation) has no shape limits
+        return True
     return bool(lib.query("siss_conv3x3_sc_takes", x.rows, co, x.c, x2.c, x.rows_per_image, x.wp, getattr(x, "ld", x.c),
                           getattr(out, "ld", out.c), getattr(x2, "ld", x2.c)))
 
@@ -134,6 +136,8 @@ def conv_dgrad(dy: Act, wT_bf16, out: Act, residual: Act = None, ksize=3):
 def conv3x3_dgrad_sc_takes(dy: Act, ci, out: Act, out_x, residual: Act = None):
     """Whether conv_dgrad_sc can run the 1x1 shortcut's dgrad (-> out_x) inside the 3x3 dgrad (-> out) over the same cotangent
     (residual: what conv_dgrad_sc will be given -- its size is part of the kernel's 32-bit addressing limit)."""
+    if lib.in_f32_mode():
+        return True
     return bool(lib.query("siss_conv3x3_dgrad_sc_takes", dy.rows, ci, dy.c, out_x.c, dy.rows_per_image, dy.wp, dy.c,
                           getattr(out, "ld", out.c), getattr(out_x, "ld", out_x.c), residual.c if residual is not None else 0))
 

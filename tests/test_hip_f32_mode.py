@@ -33,11 +33,13 @@ THREE_LEVEL = dict(sample_size=16, in_channels=3, out_channels=3, block_out_chan
                    downsample_padding=0, flip_sin_to_cos=False, freq_shift=1)
 
 
-def _pair(kw, seed=1, hip_kw=None):
+def _pair(kw, seed=1, hip_kw=None, fused=False):
     from siss_amd.config import UNet2DConfig
     from siss_amd.unet import UNetEngine
     from oracle.unet import OracleUNet2D, UNetConfig
-    eng = UNetEngine(UNet2DConfig(**dict(kw, **(hip_kw or {}))), "cuda:0", dtype=torch.float32)
+    eng = UNetEngine(UNet2DConfig(**dict(kw, **(hip_kw or {}))), "cuda:0", dtype=torch.float32, f32_fused=fused)
+    if fused:
+        eng.subpixel_min_px = 16          # the toy networks' upsamplers (4 x 4 / 8 x 8 low-resolution pixels) take the sub-pixel form too
     sd = eng.init_random(seed=seed)
     net = OracleUNet2D(UNetConfig(**kw)).double()          # the oracle in f64: ITS rounding is then not part of the comparison
     net.load_state_dict({k: v.double() for k, v in sd.items()})
@@ -77,12 +79,31 @@ def _fwd_bwd_errors(eng, net, kw, B=4, seed=0):
     return perr, max(gerr)
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["plain", "fused-schedule"])
 @pytest.mark.parametrize("name, kw", [("celeb-toy", CELEB_TOY), ("mnist-toy", MNIST_TOY), ("three-level", THREE_LEVEL)])
-def test_f32_forward_and_dual_backward_match_the_oracle_at_1e4(name, kw):
-    eng, net, _ = _pair(kw)
+def test_f32_forward_and_dual_backward_match_the_oracle_at_1e4(name, kw, fused):
+    """fused-schedule (round 5): the SCHEDULE SWITCHES of the bf16 engine left on in the f32 mode -- a resnet's 1x1 shortcut folded
+    into conv2's product (forward) and into its dgrad launch, the stride-2 dgrad's depth-to-space epilogue, Upsample2D as four
+    phase convolutions with the space-to-depth cotangent written by the consumer's GroupNorm backward, the queued weight
+    gradients -- on the f32 forms of their entry points: the schedule bench.py runs, at the same 1e-4."""
+    from siss_amd import lib
+    eng, net, _ = _pair(kw, fused=fused)
     assert eng.f32 and eng.ps.shadow is eng.ps.flat
-    perr, (gerr, s, n) = _fwd_bwd_errors(eng, net, kw)
-    print(f"\n{name}: f32 mode vs f64 oracle: pred rel err {perr:.2e}; worst per-tensor gradient rel err {gerr:.2e} (set {s}, {n})")
+    assert (eng.fold_shortcut and eng.d2s_epilogue and eng.group_rows > 0) == fused
+    calls = []
+    orig = lib.call
+    lib.call = lambda name_, *a: (calls.append(name_), orig(name_, *a))[1]
+    try:
+        perr, (gerr, s, n) = _fwd_bwd_errors(eng, net, kw)
+    finally:
+        lib.call = orig
+    if fused:                                                # the switched forms really ran
+        want = {"siss_conv3x3_sc", "siss_conv3x3_dgrad_sc", "siss_gemm_nt_d2s", "siss_gemm_tn_grouped", "siss_gemm_nt_d2s_bias",
+                "siss_upsample_phase_wgrad_fold", "siss_groupnorm_bwd_ld_s2d"}
+        assert want <= set(calls), want - set(calls)
+    else:
+        assert not ({"siss_conv3x3_sc", "siss_gemm_nt_d2s", "siss_gemm_tn_grouped", "siss_gemm_nt_d2s_bias"} & set(calls))
+    print(f"\n{name} ({'fused' if fused else 'plain'} schedule): f32 mode vs f64 oracle: pred rel err {perr:.2e}; worst per-tensor gradient rel err {gerr:.2e} (set {s}, {n})")
     assert perr <= RTOL, perr
     assert gerr <= RTOL, (gerr, s, n)
 
@@ -265,16 +286,19 @@ def _full_size_check(eng, net, x, t, cots, fwd_kw, what, rtol_pred, rtol_grad):
     assert worst[0] <= rtol_grad, worst
 
 
-def test_full_size_celebahq_network_in_f32_matches_torch_fp32():
+@pytest.mark.parametrize("fused", [False, True], ids=["plain", "fused-schedule"])
+def test_full_size_celebahq_network_in_f32_matches_torch_fp32(fused):
     """The REAL architecture of BASELINE configs[1] -- google/ddpm-celebahq-256's UNet2DModel, 113.7 M parameters, 256 x 256 -- in the
-    f32 mode at B = 2: prediction and all 450 tensors' gradients of both cotangent sets against the fp32 torch network (TF32 off)."""
+    f32 mode at B = 2: prediction and all 450 tensors' gradients of both cotangent sets against the fp32 torch network (TF32 off).
+    fused-schedule: with the bf16 engine's schedule switches on (folded shortcuts, sub-pixel upsample from 32 x 32 up, depth-to-space
+    epilogue, queued weight gradients)."""
     from siss_amd.config import UNet2DConfig
     from siss_amd.unet import UNetEngine
     from oracle.unet import OracleUNet2D, UNetConfig
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
     dev = torch.device("cuda:0")
-    eng = UNetEngine(UNet2DConfig.celebahq256(), dev, dtype=torch.float32)
+    eng = UNetEngine(UNet2DConfig.celebahq256(), dev, dtype=torch.float32, f32_fused=fused)
     sd = eng.init_random(seed=42)
     net = OracleUNet2D(UNetConfig.celebahq256())
     net.load_state_dict(sd)
