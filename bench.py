@@ -449,6 +449,18 @@ def main():
                "steps_per_sec_at_bs%d" % Bc: round(1.0 / cdt, 6),
                "timed_steps_s": [round(x, 2) for x in cdts]}
 
+    if rank == 0 and cpu is None and world > 1:
+        # N > 1: the CPU baseline is timed at N = 1 only (rank 0, one GPU's workload); a scaling record carries that measurement BY VALUE
+        # from the committed N = 1 line of this workload, so that it is self-contained
+        try:
+            ref_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                    "latest_bench_sd15_bs%d.json" % B if sd else "latest_bench_celeb_bs%d.json" % B)
+            ref = json.load(open(ref_file))
+            if ref.get("cpu_baseline"):
+                cpu = dict(ref["cpu_baseline"], measured_at="n_gpus = 1 (per-GPU workload; not re-timed in this run)",
+                           source="profiles/" + os.path.basename(ref_file))
+        except Exception:
+            cpu = None
     if rank == 0:
         steps_per_sec = 1e3 / ms
         GA = a.grad_accum

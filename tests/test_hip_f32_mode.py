@@ -160,7 +160,9 @@ def test_f32_mode_refuses_entry_points_without_an_f32_form():
     from siss_amd import lib
     with lib.f32_mode(True):
         with pytest.raises(RuntimeError, match="no f32 form"):
-            lib.call("siss_gemm_nt_d2s")
+            lib.call("siss_gemm_nt_qstats")                     # statistics of ROUNDED outputs: a bf16 notion
+        with pytest.raises(RuntimeError, match="no f32 form"):
+            lib.call("siss_attn1h_fwd")
         with pytest.raises(RuntimeError, match="no f32 form"):
             lib.call("siss_flash_attn_fwd_merged")
 
