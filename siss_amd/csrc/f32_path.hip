@@ -816,15 +816,16 @@ struct siss_tn_job_f32 {
     long x_set_rows;
     const void* zero_page; float* dbias; float* dbias2;
     int shifts[9]; int coffs[9];
+    long bias_set_stride;
 };
 int siss_gemm_tn_grouped_f32(const void* jobs, int njobs, void* stream) {
     SISS_CHECK_ARG(jobs && njobs > 0 && njobs <= 256);
     const siss_tn_job_f32* js = (const siss_tn_job_f32*)jobs;
     for (int i = 0; i < njobs; ++i) {
         const siss_tn_job_f32& j = js[i];
-        const int rc = siss_gemm_tn_f32(j.Y, j.ldy, j.X, j.ldx, j.dW, j.set_stride, j.N, j.C, j.npanels, j.shifts, j.coffs, j.nsets,
-                                        j.rows_per_set, j.x_set_rows, j.row_begin, j.row_end, j.nsplits, j.zero_page, j.dbias, j.dbias2,
-                                        stream);
+        const int rc = siss_gemm_tn_bs_f32(j.Y, j.ldy, j.X, j.ldx, j.dW, j.set_stride, j.N, j.C, j.npanels, j.shifts, j.coffs, j.nsets,
+                                           j.rows_per_set, j.x_set_rows, j.row_begin, j.row_end, j.nsplits, j.zero_page, j.dbias, j.dbias2,
+                                           j.bias_set_stride ? j.bias_set_stride : j.set_stride, stream);
         if (rc != SISS_OK) return rc;
     }
     return SISS_OK;

@@ -623,6 +623,7 @@ struct siss_tn_job {
     long x_set_rows;
     const void* zero_page; float* dbias; float* dbias2;
     int shifts[9]; int coffs[9];
+    long bias_set_stride;                 // floats between the sets of dbias / dbias2; 0 = set_stride (siss_gemm_tn_bs's extra argument)
 };
 
 static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
@@ -834,6 +835,8 @@ int siss_gemm_tn_pair(const void* job3, const void* job1, int max_blocks, void* 
                   b.x_set_rows, b.row_begin, b.row_end, s1, b.zero_page, b.dbias, b.dbias2, false, g.j1, f1);
     if (rc != SISS_OK) return rc;
     SISS_CHECK_ARG(f3 && !f1);
+    if (a.bias_set_stride) g.j3.bias_stride = a.bias_set_stride;
+    if (b.bias_set_stride) g.j1.bias_stride = b.bias_set_stride;
     g.nv3 = (int)(base3 * s3);
     g.nv1 = (int)(base1 * s1);
     g.n3 = (g.nv3 + 7) & ~7;
@@ -874,6 +877,7 @@ static int tn_grouped(const void* jobs, int njobs, int max_blocks, void* stream)
                                 j.rows_per_set, j.x_set_rows, j.row_begin, j.row_end, j.nsplits, j.zero_page, j.dbias, j.dbias2,
                                 true, p, fused3);
         if (rc != SISS_OK) return rc;
+        if (j.bias_set_stride) p.bias_stride = j.bias_set_stride;
         if (fused3) p3[n3++] = p; else p1[n1++] = p;
     }
     if (n3) { const int rc = launch_tn_group<3>(p3, n3, (hipStream_t)stream, max_blocks); if (rc != SISS_OK) return rc; }

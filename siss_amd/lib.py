@@ -178,7 +178,7 @@ class TNJob(C.Structure):
     _fields_ = [("Y", P), ("ldy", L), ("X", P), ("ldx", L), ("dW", P), ("set_stride", L),
                 ("N", I), ("C", I), ("npanels", I), ("nsets", I), ("rows_per_set", I), ("row_begin", I), ("row_end", I),
                 ("nsplits", I), ("x_set_rows", L), ("zero_page", P), ("dbias", P), ("dbias2", P),
-                ("shifts", I * 9), ("coffs", I * 9)]
+                ("shifts", I * 9), ("coffs", I * 9), ("bias_set_stride", L)]
 
 
 _lib = None

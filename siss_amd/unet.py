@@ -165,6 +165,7 @@ class UNetEngine:
     # every site 55.68, from 32 x 32 up 55.29, from 64 x 64 up 55.84 / 55.61 -- below 32 x 32 the phase products are latency-bound
     # launches that the grouped weight gradients and the slab GroupNorm of the literal form beat
     subpixel_min_px = 1024
+    subpixel_queue = 1     # ... their four phase weight gradients join the grouped-wgrad queue (the tap fold follows that launch)
     s2d_from_gn = True     # ... and their cotangent arrives space-to-depth from the GroupNorm backward that forms it (no layout pass)
     # Weight gradients of all but the top-resolution layers (at most group_rows reduction rows per set: CelebA-HQ's 8x8 .. 128x128
     # levels) are not launched one by one -- each alone leaves CUs idle in its last round of blocks and pays a launch's fixed
@@ -198,6 +199,7 @@ class UNetEngine:
     side_blocks = 128
     side_max_px = 256
     side_follow = 1            # the grouped launches that fill up AFTER the first batch go to the side stream too (behind it)
+    side_tail = 1              # the jobs queued since the last side launch go there when the pass enters its last block (not after it)
     side_top_gflop = 0         # > 0: that much of the TOP-resolution 3-tap weight gradients issued before the window joins its first batch
     # The step's preparation work that only the BACKWARD pass needs -- zeroing the 909-MB gradient pair, the transposed dgrad weight
     # copies -- runs on the side stream beside the forward pass (HBM-bound fills and copies beside MFMA-bound convolutions) and is
@@ -245,6 +247,7 @@ class UNetEngine:
         self.on_early_grads_final = None
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
+        self._wq_post = []
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._side_phase = False
         self._side_top_spent = 0.0
@@ -508,6 +511,9 @@ class UNetEngine:
         jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
         with torch.cuda.stream(self._side):
             lib.call("siss_gemm_tn_grouped_capped", jobs, len(self._wq), int(self.side_blocks) & ~7)
+            post, self._wq_post = self._wq_post, []
+            for fn in post:                              # launches that consume a queued product (the sub-pixel upsample's tap fold)
+                fn()
         for _, (dy, _x) in self._wq:                     # their cotangent operands stay out of the pool until the join
             buf = getattr(dy, "buf", None)
             if buf is not None and id(buf) in self._held:
@@ -525,6 +531,9 @@ class UNetEngine:
             jobs = (lib.TNJob * len(self._wq))(*[j for j, _ in self._wq])
             lib.call("siss_gemm_tn_grouped", jobs, len(self._wq))
             self._wq = []
+        post, self._wq_post = self._wq_post, []
+        for fn in post:                                  # launches that consume a queued product (the sub-pixel upsample's tap fold)
+            fn()
         for job, _ in self._pair1:                      # one-panel top-resolution products that found no 3-tap partner: on their own
             self._launch_tn_job(job)
         self._pair1 = []
@@ -1197,17 +1206,35 @@ class UNetEngine:
                 lib.call("siss_space_to_depth_ld", dy.data, z.data, nb, H, W, C, 0)
                 self._put(dy)
             # weight gradient: per plane, Y = the plane's columns of z, X = the four shifted low-resolution panels
-            dW4 = self._buf("up.dW4", (self.nsets, 4, 4, C, C))
-            dW4.zero_()
             rows_per_set = self.set_images * z.rows_per_image
             rb, re = z.wp + 1, rows_per_set - (z.wp + 1)
             zp = ops.zero_page(self.device)
             assert x.n in (nb, self.set_images)
-            for plane in range(4):                       # (siss_gemm_tn_bs: the scratch's set stride is 16 C^2, the bias gradient's the flat buffer's)
-                lib.call("siss_gemm_tn_bs", z.data[:, plane * C:], 4 * C, x.data, ldx, dW4[:, plane], dW4[0].numel(), C, C, 4,
-                         lib.int_array(phase_shifts(plane)), z4, self.nsets, rows_per_set, rows_per_set if x.n == nb else 0,
-                         rb, re, 0, zp, ps.g(pre + ".conv.bias", gb), None, ps.total)
-            lib.call("siss_upsample_phase_wgrad_fold", dW4, ps.grads[gb:, ps.specs[wname].off:], ps.total, self.nsets, C, C)
+            queued = bool(self.subpixel_queue and self.group_rows and re - rb <= self.group_rows)
+            # (queued: the scratch must survive until the grouped launch has run -- one per site, not the shared one)
+            dW4 = self._buf((pre if queued else "up") + ".dW4", (self.nsets, 4, 4, C, C))
+            dW4.zero_()
+            dWt, nsets_ = ps.grads[gb:, ps.specs[wname].off:], self.nsets
+            fold = lambda: lib.call("siss_upsample_phase_wgrad_fold", dW4, dWt, ps.total, nsets_, C, C)
+            for plane in range(4):                       # (the scratch's set stride is 16 C^2, the bias gradient's the flat buffer's)
+                if queued:
+                    sh4 = phase_shifts(plane)
+                    self._wq.append((lib.TNJob(Y=z.data[:, plane * C:].data_ptr(), ldy=4 * C, X=x.data.data_ptr(), ldx=ldx,
+                                               dW=dW4[:, plane].data_ptr(), set_stride=dW4[0].numel(), N=C, C=C, npanels=4,
+                                               nsets=self.nsets, rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=0,
+                                               x_set_rows=rows_per_set if x.n == nb else 0, zero_page=zp.data_ptr(),
+                                               dbias=ps.g(pre + ".conv.bias", gb).data_ptr(), dbias2=None,
+                                               shifts=(lib.I * 9)(*sh4, *([0] * 5)), coffs=(lib.I * 9)(*([0] * 9)),
+                                               bias_set_stride=ps.total), (z, x)))
+                else:
+                    lib.call("siss_gemm_tn_bs", z.data[:, plane * C:], 4 * C, x.data, ldx, dW4[:, plane], dW4[0].numel(), C, C, 4,
+                             lib.int_array(phase_shifts(plane)), z4, self.nsets, rows_per_set, rows_per_set if x.n == nb else 0,
+                             rb, re, 0, zp, ps.g(pre + ".conv.bias", gb), None, ps.total)
+            if queued:                                   # the nine-tap fold follows the grouped launch that forms the 16 phase-tap gradients
+                self._held[id(z.buf)] = z
+                self._wq_post.append(fold)
+            else:
+                fold()
             # dgrad: dx[Y, X] = sum over (plane, tap) of z_plane[Y - dy_tap, X - dx_tap] . W_plane,tap^T
             dx = self._get(nb, lo_h, lo_w, C)
             sh = [-s_ for plane in range(4) for s_ in phase_shifts(plane)]
@@ -1288,6 +1315,7 @@ class UNetEngine:
         self.tape, self.gmap, self._uid = [], {}, 0
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
+        self._wq_post = []
         if self._wT_stale:                             # the dgrad weight copies of the last optimizer step: beside this forward pass
             st = self._side_stream()
             st.wait_stream(torch.cuda.current_stream())
@@ -1303,9 +1331,12 @@ class UNetEngine:
         skips = [h]
         early = self._early_blocks()
         self._early_mark = None
+        self._side_last = None
         for (i, cin_b, cout_b, attn, down) in self.plan_down:
             if self._early_mark is None and f"down_blocks.{i}." in early:
                 self._early_mark = len(self.tape)      # closures from here on belong to the early-final group
+            if i == 1:
+                self._side_last = len(self.tape)       # below this index: the first down block = the LAST stretch of the backward pass
             for j in range(cfg.layers_per_block):
                 # a conv-produced skip is written straight into the tail columns of the concat buffer it ends up in
                 h = self.resnet(h, f"down_blocks.{i}.resnets.{j}", skip_head=None if attn else heads[len(skips)])
@@ -1458,10 +1489,13 @@ class UNetEngine:
         mark = getattr(self, "_early_mark", None)
         side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32) else -1
         self._side_top_spent = 0.0
+        side_last = (getattr(self, "_side_last", None) or 0) - 1 if self.side_tail else -2
         for idx in range(len(self.tape) - 1, -1, -1):
             if idx == side_at:
                 self._side_phase = True
                 self._flush_wgrads_side()               # the weight gradients queued so far run beside the low-resolution blocks
+            if idx == side_last and self._side_phase and self.side_follow:
+                self._flush_wgrads_side()               # what has queued up since: beside the last block instead of behind it
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail

@@ -54,6 +54,7 @@ class VAEEncoder(UNetEngine):
         self.adt, self.f32 = torch.bfloat16, False         # (forward-only front end: the bf16 path)
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
+        self._wq_post = []
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._side_phase = False
         self._side_top_spent = 0.0
