@@ -199,7 +199,7 @@ class UNetEngine:
     side_blocks = 128
     side_max_px = 256
     side_follow = 1            # the grouped launches that fill up AFTER the first batch go to the side stream too (behind it)
-    side_tail = 1              # the jobs queued since the last side launch go there when the pass enters its last block (not after it)
+    side_tail = 0              # k > 0: the jobs queued since the last side launch go there when the pass enters down block k - 1 (same-box: 52.88 off, 53.16-53.26 at k = 1)
     side_top_gflop = 0         # > 0: that much of the TOP-resolution 3-tap weight gradients issued before the window joins its first batch
     # The step's preparation work that only the BACKWARD pass needs -- zeroing the 909-MB gradient pair, the transposed dgrad weight
     # copies -- runs on the side stream beside the forward pass (HBM-bound fills and copies beside MFMA-bound convolutions) and is
@@ -1335,8 +1335,8 @@ class UNetEngine:
         for (i, cin_b, cout_b, attn, down) in self.plan_down:
             if self._early_mark is None and f"down_blocks.{i}." in early:
                 self._early_mark = len(self.tape)      # closures from here on belong to the early-final group
-            if i == 1:
-                self._side_last = len(self.tape)       # below this index: the first down block = the LAST stretch of the backward pass
+            if i == self.side_tail and i > 0:
+                self._side_last = len(self.tape)       # below this index: down blocks [0, side_tail) = the last stretch of the backward pass
             for j in range(cfg.layers_per_block):
                 # a conv-produced skip is written straight into the tail columns of the concat buffer it ends up in
                 h = self.resnet(h, f"down_blocks.{i}.resnets.{j}", skip_head=None if attn else heads[len(skips)])
