@@ -361,8 +361,10 @@ def kernel_symbol(name, a):
         return "gemm_nt_c3p_kernel"
     if name == "siss_gemm_nt_mulsub":
         return "gemm_nt_kernel"
-    if name in ("siss_gemm_tn_grouped", "siss_gemm_tn_grouped_capped"):
+    if name == "siss_gemm_tn_grouped":
         return "gemm_tn_grouped_kernel"
+    if name == "siss_gemm_tn_grouped_capped":
+        return "gemm_tn_grouped_capped_kernel"
     if name == "siss_gemm_tn_pair":
         return "gemm_tn_mixed_kernel"
     if name == "siss_gemm_tn":

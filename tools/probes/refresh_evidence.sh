@@ -1,5 +1,5 @@
 set -e
-tag=${1:-r03r}
+tag=${1:-r05a}
 bash tools/pmc_traffic.sh $tag
 cp gpurun_out/${tag}_hbm_traffic.json profiles/latest_hbm_traffic.json
 echo "== celeb bench"
