@@ -194,8 +194,14 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m siss_amd.build` "
             "(there is no CPU fallback for the SISS hot path)")
     lib = C.CDLL(LIB_PATH)
+    override = os.path.abspath(LIB_PATH) != os.path.join(_HERE, "libsiss_hip.so")
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)           # AttributeError if the symbol is missing
+        try:
+            fn = getattr(lib, name)       # AttributeError if the symbol is missing
+        except AttributeError:
+            if override:                  # an OLDER build loaded for an A/B (bench.py --lib, tools/ab_bench.sh): newer entry points absent
+                continue
+            raise
         fn.argtypes = argtypes
         fn.restype = C.c_long if name in _RET_LONG else C.c_int
     _lib = lib

@@ -52,10 +52,17 @@ class _DeleteBase(Task):
     def compute_dtype(self):
         """`mixed_precision: null` -- the reference's shipped default: fp32 everywhere (delete_celeb.yaml:103) -- runs the f32 engine
         (every tensor and product f32: the parity mode, 1/16 of the bf16 MFMA rate at best); `bf16` the bf16 MFMA path."""
-        if self.cfg.get("mixed_precision") == "bf16":
+        mp = self.cfg.get("mixed_precision")
+        if mp == "bf16":
             return torch.bfloat16
-        print("[siss_amd] mixed_precision is null: true f32 compute (the reference's default; a parity mode here, far slower than "
-              "mixed_precision=bf16, which is what the benchmark runs)")
+        if mp not in (None, "no", "null", "None"):
+            # the reference's YAML lists fp16 / fp8 as choices of accelerate; there is no fp16 path here (and no loss scaler in the
+            # reference's loop either): refuse instead of silently running something else
+            raise NotImplementedError(f"mixed_precision={mp!r}: this build computes in 'bf16' or in f32 (null / 'no'); "
+                                      "fp16 / fp8 are not provided")
+        print("[siss_amd] mixed_precision is null / 'no': true f32 compute for the UNet, the loss and the optimizer (the reference's "
+              "default; a parity mode here, far slower than mixed_precision=bf16, which is what the benchmark runs; the SD front end -- "
+              "VAE / text encoder -- stays bf16)")
         return torch.float32
 
     def load_unet(self, device):

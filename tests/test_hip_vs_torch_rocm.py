@@ -118,3 +118,6 @@ def test_fused_step_beats_pytorch_rocm_eager_on_the_same_gpu():
           f"fused HIP step (eager launches): {ms_hip:.1f} ms/step = {B / ms_hip * 1e3:.1f} samples/s; "
           f"speed-up {ms_ref / ms_hip:.2f}x")
     assert ms_hip < ms_ref
+    # ... and against the reference stack's RECORDED time with MIOpen's exhaustively tuned kernels (269.8 ms, round 1), not only
+    # against today's run, whose oracle side uses MIOpen's heuristic find mode (tests/conftest.py) and may be slower than that
+    assert ms_hip < 269.8 / 3.0, ms_hip
