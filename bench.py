@@ -369,6 +369,21 @@ def main():
             one_step()
         sync()
         prof, lib.PROF = lib.PROF, None
+        # ... and the same kernel with the chip to itself: the weight gradients of the timed schedule run on a side stream beside part
+        # of these launches (UNetEngine.wgrad_side), so their event times include what they lose to it; a second eager leg on the
+        # ONE-STREAM schedule (same kernels, same shapes) prices the kernel itself
+        prof1 = None
+        if getattr(eng, "wgrad_side", False):
+            saved = (eng.wgrad_side, eng.prep_side)
+            eng.wgrad_side, eng.prep_side = False, False
+            one_step()
+            sync()
+            lib.PROF = [] if rank == 0 else None
+            for _ in range(ksteps):
+                one_step()
+            sync()
+            prof1, lib.PROF = lib.PROF, None
+            eng.wgrad_side, eng.prep_side = saved
     if not a.no_kernel_timing and rank == 0:
         ksym = {}
         hbm = {}
@@ -415,6 +430,12 @@ def main():
                                     "avg_launch_us": round(v[1] / v[0] * 1e3, 2)} for k, v in sorted(dom_kind.items())}}
                    if dom == "gemm_nt_c3p_kernel" and len(dom_kind) > 1 else {}),
                 "share_of_step_kernel_time": round(tms / tot_ms, 3),
+                **({"one_stream_schedule": (lambda w_, t_, n_: {"achieved": round(w_ / (t_ * 1e-3) / 1e12, 2),
+                                                                 "frac": round(w_ / (t_ * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                                 "avg_launch_us": round(t_ / n_ * 1e3, 2),
+                                                                 "note": "the same launches with the side stream off (nothing shares the chip)"})(
+                        sum(r[3] for r in prof1 if r[5] == dom), sum(r[1].elapsed_time(r[2]) for r in prof1 if r[5] == dom),
+                        max(1, sum(1 for r in prof1 if r[5] == dom)))} if prof1 else {}),
                 # the HBM-bound launchers of the step (K1, K5, K10-12), each against the HBM peak:
                 # ALGORITHMIC bytes (operands read once, results written once; lib.hbm_bytes) / summed launch time
                 "hbm_kernels": {k: {"achieved": round(v[2] / (v[1] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
