@@ -68,7 +68,7 @@ def test_full_size_no_is_step_matches_the_fp32_oracle_step():
 
 
 def test_sd15_full_size_step_matches_the_fp32_oracle_step():
-    """BASELINE configs[4]: the SD v1.5 UNet (859,520,964 parameters), B = 2, 64 x 64 x 4 latents, 77 x 768 text conditioning, SISS
+    """BASELINE configs[4]: the SD v1.5 UNet (859,520,964 parameters), B = 4 (the batch bench.py --workload sd15 runs), 64 x 64 x 4 latents, 77 x 768 text conditioning, SISS
     lambd = 0.5 with config/delete_sd.yaml's optimizer and scaling_norm (delete_sd.py:977-1127)."""
     from siss_amd.config import UNet2DConditionConfig
     from siss_amd.step import SISSStepper
@@ -81,7 +81,7 @@ def test_sd15_full_size_step_matches_the_fp32_oracle_step():
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
     dev = torch.device("cuda:0")
-    B = 2
+    B = 4
     eng = UNetCondEngine(UNet2DConditionConfig.sd15(), dev)
     sd = eng.init_random(seed=3)
     ac = S.alphas_cumprod(beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012).to(dev)
@@ -91,7 +91,7 @@ def test_sd15_full_size_step_matches_the_fp32_oracle_step():
     a0 = (0.18215 * torch.randn(1, 4, 64, 64, generator=g, device=dev)).repeat(B, 1, 1, 1).to(torch.bfloat16)
     noise = torch.randn(B, 4, 64, 64, generator=g, device=dev).to(torch.bfloat16)
     t = torch.full((B,), 999, dtype=torch.long, device=dev)
-    u = torch.tensor([0.9, 0.2], device=dev)
+    u = torch.tensor([0.9, 0.2, 0.6, 0.35], device=dev)
     ctx = torch.randn(1, 77, 768, generator=g, device=dev).repeat(B, 1, 1).to(torch.bfloat16)  # one prompt repeated (:941-944)
 
     net = OracleUNet2DCondition(UNetCondConfig.sd15())
@@ -112,4 +112,4 @@ def test_sd15_full_size_step_matches_the_fp32_oracle_step():
     got = st.stats()
     check_scalars(ref, got)
     cos = assert_update_direction(sd, after, eng.state_dict(), gfin, "full-size SD v1.5 step")
-    _report("full-size SD v1.5 step (B = 2)", ref, got, cos)
+    _report("full-size SD v1.5 step (B = 4)", ref, got, cos)
