@@ -52,15 +52,17 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     // XCD-aware tile order: blocks b, b+8, ... share an L2; give each XCD a contiguous run of
     // tiles (n-tiles of one m-tile adjacent) so shifted A panels and weights hit in L2.
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int nwg = tiles_n * tiles_m;
+    const int nz = p.nphase ? p.nphase : 1;             // phases: (tile, phase) blocks on grid.x, a tile's phases adjacent
+    const int nwg = tiles_n * tiles_m * nz;
     int bid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    int bz = blockIdx.z;
+    if (p.nphase) { bz = bid % nz; bid /= nz; }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int bz = blockIdx.z;
     const bf16_t* A = p.A + (long)bz * p.strideA;
     const bf16_t* W = p.W + (long)bz * p.strideW;
 
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     const long wpanel = (long)p.N * p.Kp;
     // split-K (small grids: the 8x8 / 16x16 layers leave most CUs idle and are bound by the serial K loop):
     // block (tile, blockIdx.y) runs K-steps [s_begin, s_begin + steps) and parks its raw accumulators in a slab
-    int s_begin = 0, steps = p.npanels * kchunks;
+    const int pn0 = p.nphase ? p.ph_p0[bz] : 0, pn1 = p.nphase ? p.ph_p0[bz + 1] : p.npanels;
+    int s_begin = 0, steps = (pn1 - pn0) * kchunks;
     if (p.ksplit > 1) {
         const int all = steps;
         s_begin = (int)((long)all * blockIdx.y / p.ksplit);
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     // offset live in the kernel arguments: they are fetched right AFTER a stage's DMA has been issued, so the
     // scalar-load latency hides behind the compute phase instead of sitting between the barrier and the DMA.
     int st_pn = s_begin / kchunks, st_kc = s_begin - st_pn * kchunks;
+    st_pn += pn0;
     long a_base = (long)p.shift[st_pn] * p.lda + p.coff[st_pn], w_base = st_pn * wpanel;
     const unsigned smem_a = lds_addr(smem);
     auto stage = [&](int buf, int step) {
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
         for (int j = 0; j < C_::kWPieces; ++j) glds16_asm(wsrc[j] + woff, base + BM * 128 + (w * C_::kWPieces + j) * 1024);
         if (++st_kc == kchunks) {
             st_kc = 0;
-            if (++st_pn < p.npanels) {
+            if (++st_pn < pn1) {
                 a_base = (long)p.shift[st_pn] * p.lda + p.coff[st_pn];
                 w_base += wpanel;
             }
@@ -270,7 +274,7 @@ int launch_nt(const NTParams& p, int batch, hipStream_t st) {
     static unsigned char attr_set[kMaxDevices];
     if (siss_ensure_smem((const void*)gemm_nt_kernel<BM, NW, STAGES>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
     siss_count_dispatch(p.ksplit > 1 ? SISS_K_NT_SPLITK : SISS_K_NT);
-    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.ksplit > 1 ? p.ksplit : 1, batch);
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN) * (p.nphase ? p.nphase : 1), p.ksplit > 1 ? p.ksplit : 1, p.nphase ? 1 : batch);
     gemm_nt_kernel<BM, NW, STAGES><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
     if (p.ksplit > 1) {
         static unsigned char attr2[kMaxDevices];
@@ -380,7 +384,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
                      int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream,
                      float* qstats = nullptr, int* qstats_written = nullptr, int d2s = 0, const void* A2 = nullptr, long lda2 = 0,
                      const void* W2 = nullptr, int K2 = 0, const float* bias2 = nullptr, const void* Wx = nullptr, void* Cx = nullptr,
-                     long ldcx = 0, int Nx = 0, int alpha_cols = 0) {
+                     long ldcx = 0, int Nx = 0, int alpha_cols = 0, const int* phase_p0 = nullptr) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
     SISS_CHECK_ARG(alpha_cols == 0 || (alpha_cols > 0 && alpha_cols % 4 == 0 && npanels == 1 && !mul_r));   // (one-panel products: the generic kernel)
     if (qstats_written) *qstats_written = 0;
@@ -409,6 +413,14 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     { const char* e = getenv("SISS_NT_DEBUG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
     SISS_CHECK_ARG(d2s == 0 || (d2s >= 1 && d2s <= 4 && Hp > 2 && Wp > 2 && batch == 1 && !rowsub && !mul_r));
+    p.nphase = 0;
+    for (int i = 0; i < 5; ++i) p.ph_p0[i] = 0;
+    if (phase_p0) {                                            // the four planes' products as ONE launch (siss_gemm_nt_d2s_phases)
+        SISS_CHECK_ARG(d2s && phase_p0[0] == 0 && phase_p0[4] == npanels && !qstats && !A2 && !Cx);
+        for (int i = 0; i < 4; ++i) SISS_CHECK_ARG(phase_p0[i + 1] > phase_p0[i]);
+        p.nphase = 4;
+        for (int i = 0; i < 5; ++i) p.ph_p0[i] = phase_p0[i];
+    }
     p.rowsub = rowsub; p.mul_r = mul_r;
     SISS_CHECK_ARG(!mul_r || (R && Hp == 0));              // the multiplicative epilogue has no halo form
     const int dev_ = siss_current_device();
@@ -434,7 +446,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     SISS_CHECK_ARG(!A2 && !Cx);                                // only the persistent kernel folds a shortcut in (callers ask siss_conv3x3_*_takes first)
     // Large grids: single-buffered blocks at 4 per CU (latency hidden by the other three) measured 10-15 %
     // faster than double-buffered blocks at 2 per CU; small grids (< 4 blocks per CU) keep the double buffer.
-    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch;
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(N, BN) * batch * (p.nphase ? p.nphase : 1);
     // (more tiles than the double-buffered form keeps resident -- 2 blocks x 256 CUs -- : that form would run a second, partly
     // empty round; A/B of the threshold on one box, 2048 / 1100 / 520 / 384 / 260 tiles: SD v1.5 B = 16 112.5 / 112.8 / 111.3 /
     // 111.5 / 111.8 ms, B = 4 46.0 / 46.9 / 45.8 / 46.2 / 46.3 ms, CelebA-HQ unchanged -- e.g. 8192 x 1280 x K 10240: 640 tiles)
@@ -445,7 +457,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
         // Few tiles and a long K loop: split K over up to 8 blocks per tile so that (nearly) every CU holds one
         // block; each block keeps >= 6 K-steps.  Partial tiles go through the host-provided slab.
         const int steps = npanels * (Kp / BK);
-        if (batch == 1 && tiles128 <= 128 && steps >= 12 && g_slab) {
+        if (batch == 1 && !p.nphase && tiles128 <= 128 && steps >= 12 && g_slab) {
             int S = (int)(256 / tiles128);
             if (S > 8) S = 8;
             if (S > steps / 6) S = steps / 6;
@@ -454,7 +466,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
             }
         }
         // 129..256 tiles (the 16x16 layers): two double-buffered blocks per CU, each with half the K loop
-        if (batch == 1 && tiles128 > 128 && steps >= 24 && g_slab &&
+        if (batch == 1 && !p.nphase && tiles128 > 128 && steps >= 24 && g_slab &&
             (long)tiles128 * 2 * 128 * BN * (long)sizeof(float) <= g_slab_bytes) {
             p.ksplit = 2; p.slab = g_slab;
             return launch_nt<128, 4, 2>(p, batch, (hipStream_t)stream);
@@ -558,6 +570,21 @@ int siss_gemm_nt_d2s_bias(const void* A, long lda, const void* W, void* C, long 
     SISS_CHECK_ARG(plane >= 0 && plane < 4);
     return gemm_nt_dispatch(A, lda, W, C, ldc, bias, nullptr, N, nullptr, 0, M, N, Kp, npanels, shifts, coffs,
                             rows_per_image, Hp, Wp, 1.0f, 1, 0, 0, 0, nullptr, 0, stream, nullptr, nullptr, 1 + plane);
+}
+
+// The FOUR planes of siss_gemm_nt_d2s / siss_gemm_nt_d2s_bias as one launch: plane z runs panels [phase_p0[z], phase_p0[z + 1]) of
+// shifts / coffs / W (W holds the planes' panels back to back: [phase_p0[4]][N][Kp]; phase_p0[0] = 0, every plane at least one
+// panel, at most 16 in all) and scatters to plane z.  bias and R are optional as in the single-plane entry points.  Each block
+// does what the corresponding block of the single-plane launch does (same K order, same epilogue): bitwise the same C.  A row
+// tile's four planes run as adjacent blocks on one XCD, so the shifted A rows they share come out of L2, and the launch pays one
+// ramp and one drain instead of four (the low-resolution sites are four latency-bound launches otherwise).
+int siss_gemm_nt_d2s_phases(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const void* R, long ldr,
+                            int M, int N, int Kp, const int* phase_p0, const int* shifts, const int* coffs, int rows_per_image,
+                            int Hp, int Wp, void* stream) {
+    SISS_CHECK_ARG(phase_p0 && phase_p0[4] >= 4 && phase_p0[4] <= kMaxPanels);
+    return gemm_nt_dispatch(A, lda, W, C, ldc, bias, nullptr, N, R, ldr, M, N, Kp, phase_p0[4], shifts, coffs,
+                            rows_per_image, Hp, Wp, 1.0f, 1, 0, 0, 0, nullptr, 0, stream, nullptr, nullptr, 1, nullptr, 0, nullptr, 0,
+                            nullptr, nullptr, nullptr, 0, 0, 0, phase_p0);
 }
 
 // floats in the `qstats` buffer of a product with M rows and N output channels

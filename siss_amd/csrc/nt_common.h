@@ -27,6 +27,9 @@ struct NTParams {
 #endif
     int d2s;                          // 0, or 1 + plane: rows are pixels of space-to-depth plane (py, px) = (plane >> 1, plane & 1); the epilogue
                                       // writes (and reads R) at the pixel's place in the FULL-resolution tensor (2 Hp - 2) x (2 Wp - 2) padded
+    int nphase;                       // 0, or 2..4 PHASES in one launch (generic kernel only; d2s != 0): phase z runs the panels
+    int ph_p0[5];                     // [ph_p0[z], ph_p0[z + 1]) of shift / coff / W and scatters to space-to-depth plane z -- what would
+                                      // be nphase launches with d2s = 1 + z; a tile's phases are adjacent blocks of one XCD (shared A rows in L2)
     float* qstats;                    // optional (persistent 3x3 kernel only): per-(half tile, image slot, 4-channel quad) sums and
                                       // sums of squares of the bf16 OUTPUT, [2 * row tiles][2][N / 4][2] f32 -- the GroupNorm that
                                       // consumes the result folds them instead of reading the tensor a second time
@@ -155,7 +158,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
                 // depth-to-space in the epilogue (stride-2 conv dgrad): this plane's pixel (y, x) is pixel (2y + py, 2x + px) of the
                 // full-resolution tensor; the plane's halo rows have no place there (its halo is zero already and stays so)
                 if (halo) continue;
-                const int pl = p.d2s - 1, wf = 2 * p.Wp - 2;
+                const int pl = p.nphase ? bz : p.d2s - 1, wf = 2 * p.Wp - 2;
                 ro = (long)img * (2 * p.Hp - 2) * wf + (long)(2 * y - 1 + (pl >> 1)) * wf + (2 * x - 1 + (pl & 1));
             }
             if (halo) o = u32x4_t{0u, 0u, 0u, 0u};

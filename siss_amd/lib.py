@@ -43,6 +43,7 @@ SIGNATURES = {
     "siss_conv_qstats_words": [L, I],
     "siss_gemm_nt_d2s": [P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, I, P],
     "siss_gemm_nt_d2s_bias": [P, L, P, P, L, P, I, I, I, I, IP, IP, I, I, I, I, P],
+    "siss_gemm_nt_d2s_phases": [P, L, P, P, L, P, P, L, I, I, I, IP, IP, IP, I, I, I, P],
     "siss_upsample_phase_weights": [P, P, P, I, I, P],
     "siss_upsample_phase_wgrad_fold": [P, P, L, I, I, I, P],
     "siss_gemm_nt_set_workspace": [P, L],
@@ -322,7 +323,7 @@ def hbm_bytes(name, a):
 def _shape_key(name, a):
     """Problem shape of a launch, for per-layer breakdowns (tools/step_breakdown.py)."""
     if name == "siss_gemm_nt":
-        return ("M", a[10], "N", a[11], "K", a[12], "panels", a[13], "batch", a[20])
+        return ("M", a[10], "N", a[11], "K", a[12], "panels", a[13], "batch", a[20]) + ((a[24],) if len(a) > 24 else ())
     if name == "siss_conv3x3_sc":
         return ("M", a[13], "N", a[14], "K", a[15], "panels", 9, "+1x1 K", a[11])
     if name == "siss_conv3x3_dgrad_sc":
@@ -358,7 +359,7 @@ def kernel_symbol(name, a):
     if name == "siss_gemm_nt":
         M, N, Kp, npan, batch, rpi = a[10], a[11], a[12], a[13], a[20], a[16]
         tiles = -(-M // 128) * -(-N // 128)
-        if (npan == 9 and batch == 1 and Kp % 64 == 0 and N % 128 == 0 and rpi >= 256
+        if (npan == 9 and batch == 1 and len(a) <= 24 and Kp % 64 == 0 and N % 128 == 0 and rpi >= 256
                 and tiles >= 256
                 and triples(a[14], a[15], 9)):
             return "gemm_nt_c3p_kernel"
@@ -409,6 +410,10 @@ def call(name, *args):
             a = args
             name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], a[5], None, a[7], None, 0, a[6], a[7], a[8], a[9],
                                           a[10], a[11], a[12], a[13], a[14], 1.0, 1, 0, 0, 0]
+        elif name == "siss_gemm_nt_d2s_phases":             # (A, lda, W, C, ldc, bias, R, ldr, M, N, Kp, phase_p0, shifts, coffs, rpi, Hp, Wp)
+            a = args
+            name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], a[5], None, a[9], a[6], a[7], a[8], a[9], a[10], a[11][4],
+                                          a[12], a[13], a[14], a[15], a[16], 1.0, 1, 0, 0, 0, "4 planes"]
         elif name == "siss_gemm_nt_d2s":
             a = args
             name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], None, None, a[8], a[5], a[6], a[7], a[8], a[9], a[10],

@@ -166,6 +166,8 @@ class UNetEngine:
     # launches that the grouped weight gradients and the slab GroupNorm of the literal form beat
     subpixel_min_px = 1024
     subpixel_queue = 1     # ... their four phase weight gradients join the grouped-wgrad queue (the tap fold follows that launch)
+    phase_launch = True    # the four space-to-depth planes of a downsample dgrad / the four phases of a sub-pixel upsample forward as ONE
+    #                        launch each (siss_gemm_nt_d2s_phases; bitwise the four launches' result; the f32 mode keeps the four launches)
     s2d_from_gn = True     # ... and their cotangent arrives space-to-depth from the GroupNorm backward that forms it (no layout pass)
     # Weight gradients of all but the top-resolution layers (at most group_rows reduction rows per set: CelebA-HQ's 8x8 .. 128x128
     # levels) are not launched one by one -- each alone leaves CUs idle in its last round of blocks and pays a launch's fixed
@@ -1133,12 +1135,20 @@ class UNetEngine:
             if self.d2s_epilogue:
                 # each plane GEMM writes its pixels straight to their place in dx (and adds the cotangent x already has):
                 # no dz tensor, no depth-to-space pass
-                for plane in sorted(planes):
-                    taps = planes[plane]
-                    lib.call("siss_gemm_nt_d2s", dy.data, C, wds[pos:], dx.data, C, dx.data if acc is not None else None, C,
-                             dy.rows, C, C, len(taps), lib.int_array([-shifts[tap] for tap in taps]),
-                             lib.int_array([0] * len(taps)), dy.rows_per_image, dy.hp, dy.wp, plane)
-                    pos += len(taps)
+                if self.phase_launch and not self.f32 and len(planes) == 4:
+                    p0 = [0]                             # the four planes' products as ONE launch (bitwise the same result)
+                    for plane in sorted(planes):
+                        p0.append(p0[-1] + len(planes[plane]))
+                    lib.call("siss_gemm_nt_d2s_phases", dy.data, C, wds, dx.data, C, None, dx.data if acc is not None else None, C,
+                             dy.rows, C, C, lib.int_array(p0), lib.int_array([-shifts[tap] for tap in order]),
+                             lib.int_array([0] * 9), dy.rows_per_image, dy.hp, dy.wp)
+                else:
+                    for plane in sorted(planes):
+                        taps = planes[plane]
+                        lib.call("siss_gemm_nt_d2s", dy.data, C, wds[pos:], dx.data, C, dx.data if acc is not None else None, C,
+                                 dy.rows, C, C, len(taps), lib.int_array([-shifts[tap] for tap in taps]),
+                                 lib.int_array([0] * len(taps)), dy.rows_per_image, dy.hp, dy.wp, plane)
+                        pos += len(taps)
                 self._put(dy)
             else:
                 dz = self._get(nb, Ho, Wo, 4 * C)
@@ -1192,9 +1202,15 @@ class UNetEngine:
             py, px = plane >> 1, plane & 1
             return [(a + py - 1) * wp + (b + px - 1) for a in range(2) for b in range(2)]
         z4 = lib.int_array([0] * 4)
-        for plane in range(4):
-            lib.call("siss_gemm_nt_d2s_bias", x.data, ldx, wf[plane], y.data, getattr(y, "ld", C), ps.p(pre + ".conv.bias"),
-                     x.rows, C, C, 4, lib.int_array(phase_shifts(plane)), z4, x.rows_per_image, x.hp, x.wp, plane)
+        if self.phase_launch and not self.f32:           # the four phase products as ONE launch (bitwise the same result)
+            lib.call("siss_gemm_nt_d2s_phases", x.data, ldx, wf, y.data, getattr(y, "ld", C), ps.p(pre + ".conv.bias"), None, 0,
+                     x.rows, C, C, lib.int_array([0, 4, 8, 12, 16]),
+                     lib.int_array([s_ for plane in range(4) for s_ in phase_shifts(plane)]), lib.int_array([0] * 16),
+                     x.rows_per_image, x.hp, x.wp)
+        else:
+            for plane in range(4):
+                lib.call("siss_gemm_nt_d2s_bias", x.data, ldx, wf[plane], y.data, getattr(y, "ld", C), ps.p(pre + ".conv.bias"),
+                         x.rows, C, C, 4, lib.int_array(phase_shifts(plane)), z4, x.rows_per_image, x.hp, x.wp, plane)
 
         def bwd():
             nb, gb = self.nb, self.gbase

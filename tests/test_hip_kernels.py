@@ -158,6 +158,48 @@ def test_gemm_with_depth_to_space_epilogue_equals_gemm_then_scatter(dev, accumul
     assert torch.equal(fused_dx.buf, ref_dx.buf)
 
 
+@pytest.mark.parametrize("kind", ["downsample dgrad (1/2/2/4 taps, adds R in place)", "sub-pixel upsample forward (4 x 4 taps, bias)"])
+@pytest.mark.parametrize("shape", [(3, 24, 20, 128), (2, 8, 8, 256), (9, 64, 64, 128)], ids=["24x20x128", "8x8x256", "64x64x128 large grid"])
+def test_four_planes_in_one_launch_equal_four_launches(dev, kind, shape):
+    """siss_gemm_nt_d2s_phases against the four single-plane launches it replaces (siss_gemm_nt_d2s / siss_gemm_nt_d2s_bias): every
+    block runs the same K order and the same epilogue, so the full-resolution tensor is BITWISE the same (Downsample2D backward /
+    Upsample2D forward behind losses/ddpm_deletion_loss.py:24 and delete_celeb.py:691,:702)."""
+    from siss_amd import lib
+    from siss_amd.layout import Act
+    n, ho, wo, c = shape
+    g = torch.Generator().manual_seed(5 + c + ho)
+    a = Act.from_nchw(torch.randn(n, c, ho, wo, generator=g).bfloat16().float(), dev)
+    wp = wo + 2
+    down = kind.startswith("down")
+    if down:
+        taps = [[(0, 0)], [(0, 1), (0, 0)], [(1, 0), (0, 0)], [(1, 1), (1, 0), (0, 1), (0, 0)]]
+    else:
+        taps = [[(y + (pl >> 1) - 1, x + (pl & 1) - 1) for y in range(2) for x in range(2)] for pl in range(4)]
+    shifts = [[dy_ * wp + dx_ for dy_, dx_ in tl] for tl in taps]
+    npan = sum(len(tl) for tl in taps)
+    w = (torch.randn(npan, c, c, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    bias = None if down else torch.randn(c, generator=g).to(dev)
+    prior = torch.randn(n, c, 2 * ho, 2 * wo, generator=g).bfloat16().float()
+    one, four = Act.from_nchw(prior, dev), Act.from_nchw(prior, dev)
+    p0, pos = [0], 0
+    for plane, sh in enumerate(shifts):
+        if down:
+            lib.call("siss_gemm_nt_d2s", a.data, c, w[pos:], four.data, c, four.data, c, a.rows, c, c, len(sh), lib.int_array(sh),
+                     lib.int_array([0] * len(sh)), a.rows_per_image, a.hp, a.wp, plane)
+        else:
+            lib.call("siss_gemm_nt_d2s_bias", a.data, c, w[pos:], four.data, c, bias, a.rows, c, c, len(sh), lib.int_array(sh),
+                     lib.int_array([0] * len(sh)), a.rows_per_image, a.hp, a.wp, plane)
+        pos += len(sh)
+        p0.append(pos)
+    flat = [s_ for sh in shifts for s_ in sh]
+    lib.call("siss_gemm_nt_d2s_phases", a.data, c, w, one.data, c, bias, one.data if down else None, c if down else 0, a.rows, c, c,
+             lib.int_array(p0), lib.int_array(flat), lib.int_array([0] * npan), a.rows_per_image, a.hp, a.wp)
+    torch.cuda.synchronize()
+    assert one.halo_is_zero()
+    assert torch.equal(one.buf, four.buf)
+    assert float((one.interior().float() - prior.to(dev).permute(0, 2, 3, 1)).abs().max()) > 0.1      # (it did write)
+
+
 @pytest.mark.parametrize("path", LOSS_FILES, ids=[os.path.basename(p)[10:-4] for p in LOSS_FILES])
 def test_mixture_and_loss_seed_vs_golden(dev, path):
     """fp32 mode against the golden vectors made by the reference's own loss code."""

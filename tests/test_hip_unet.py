@@ -506,10 +506,10 @@ def test_depth_to_space_in_the_dgrad_epilogue_equals_the_separate_pass():
     t = torch.tensor([999, 500, 3, 999]).cuda()
     cot = (torch.randn(8, 3, 16, 16, generator=g) * 1e-2).cuda()
     outs = {}
-    for fused in (True, False):
+    for fused in (True, False, "one launch"):
         eng = UNetEngine(hc, "cuda:0")
         eng.init_random(seed=1)
-        eng.d2s_epilogue = fused
+        eng.d2s_epilogue, eng.phase_launch = bool(fused), fused == "one launch"
         calls = []
         orig = lib.call
         lib.call = lambda name, *a, _o=orig, _c=calls: (_c.append(name), _o(name, *a))[1]
@@ -523,8 +523,11 @@ def test_depth_to_space_in_the_dgrad_epilogue_equals_the_separate_pass():
         outs[fused] = (eng.ps.grads.clone(), calls)
     assert outs[True][1].count("siss_gemm_nt_d2s") == 4 and outs[True][1].count("siss_depth_to_space") == 0
     assert outs[False][1].count("siss_gemm_nt_d2s") == 0 and outs[False][1].count("siss_depth_to_space") == 1
+    # ... and the four plane products as ONE launch (siss_gemm_nt_d2s_phases: UNetEngine.phase_launch, the default)
+    assert outs["one launch"][1].count("siss_gemm_nt_d2s_phases") == 1 and outs["one launch"][1].count("siss_gemm_nt_d2s") == 0
     ga, gb = outs[True][0], outs[False][0]
     assert float((ga - gb).norm() / gb.norm()) < 1e-5
+    assert float((outs["one launch"][0] - gb).norm() / gb.norm()) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------------------------
