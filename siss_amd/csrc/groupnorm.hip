@@ -268,6 +268,55 @@ __global__ __launch_bounds__(kThreads) void gn_qstats_finalize_kernel(
     }
 }
 
+// The same (half tile, image slot, quad) entries for a tensor that did NOT come out of the persistent 3x3 kernel (conv_in, the
+// stride-2 downsample, the sub-pixel upsample: the generic kernels form no statistics): one read of the tensor, block
+// (tile t, half h) over its <= 128 flat padded rows, lane = (row in flight, 16-B channel chunk = two quads).  Halo rows are zero
+// (every producer masks them) and add nothing.  A skip tensor is normalised twice (alone on the way down, as one half of a concat
+// on the way up): the engine keeps these entries, and the second GroupNorm has no statistics pass at all.
+__global__ __launch_bounds__(kThreads) void gn_quad_stats_kernel(const bf16_t* __restrict__ x, long ld, int M, int N, int rpi,
+                                                                 float* __restrict__ qs) {
+    __shared__ float red[8][kThreads];
+    const int t = blockIdx.x >> 1, h = blockIdx.x & 1, tid = threadIdx.x;
+    const int r0 = t * kQsTileRows + h * kQsHalfRows;
+    int r1 = r0 + (h ? kQsTileRows - kQsHalfRows : kQsHalfRows);
+    r1 = r1 < M ? r1 : M;
+    const int bnd = (t * kQsTileRows / rpi + 1) * rpi;      // first row of the tile's second image (slot 1)
+    const int lpr = N >> 3, par = kThreads / lpr;           // lanes per row, rows in flight
+    const int rr = tid / lpr, cc = tid - rr * lpr;
+    float a[8];                                             // [quad j][slot][sum, sum of squares]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.f;
+    if (rr < par) {
+        const bf16_t* src = x + cc * 8;
+        for (int r = r0 + rr; r < r1; r += par) {
+            const u32x4_t v4 = *reinterpret_cast<const u32x4_t*>(src + (long)r * ld);
+            float v[8];
+            unpack8(v4, v);
+            const float w1 = r >= bnd ? 1.f : 0.f, w0 = 1.f - w1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float s1 = (v[4 * j] + v[4 * j + 1]) + (v[4 * j + 2] + v[4 * j + 3]);
+                const float s2 = (v[4 * j] * v[4 * j] + v[4 * j + 1] * v[4 * j + 1]) + (v[4 * j + 2] * v[4 * j + 2] + v[4 * j + 3] * v[4 * j + 3]);
+                a[4 * j] += w0 * s1; a[4 * j + 1] += w0 * s2;
+                a[4 * j + 2] += w1 * s1; a[4 * j + 3] += w1 * s2;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[i][tid] = a[i];
+    __syncthreads();
+    if (tid < lpr * 4) {                                    // one thread per (chunk, quad j, slot)
+        const int c = tid >> 2, j = (tid >> 1) & 1, slot = tid & 1;
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < par; ++k) {
+            s1 += red[4 * j + 2 * slot][k * lpr + c];
+            s2 += red[4 * j + 2 * slot + 1][k * lpr + c];
+        }
+        const long e = ((long)(2 * t + h) * 2 + slot) * (N >> 2) + (2 * c + j);
+        *reinterpret_cast<float2*>(qs + 2 * e) = float2{s1, s2};
+    }
+}
+
 // ---------------------------------------------------------------- backward
 // grid.y = nx (saved samples); each block handles the SETS cotangent samples n2 = set*nx + n that share
 // saved sample n, so x is read once for both gradient sets.
@@ -618,6 +667,18 @@ long siss_gn_partial_words(int n, int H, int W, int C, int G) {
     GNShape s;
     if (!make_shape(H, W, C, G, s, 1)) return -1;   // N = 1 gives the largest chunk count -> upper bound
     return (long)n * s.nslices * s.nchunks * 2 * s.G;
+}
+
+// GroupNorm statistics of a padded-NHWC tensor (M flat rows of N channels, row stride ld elements, zero halo rows) in the format
+// the persistent 3x3 convolution leaves them (siss_gemm_nt_qstats; siss_conv_qstats_words(M, N) floats): what siss_groupnorm_fwd_qs
+// takes as qsA / qsB for a producer that forms none.  rows_per_image >= 256 (a 254-row tile spans at most two images), N % 8 == 0,
+// N <= 2048.  One read of the tensor.
+int siss_quad_stats(const void* x, long ld, int M, int N, int rows_per_image, float* qs, void* stream) {
+    SISS_CHECK_ARG(x && qs && M > 0 && N > 0 && N % 8 == 0 && N <= 8 * kThreads && ld >= N && ld % 8 == 0 && rows_per_image >= 256);
+    SISS_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)qs % 8 == 0 && (N >> 3) * 4 <= kThreads);
+    const int tiles = (M + kQsTileRows - 1) / kQsTileRows;
+    gn_quad_stats_kernel<<<dim3(2 * tiles), kThreads, 0, (hipStream_t)stream>>>((const bf16_t*)x, ld, M, N, rows_per_image, qs);
+    SISS_LAUNCH_RET();
 }
 
 // y = act(GroupNorm(x)); x padded NHWC; y padded or compact ([N][H*W][C]).  Writes mean/rstd [N][G].

@@ -62,6 +62,7 @@ SIGNATURES = {
     "siss_groupnorm_set_slab": [I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
     "siss_groupnorm_fwd_ld": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, I, P],
+    "siss_quad_stats": [P, L, I, I, I, P, P],
     "siss_groupnorm_fwd_qs": [P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, F, I, I, I, P],
     "siss_groupnorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, P],
     "siss_groupnorm_bwd_ld": [P, P, P, P, P, P, P, P, P, P, I, I, P, P, P, L, P, I, I, I, L, I, I, I, I, I, I, I, P],

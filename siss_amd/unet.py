@@ -166,6 +166,8 @@ class UNetEngine:
     # launches that the grouped weight gradients and the slab GroupNorm of the literal form beat
     subpixel_min_px = 1024
     subpixel_queue = 1     # ... their four phase weight gradients join the grouped-wgrad queue (the tap fold follows that launch)
+    quad_stats = True      # GroupNorm statistics of tensors no persistent-conv epilogue produced: one read of the part that lacks them, kept
+    #                        for the forward pass (siss_quad_stats) -- instead of a statistics pass over the whole (concat) input at every use
     phase_launch = True    # the four space-to-depth planes of a downsample dgrad / the four phases of a sub-pixel upsample forward as ONE
     #                        launch each (siss_gemm_nt_d2s_phases; bitwise the four launches' result; the f32 mode keeps the four launches)
     s2d_from_gn = True     # ... and their cotangent arrives space-to-depth from the GroupNorm backward that forms it (no layout pass)
@@ -589,6 +591,23 @@ class UNetEngine:
         assert words > 0
         return self._buf("gn_partial", (max(words, 1),))
 
+    def _quad_stats_of(self, a, form=True):
+        """The GroupNorm statistics entries of `a` in the persistent conv kernel's format: the ones its producer left, or (two-pass
+        sites only) the ones siss_quad_stats forms from one read of it -- once per forward pass."""
+        if a.qstats is not None:
+            return a.qstats
+        cache = getattr(self, "_qs_cache", None)          # (reset by _forward: an engine that does not, does not take this path)
+        if (cache is None or not form or not self.quad_stats or self.f32 or a.h * a.w <= 1024 or a.c % 8 or a.c > 512
+                or (a.h + 2) * (a.w + 2) < 256):
+            return None
+        key = (a.data.data_ptr(), a.c)
+        qs = cache.get(key)
+        if qs is None:
+            qs = self._buf("quad_stats.%x.%d" % key, (lib.query("siss_conv_qstats_words", a.rows, a.c),))
+            lib.call("siss_quad_stats", a.data, getattr(a, "ld", a.c), a.rows, a.c, a.rows_per_image, qs)
+            self._qs_cache[key] = qs
+        return qs
+
     def gn(self, x: Act, pre, silu, compact_out=False, eps=None):
         """GroupNorm(+SiLU).  Returns Act (or a compact [N*H*W, C] bf16 tensor)."""
         G, eps = self.cfg.norm_num_groups, (self.cfg.norm_eps if eps is None else eps)
@@ -608,11 +627,16 @@ class UNetEngine:
         ca = x.c
         if self.epi_stats:
             parts = getattr(x, "cat_parts", None)
+            # (quad_stats: a part whose producer left none -- conv_in, a downsample, a sub-pixel upsample -- gets them from one read
+            #  of that part alone, kept for the forward pass: a skip tensor's second GroupNorm then has no statistics pass at all)
+            form = (x.c // G) % 4 == 0 and x.c % G == 0   # (groups of whole 4-channel quads: what the finalize kernel folds)
             if parts is not None:
-                if parts[0].qstats is not None and parts[1].qstats is not None:
-                    qa, qb, ca = parts[0].qstats, parts[1].qstats, parts[0].c
+                sa = self._quad_stats_of(parts[0], form and parts[1].c <= 512 and parts[1].c % 8 == 0)
+                sb = self._quad_stats_of(parts[1], form and sa is not None)
+                if sa is not None and sb is not None:
+                    qa, qb, ca = sa, sb, parts[0].c
             else:
-                qa = x.qstats
+                qa = self._quad_stats_of(x, form)
         if qa is not None:
             lib.call("siss_groupnorm_fwd_qs", x.data, ps.p(pre + ".weight"), ps.p(pre + ".bias"), yptr, mean, rstd,
                      self._gn_partial(x.n, x.h, x.w, x.c), qa, ca, qb, x.n, x.h, x.w, x.c, G, float(eps), int(silu),
@@ -1332,6 +1356,7 @@ class UNetEngine:
         self._wq, self._held, self._held_release = [], {}, []
         self._pair1 = []
         self._wq_post = []
+        self._qs_cache = {}
         if self._wT_stale:                             # the dgrad weight copies of the last optimizer step: beside this forward pass
             st = self._side_stream()
             st.wait_stream(torch.cuda.current_stream())

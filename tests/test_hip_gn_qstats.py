@@ -180,3 +180,93 @@ def test_engine_with_and_without_the_hand_over(dev):
         cos = torch.nn.functional.cosine_similarity(g0[s], g1[s], dim=0).item()
         assert cos > 0.9999, cos
         assert abs(g0[s].norm().item() / g1[s].norm().item() - 1) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# siss_quad_stats: the same entries for a tensor that no persistent-conv epilogue produced (conv_in, downsample, sub-pixel upsample)
+@pytest.mark.parametrize("n,h,w,c,ld", [
+    (2, 128, 128, 128, 128),         # a tile straddles the two images
+    (5, 40, 40, 256, 384),           # a column view of a concat buffer (ld > c), four image seams, partial last tile
+    (3, 64, 64, 384, 384),           # 48 lanes per row: 5 rows in flight, 16 idle lanes
+    (16, 34, 34, 512, 512),          # the widest part the engine hands over
+])
+def test_quad_stats_entries_match_the_tensor(dev, n, h, w, c, ld):
+    from siss_amd import lib
+    from siss_amd.layout import Act, ActView
+    g = torch.Generator().manual_seed(n + h + c)
+    x = _bf(torch.randn(n, c, h, w, generator=g) + 0.3)
+    if ld == c:
+        a = Act.from_nchw(x, dev)
+    else:
+        base = Act.from_nchw(_bf(torch.randn(n, ld, h, w, generator=g)), dev)
+        a = ActView(base, ld - c, c)
+        a.data.copy_(Act.from_nchw(x, dev).data)
+    qs = torch.full((lib.query("siss_conv_qstats_words", a.rows, c),), float("nan"), device=dev)
+    lib.call("siss_quad_stats", a.data, ld, a.rows, c, a.rows_per_image, qs)
+    torch.cuda.synchronize()
+    got = _fold_on_host(qs, n, h, w, c)
+    y = x.double()
+    ref_s = y.view(n, c // 4, 4, -1).sum(dim=(2, 3))
+    ref_q = (y * y).view(n, c // 4, 4, -1).sum(dim=(2, 3))
+    scale = ref_q.abs().max().item()
+    assert (got[..., 0] - ref_s).abs().max().item() <= 2e-5 * max(scale, ref_s.abs().max().item())
+    assert (got[..., 1] - ref_q).abs().max().item() <= 2e-5 * scale
+
+
+def test_groupnorm_on_formed_statistics_of_one_half_and_conv_statistics_of_the_other(dev):
+    """concat(a sub-pixel upsample's output: siss_quad_stats, a resnet's output: the conv's epilogue) -> the two-pass form's result."""
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act, ActView
+    n, h, w, ca, cb = 8, 64, 64, 128, 128
+    cat = Act(n, h, w, ca + cb, dev)
+    g = torch.Generator().manual_seed(77)
+    va, vb = ActView(cat, 0, ca), ActView(cat, ca, cb)
+    va.data.copy_(Act.from_nchw(_bf(torch.randn(n, ca, h, w, generator=g) * 1.5 - 0.2), dev).data)
+    qa = torch.full((lib.query("siss_conv_qstats_words", va.rows, ca),), float("nan"), device=dev)
+    lib.call("siss_quad_stats", va.data, ca + cb, va.rows, ca, va.rows_per_image, qa)
+    x = Act.from_nchw(_bf(torch.randn(n, 128, h, w, generator=g)), dev)
+    wt = _bf(torch.randn(cb, 128, 3, 3, generator=g) * 0.03)
+    qb = torch.full((lib.query("siss_conv_qstats_words", x.rows, cb),), float("nan"), device=dev)
+    assert ops.conv_fprop_qstats(x, ops.conv_w_to_native(wt).to(dev).to(torch.bfloat16), vb, qb, bias=(torch.randn(cb, generator=g) + 0.2).to(dev))
+    torch.cuda.synchronize()
+    assert cat.halo_is_zero()
+    _gn_both_ways(dev, cat, ca + cb, 32, qa, ca, qb)
+
+
+def test_engine_forms_statistics_once_per_skip_tensor(dev):
+    """CelebA-HQ-shaped UNet at 128 x 128: with UNetEngine.quad_stats the two-pass GroupNorm sites whose input (or one half of it) no
+    persistent-conv epilogue produced run on formed statistics -- no statistics pass of their own --, a skip tensor's entries are
+    formed once and used twice, and the prediction / gradients equal the run without."""
+    from siss_amd import lib
+    from siss_amd.config import UNet2DConfig
+    from siss_amd.unet import UNetEngine
+    cfg = UNet2DConfig(sample_size=128, block_out_channels=(128, 128, 256), down_block_types=("DownBlock2D",) * 3,
+                       up_block_types=("UpBlock2D",) * 3)
+    x = torch.randn(4, 3, 128, 128, generator=torch.Generator().manual_seed(0)).to(dev)
+    t = torch.full((4,), 999, dtype=torch.int64, device=dev)
+    cot = torch.randn(8, 3, 128, 128, generator=torch.Generator().manual_seed(1)).to(dev)
+    runs = []
+    for on in (False, True):
+        eng = UNetEngine(cfg, "cuda:0")
+        eng.init_random(seed=3)
+        eng.quad_stats = on
+        calls = []
+        orig = lib.call
+        lib.call = lambda name, *a, _o=orig, _c=calls: (_c.append(name), _o(name, *a))[1]
+        try:
+            for _ in range(2):                              # twice: the entries of the first pass must not serve the second
+                pred = eng.forward(x if _ == 1 else x * 0.5, t).clone()
+            eng.zero_grad()
+            eng.backward(cot, nsets=2)
+            torch.cuda.synchronize()
+        finally:
+            lib.call = orig
+        runs.append((pred.cpu(), eng.ps.grads.clone().cpu(), calls))
+    (p0, g0, c0), (p1, g1, c1) = runs
+    assert c0.count("siss_quad_stats") == 0 and c1.count("siss_quad_stats") > 0
+    assert c1.count("siss_groupnorm_fwd_qs") > c0.count("siss_groupnorm_fwd_qs")        # sites that left the statistics pass
+    two_pass = lambda c: c.count("siss_groupnorm_fwd_ld")
+    assert two_pass(c1) < two_pass(c0)
+    assert (p0 - p1).abs().max().item() <= 2e-2 * p0.abs().max().item()
+    for s in range(2):
+        assert torch.nn.functional.cosine_similarity(g0[s], g1[s], dim=0).item() > 0.9999
