@@ -575,7 +575,8 @@ int siss_gemm_nt_d2s_bias(const void* A, long lda, const void* W, void* C, long 
 // The FOUR planes of siss_gemm_nt_d2s / siss_gemm_nt_d2s_bias as one launch: plane z runs panels [phase_p0[z], phase_p0[z + 1]) of
 // shifts / coffs / W (W holds the planes' panels back to back: [phase_p0[4]][N][Kp]; phase_p0[0] = 0, every plane at least one
 // panel, at most 16 in all) and scatters to plane z.  bias and R are optional as in the single-plane entry points.  Each block
-// does what the corresponding block of the single-plane launch does (same K order, same epilogue): bitwise the same C.  A row
+// does what the corresponding block of the single-plane launch does (same K order, same epilogue): bitwise the same C -- unless
+// that launch is small enough to split K (this one has four times the blocks and never does): then one bf16 rounding apart.  A row
 // tile's four planes run as adjacent blocks on one XCD, so the shifted A rows they share come out of L2, and the launch pays one
 // ramp and one drain instead of four (the low-resolution sites are four latency-bound launches otherwise).
 int siss_gemm_nt_d2s_phases(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const void* R, long ldr,

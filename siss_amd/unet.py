@@ -169,7 +169,7 @@ class UNetEngine:
     quad_stats = True      # GroupNorm statistics of tensors no persistent-conv epilogue produced: one read of the part that lacks them, kept
     #                        for the forward pass (siss_quad_stats) -- instead of a statistics pass over the whole (concat) input at every use
     phase_launch = True    # the four space-to-depth planes of a downsample dgrad / the four phases of a sub-pixel upsample forward as ONE
-    #                        launch each (siss_gemm_nt_d2s_phases; bitwise the four launches' result; the f32 mode keeps the four launches)
+    #                        launch each (siss_gemm_nt_d2s_phases: the four launches' blocks, minus their split-K at the smallest sites; the f32 mode keeps the four launches)
     s2d_from_gn = True     # ... and their cotangent arrives space-to-depth from the GroupNorm backward that forms it (no layout pass)
     # Weight gradients of all but the top-resolution layers (at most group_rows reduction rows per set: CelebA-HQ's 8x8 .. 128x128
     # levels) are not launched one by one -- each alone leaves CUs idle in its last round of blocks and pays a launch's fixed
@@ -1160,7 +1160,7 @@ class UNetEngine:
                 # each plane GEMM writes its pixels straight to their place in dx (and adds the cotangent x already has):
                 # no dz tensor, no depth-to-space pass
                 if self.phase_launch and not self.f32 and len(planes) == 4:
-                    p0 = [0]                             # the four planes' products as ONE launch (bitwise the same result)
+                    p0 = [0]                             # the four planes' products as ONE launch
                     for plane in sorted(planes):
                         p0.append(p0[-1] + len(planes[plane]))
                     lib.call("siss_gemm_nt_d2s_phases", dy.data, C, wds, dx.data, C, None, dx.data if acc is not None else None, C,
@@ -1226,7 +1226,7 @@ class UNetEngine:
             py, px = plane >> 1, plane & 1
             return [(a + py - 1) * wp + (b + px - 1) for a in range(2) for b in range(2)]
         z4 = lib.int_array([0] * 4)
-        if self.phase_launch and not self.f32:           # the four phase products as ONE launch (bitwise the same result)
+        if self.phase_launch and not self.f32:           # the four phase products as ONE launch
             lib.call("siss_gemm_nt_d2s_phases", x.data, ldx, wf, y.data, getattr(y, "ld", C), ps.p(pre + ".conv.bias"), None, 0,
                      x.rows, C, C, lib.int_array([0, 4, 8, 12, 16]),
                      lib.int_array([s_ for plane in range(4) for s_ in phase_shifts(plane)]), lib.int_array([0] * 16),

@@ -163,9 +163,11 @@ def test_gemm_with_depth_to_space_epilogue_equals_gemm_then_scatter(dev, accumul
 def test_four_planes_in_one_launch_equal_four_launches(dev, kind, shape):
     """siss_gemm_nt_d2s_phases against the four single-plane launches it replaces (siss_gemm_nt_d2s / siss_gemm_nt_d2s_bias): every
     block runs the same K order and the same epilogue, so the full-resolution tensor is BITWISE the same (Downsample2D backward /
-    Upsample2D forward behind losses/ddpm_deletion_loss.py:24 and delete_celeb.py:691,:702)."""
+    Upsample2D forward behind losses/ddpm_deletion_loss.py:24 and delete_celeb.py:691,:702).  (Where the single-plane launches
+    split K -- small grids with a long K loop -- the sums are formed in another order: one bf16 rounding apart.)"""
     from siss_amd import lib
     from siss_amd.layout import Act
+    lib.ensure_workspace(dev)                              # (split-K needs it: the case below must not depend on test order)
     n, ho, wo, c = shape
     g = torch.Generator().manual_seed(5 + c + ho)
     a = Act.from_nchw(torch.randn(n, c, ho, wo, generator=g).bfloat16().float(), dev)
@@ -196,7 +198,14 @@ def test_four_planes_in_one_launch_equal_four_launches(dev, kind, shape):
              lib.int_array(p0), lib.int_array(flat), lib.int_array([0] * npan), a.rows_per_image, a.hp, a.wp)
     torch.cuda.synchronize()
     assert one.halo_is_zero()
-    assert torch.equal(one.buf, four.buf)
+    if c * max(len(sh) for sh in shifts) // 64 >= 12 and a.rows <= 128 * 128:
+        # the single-plane launches of this small grid split K (>= 12 K-steps on <= 128 tiles: f32 partial tiles summed by a second
+        # kernel), the one launch has 4x the blocks and does not: the same products summed in another order, one bf16 rounding apart
+        d = (one.buf.float() - four.buf.float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * float(four.buf.float().abs().max())
+        assert float((d > 0).float().mean()) < 0.05
+    else:
+        assert torch.equal(one.buf, four.buf)
     assert float((one.interior().float() - prior.to(dev).permute(0, 2, 3, 1)).abs().max()) > 0.1      # (it did write)
 
 
