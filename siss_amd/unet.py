@@ -166,6 +166,7 @@ class UNetEngine:
     # launches that the grouped weight gradients and the slab GroupNorm of the literal form beat
     subpixel_min_px = 1024
     subpixel_queue = 1     # ... their four phase weight gradients join the grouped-wgrad queue (the tap fold follows that launch)
+    side_max_batch = 1 << 30   # ... for forward batches of at most this many samples (UNetCondEngine lowers it)
     quad_stats = True      # GroupNorm statistics of tensors no persistent-conv epilogue produced: one read of the part that lacks them, kept
     #                        for the forward pass (siss_quad_stats) -- instead of a statistics pass over the whole (concat) input at every use
     phase_launch = True    # the four space-to-depth planes of a downsample dgrad / the four phases of a sub-pixel upsample forward as ONE
@@ -1528,7 +1529,7 @@ class UNetEngine:
         self.dtp_all = self._buf("temb.dtp_all", (nb, self.temb_ntot))
         self.dtp_all.zero_()
         mark = getattr(self, "_early_mark", None)
-        side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32) else -1
+        side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32 and self.nf <= self.side_max_batch) else -1
         self._side_top_spent = 0.0
         side_last = (getattr(self, "_side_last", None) or 0) - 1 if self.side_tail else -2
         for idx in range(len(self.tape) - 1, -1, -1):

@@ -30,6 +30,12 @@ def _up(n, m):
 
 
 class UNetCondEngine(UNetEngine):
+    # The side-stream weight gradients (UNetEngine.wgrad_side) pay at small batches only: this network's low-resolution stretch is
+    # transformer blocks whose fused attention kernels (D = 160: one 4-wave block per CU, whole register file) run 3-5x longer on
+    # the half of the chip the side launch leaves.  Same box, alternating: B = 4 46.24 / 46.27 ms with, 46.54 / 46.66 without;
+    # B = 16 110.06 / 110.04 with, 108.88 / 108.90 without.
+    side_max_batch = 8
+
     def __init__(self, cfg: UNet2DConditionConfig, device="cuda", dtype=torch.bfloat16):
         super().__init__(cfg, device, dtype=dtype)
         self.ctx = None
