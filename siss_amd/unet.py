@@ -204,11 +204,6 @@ class UNetEngine:
     side_blocks = 128
     side_max_px = 256
     side_follow = 1            # the grouped launches that fill up AFTER the first batch go to the side stream too (behind it)
-    side_tail = 0              # k > 0: the jobs queued since the last side launch go there when the pass enters down block k - 1 (same-box: 52.88 off, 53.16-53.26 at k = 1)
-    side_top_gflop = 0         # > 0: that much of the TOP-resolution 3-tap weight gradients issued before the window joins its first batch
-    # The step's preparation work that only the BACKWARD pass needs -- zeroing the 909-MB gradient pair, the transposed dgrad weight
-    # copies -- runs on the side stream beside the forward pass (HBM-bound fills and copies beside MFMA-bound convolutions) and is
-    # joined at the start of the backward pass (SISSStepper asks for it: zero_grad(beside_forward=True), refresh_weights(lazy=True))
     prep_side = True
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
@@ -255,7 +250,6 @@ class UNetEngine:
         self._wq_post = []
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._side_phase = False
-        self._side_top_spent = 0.0
         self._prep_pending, self._wT_stale = False, False
         self._up_w = {}
 
@@ -790,21 +784,6 @@ class UNetEngine:
             self._held[id(dy.buf)] = dy
             if len(self._wq) >= self.group_max:
                 self._flush_wgrads_side() if (self._side_phase and self.side_follow) else self._flush_wgrads()
-            return
-        if (self.wgrad_side and self.side_top_gflop and not self.f32 and not self._side_phase and isinstance(dy, Act)
-                and ops.is_conv3_panels(shifts, coffs) and self._side_top_spent < self.side_top_gflop):
-            # a top-resolution 3-tap product issued BEFORE the side-stream window opens: it waits in the queue and goes with the first batch
-            base = tiles * (t // 3) * nsets
-            nsp = max(1, min(-(-(re - rb) // 1024), (int(self.side_blocks) & ~7) // base))
-            job = lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
-                            dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
-                            rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=nsp, x_set_rows=x_set_rows,
-                            zero_page=zp.data_ptr(), dbias=dbias.data_ptr() if dbias is not None else None,
-                            dbias2=dbias2.data_ptr() if dbias2 is not None else None,
-                            shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t))))
-            self._wq.append((job, (dy, x)))
-            self._held[id(dy.buf)] = dy
-            self._side_top_spent += 2e-9 * co * ci * t * nsets * (re - rb)
             return
         if (self.pair_top and not self.f32 and isinstance(dy, Act) and re - rb >= self.pair_min_rows
                 and (t == 1 or (ops.is_conv3_panels(shifts, coffs) and self._pair1))):
@@ -1373,12 +1352,9 @@ class UNetEngine:
         skips = [h]
         early = self._early_blocks()
         self._early_mark = None
-        self._side_last = None
         for (i, cin_b, cout_b, attn, down) in self.plan_down:
             if self._early_mark is None and f"down_blocks.{i}." in early:
                 self._early_mark = len(self.tape)      # closures from here on belong to the early-final group
-            if i == self.side_tail and i > 0:
-                self._side_last = len(self.tape)       # below this index: down blocks [0, side_tail) = the last stretch of the backward pass
             for j in range(cfg.layers_per_block):
                 # a conv-produced skip is written straight into the tail columns of the concat buffer it ends up in
                 h = self.resnet(h, f"down_blocks.{i}.resnets.{j}", skip_head=None if attn else heads[len(skips)])
@@ -1530,14 +1506,10 @@ class UNetEngine:
         self.dtp_all.zero_()
         mark = getattr(self, "_early_mark", None)
         side_at = (self._side_mark or 0) - 1 if (self.wgrad_side and not self.f32 and self.nf <= self.side_max_batch) else -1
-        self._side_top_spent = 0.0
-        side_last = (getattr(self, "_side_last", None) or 0) - 1 if self.side_tail else -2
         for idx in range(len(self.tape) - 1, -1, -1):
             if idx == side_at:
                 self._side_phase = True
                 self._flush_wgrads_side()               # the weight gradients queued so far run beside the low-resolution blocks
-            if idx == side_last and self._side_phase and self.side_follow:
-                self._flush_wgrads_side()               # what has queued up since: beside the last block instead of behind it
             self.tape[idx]()
             if idx == mark and self.on_early_grads_final is not None:
                 self._flush_wgrads()                    # queued low-resolution wgrads belong to the early-final tail

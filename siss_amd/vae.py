@@ -57,7 +57,6 @@ class VAEEncoder(UNetEngine):
         self._wq_post = []
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._side_phase = False
-        self._side_top_spent = 0.0
         self._prep_pending, self._wT_stale = False, False
         self._up_w = {}
 
