@@ -335,16 +335,43 @@ class SISSStepper:
         """The scalars the reference logs for the LAST micro-batch (delete_celeb.py:626-663: loss / loss_x / loss_a mean
         over all elements and max / min / unbiased std over the per-sample means; importance-weight mean / max / min /
         std; superfactor) plus the optimizer step's gradient scalars (:748) -- fetched with ONE device-to-host copy."""
-        import math
-        last = self.last or {}
+        return self.stats_async().get()
+
+    def stats_async(self):
+        """The same without stalling the launch stream: the scalars are gathered on the device and copied to pinned host memory
+        behind the step's kernels NOW; `.get()` waits for that copy and forms the dictionary.  A training loop calls `.get()`
+        one step later (siss_amd/tasks.py), so the device always has the next step queued behind the one it is running."""
+        last = dict(self.last or {})
         keys = [k for k in ("loss", "loss_x", "loss_a", "iw_x", "iw_a", "rows_x", "rows_a") if last.get(k) is not None]
-        parts = [self.opt.scalars.float().flatten()] + [last[k].float().flatten() for k in keys]
-        host = torch.cat(parts).cpu()                           # the one D2H of the step
-        st = self.opt.stats_from(host[:self.opt.scalars.numel()])
-        off = self.opt.scalars.numel()
+        sizes = [self.opt.scalars.numel()] + [last[k].numel() for k in keys]
+        dev = torch.cat([self.opt.scalars.float().flatten()] + [last[k].float().flatten() for k in keys])
+        if dev.is_cuda:
+            host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+            host.copy_(dev, non_blocking=True)                  # the one D2H of the step
+            done = torch.cuda.Event()
+            done.record()
+        else:
+            host, done = dev.clone(), None
+        return _PendingStats(host, done, keys, sizes, last.get("subscore"), last.get("superfactor") if "superfactor" in last else None,
+                             self.opt.stats_from)
+
+
+class _PendingStats:
+    """Handle of SISSStepper.stats_async()."""
+
+    def __init__(self, host, done, keys, sizes, subscore, superfactor, opt_stats_from):
+        self.host, self.done, self.keys, self.sizes = host, done, keys, sizes
+        self.subscore, self.superfactor, self.opt_stats_from = subscore, superfactor, opt_stats_from
+
+    def get(self):
+        import math
+        if self.done is not None:
+            self.done.synchronize()
+        host = self.host
+        st = self.opt_stats_from(host[:self.sizes[0]])
+        off = self.sizes[0]
         vals = {}
-        for k in keys:
-            n = last[k].numel()
+        for k, n in zip(self.keys, self.sizes[1:]):
             vals[k] = host[off:off + n].double()
             off += n
 
@@ -356,7 +383,7 @@ class SISSStepper:
         for k in ("loss", "loss_x", "loss_a"):
             if k in vals:
                 v = vals[k]
-                if last.get("subscore") and k != "loss":
+                if self.subscore and k != "loss":
                     v = v[vals["rows_" + k[-1]] > 0]
                     if v.numel() == 0:
                         v = torch.zeros(1, dtype=torch.float64)                 # ddpm_deletion_loss.py:113-120
@@ -364,6 +391,6 @@ class SISSStepper:
         for k in ("iw_x", "iw_a"):
             if k in vals:
                 block("importance_weight_" + k[-1], vals[k])
-        if "superfactor" in last:
-            st["superfactor"] = last["superfactor"]
+        if self.superfactor is not None:
+            st["superfactor"] = self.superfactor
         return st

@@ -227,6 +227,18 @@ class _DeleteBase(Task):
         T = sched.config.num_train_timesteps
         t0 = time.perf_counter()
         eval_every = int(cfg.get("eval_every") or 0)
+        pending = None
+
+        def write_log(handle, meta):
+            st = handle.get()
+            st["global_step"], st["lr"] = meta
+            st["elapsed_s"] = time.perf_counter() - t0
+            log.write(json.dumps(st) + "\n")
+            log.flush()
+            if rank == 0:
+                print(f"step {meta[0]}/{n_steps}  |g_x| {st['norm_loss_x']:.4g}  |g_a| {st['norm_loss_a']:.4g}  "
+                      f"s {st['scaling_factor']:.4g}")
+
         for step in range(n_steps):
             # lr_scheduler.step() after every optimizer step (delete_celeb.py:770); accelerate's wrapper advances the
             # schedule once per PROCESS per optimizer step (AcceleratedScheduler, split_batches=False)
@@ -238,17 +250,18 @@ class _DeleteBase(Task):
                 t = torch.randint(self.timestep_low, T, (B,), device=device, generator=g)
                 u = torch.rand(B, device=device, generator=g)
                 stepper.micro_step(x0, a0, noise, t, u, cond)
-            st = stepper.stats()
-            st["global_step"] = step + 1
-            st["lr"] = stepper.opt.lr
-            st["elapsed_s"] = time.perf_counter() - t0
-            log.write(json.dumps(st) + "\n")
-            log.flush()
+            # the step's scalars travel to the host behind its kernels; they are read (and logged) once the NEXT step is queued,
+            # so the device never waits for the host between steps (same lines, written one step later)
+            handle, meta = stepper.stats_async(), (step + 1, stepper.opt.lr)
+            if pending is not None:
+                write_log(*pending)
+            pending = (handle, meta)
             if rank == 0 and eval_every and (step + 1) % eval_every == 0 and not isinstance(self, DeleteSD):
+                write_log(*pending)
+                pending = None
                 self.evaluate(unet, sched, ds_del[0], step + 1, device)
-            if rank == 0:
-                print(f"step {step + 1}/{n_steps}  |g_x| {st['norm_loss_x']:.4g}  |g_a| {st['norm_loss_a']:.4g}  "
-                      f"s {st['scaling_factor']:.4g}")
+        if pending is not None:
+            write_log(*pending)
         it_all.close()
         if rank == 0 and cfg.get("save_final", True):
             unet.save_pretrained(os.path.join(cfg.output_dir, "unet"))
