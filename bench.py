@@ -317,6 +317,14 @@ def main():
         sync()
         eager_ms = (time.perf_counter() - t0) / min(a.steps, 5) * 1e3
 
+    # ---- what the chip does while the step runs (untimed leg, rank 0, N = 1): the step sits at the board's power limit, and what a box's
+    #      silicon clocks there is most of the box-to-box spread of `value`.  One rocm-smi reading taken WHILE ~1.5 s
+    #      of replays are in flight; absent (None) where the tool or the permission is missing ----
+    device_state = None
+    if rank == 0 and world == 1 and graph is not None and not a.no_kernel_timing:
+        device_state = _smi_under_load(lambda: [graph.replay() for _ in range(max(8, int(1500 / max(ms, 1.0))))])
+        sync()
+
     # ---- N > 1 self-check: every rank must hold bit-identical parameters after the timed steps (the replicated
     #      norm-fix / clip / AdamW only stays in step if the exchange really summed [g_x ; g_a] over all ranks) ----
     selfcheck = None
@@ -518,11 +526,38 @@ def main():
             "step_mfma_frac": round(step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4) if step_tflop else None,
             "roofline": roof, "cpu_baseline": cpu,
             "step_scalars": {k: stats[k] for k in ("norm_loss_x", "norm_loss_a", "scaling_factor", "pre_clip_norm")},
+            **({"device_under_load": device_state} if device_state else {}),
             "kernel_ms_per_step": {k: round(v[1] / max(min(a.steps, 3), 1), 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]},
         }
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def _smi_under_load(enqueue):
+    """Power / shader clock / temperature from ONE `rocm-smi` call made while the work `enqueue()` queued is running (the replays
+    are asynchronous: the call overlaps them).  None when rocm-smi is not there or fails."""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        enqueue()
+        time.sleep(0.3)                                # (the first replays ramp the clocks)
+        r = subprocess.run([exe, "--showpower", "--showmaxpower", "--showclocks", "--showtemp"], capture_output=True, text=True, timeout=20)
+        txt = r.stdout
+        grab = lambda pat: (lambda m: float(m.group(1)) if m else None)(re.search(pat, txt))
+        out = {"power_w": grab(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)"),
+               "power_cap_w": grab(r"Max Graphics Package Power \(W\): ([0-9.]+)"),
+               "sclk_mhz": grab(r"sclk clock level: \S+ \(([0-9.]+)Mhz\)"),
+               "mclk_mhz": grab(r"mclk clock level: \S+ \(([0-9.]+)Mhz\)"),
+               "junction_c": grab(r"Sensor junction\) \(C\): ([0-9.]+)"),
+               "source": "one rocm-smi reading while ~1.5 s of hipGraph replays of the step were in flight (untimed leg)"}
+        return out if out["power_w"] is not None else None
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":
