@@ -111,6 +111,7 @@ def test_delete_celeb_entry_point_on_a_jpeg_directory(tmp_path):
     lines = [json.loads(l) for l in open(out / run / "train_log_rank0.jsonl")]
     assert len(lines) == 2 and all(abs(s["scaling_factor"] * s["norm_loss_a"] - 500.0) < 0.5 for s in lines)
     assert [s["lr"] for s in lines] == [0.0, 2.5e-6]           # constant_with_warmup over 2 steps of lr 5e-6 (get_scheduler)
+    assert [s["global_step"] for s in lines] == [1, 2]         # (a step's line is written once the next step is queued: same order, same lr)
     # the reference's whole per-micro-step block is in the log (delete_celeb.py:626-663)
     assert {"loss_x/mean", "loss_x/std", "loss_a/max", "importance_weight_x/min", "importance_weight_a/std"} <= set(lines[0])
     assert os.path.exists(out / run / "unet" / "diffusion_pytorch_model.safetensors")
