@@ -21,7 +21,8 @@ EXACT = {"siss_loss.hip", "optimizer.hip"}
 # tile, and with the default (AGPR destinations) each one cost a v_accvgpr_read in loops that are VALU-bound (832 -> 10 in the file);
 # no SLP vectoriser: it pairs the softmax arithmetic into v_pk_*_f32 (526 in the file), which cost more issue slots beside MFMAs than
 # the scalar forms (MI355X_MICROARCH issue-cost table) -- same IEEE results, 1.0-1.5 % faster on both kernels (same-box A/B x2)
-EXTRA = {"flash_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
+_FA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]
+EXTRA = {"flash_attn.hip": _FA, "flash_attn32.hip": _FA}
 
 
 def sources():

@@ -24,6 +24,7 @@
 // LDS tiles: 64 rows x D_pad, 16-B chunk index XOR f(row) -- conflict-free for the row-major ds_read_b128 fragment reads AND
 // for the ds_read_b64_tr_b16 transposed reads (see swz()).
 #include "common.h"
+#include "flash32.h"
 
 namespace {
 
@@ -821,6 +822,10 @@ int siss_flash_attn_fwd_merged(const void* q, long ldq, const void* k, long ldk,
                    ldv >= (long)H * D && ldo >= (long)H * D);
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0);
     siss_count_dispatch(SISS_K_FLASH_FWD);
+    {   // narrow heads on whole 128-row blocks: the 32x32x16 form (flash_attn32.hip)
+        const FA32FwdArgs a32{q, k, v, o, ldq, ldk, ldv, ldo, lse2, B, H, D, Sq, Sk, scale, q_prescaled != 0};
+        if (siss_fa32_fwd_takes(a32)) return siss_fa32_fwd(a32, stream);
+    }
     const FAShape sh{H, D, D, Sq, Sk, up64(Sq), up64(Sk), Sk};
     return fa_launch_fwd(FwdArgs{q, k, v, o, ldq, ldk, ldv, ldo, lse2}, B * H, sh, scale, q_prescaled != 0, stream);
 }
@@ -858,6 +863,10 @@ int siss_flash_attn_bwd_merged(const void* q, long ldq, const void* k, long ldk,
     SISS_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 16 == 0);
     SISS_CHECK_ARG(((uintptr_t)lse2 | (uintptr_t)delta) % 16 == 0);
     siss_count_dispatch(SISS_K_FLASH_BWD);
+    {   // narrow heads on whole 128-row blocks (SD's 4096-key self-attention sites): the 32x32x16 form (flash_attn32.hip)
+        const FA32Args a32{q, k, v, o, d_o, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, lse2, delta, nB, B, H, D, Sq, Sk, scale, q_prescaled != 0};
+        if (siss_fa32_bwd_takes(a32)) return siss_fa32_bwd(a32, stream);
+    }
     const FAShape sh{H, D, D, Sq, Sk, up64(Sq), up64(Sk), Sk};
     return fa_launch_bwd(BwdArgs{q, k, v, o, d_o, dq, dk, dv, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, lse2, delta},
                          nB * H, B, sh, scale, q_prescaled != 0, stream);

@@ -162,7 +162,7 @@ _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_sc
 # siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
 KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "flash_attn_fwd": 2, "flash_attn_bwd": 3,
               "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8, "flash_dkdv_qsplit": 9,
-              "attn1h_fwd": 10, "attn1h_bwd": 11, "gemm_tn_pair": 12}
+              "attn1h_fwd": 10, "attn1h_bwd": 11, "gemm_tn_pair": 12, "flash32_bwd": 13, "flash32_fwd": 14}
 
 
 def dispatch_counts(reset=False):

@@ -3,8 +3,8 @@
 # Usage (GPU box): bash tools/pmc_flash.sh > gpurun_out/pmc_flash.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PRE=1
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d gpurun_out/pmc_flash_a -- python tools/probes/flash_time.py > gpurun_out/pmc_flash_a.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_flash_b -- python tools/probes/flash_time.py > gpurun_out/pmc_flash_b.log 2>&1
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d gpurun_out/pmc_flash_a -- python tools/probes/flash_time.py > gpurun_out/pmc_flash_a.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_flash_b -- python tools/probes/flash_time.py > gpurun_out/pmc_flash_b.log 2>&1
 python - <<'PY'
 import csv, glob, collections
 for tag in ("a", "b"):
@@ -13,8 +13,9 @@ for tag in ("a", "b"):
         print("no counters for pass", tag); continue
     d = collections.OrderedDict()
     for r in csv.DictReader(open(fs[0])):
-        if 'flash' not in r['Kernel_Name']: continue
-        k = r['Kernel_Name'][r['Kernel_Name'].find('flash'):][:40]
+        kn = r['Kernel_Name']
+        if 'flash' not in kn and 'fa32' not in kn: continue
+        k = kn[min(i for i in (kn.find('flash'), kn.find('fa32')) if i >= 0):][:40]
         e = d.setdefault(k, collections.defaultdict(float))
         e[r['Counter_Name']] += float(r['Counter_Value'])
         e['_t_' + r['Counter_Name']] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3

@@ -21,3 +21,13 @@ tf = timeit(lambda: lib.call("siss_flash_attn_fwd_merged", q, C, k, C, v, C, o, 
 tb = timeit(lambda: lib.call("siss_flash_attn_bwd_merged", q, C, k, C, v, C, o, C, do, C, lse, delta, dq, C, dk, C, dv, C, 2 * B, B, H, S, S, D, sc, PRE), 5)
 fl = 2.0 * B * H * S * S * D
 print(f"B {B} S {S} D {D}: fwd {tf * 1e3:8.1f} us ({2 * fl / tf / 1e9:6.0f} TF/s)   bwd {tb * 1e3:8.1f} us ({2 * 5 * fl / tb / 1e9:6.0f} TF/s)")
+if os.environ.get("CLOCK"):
+    # shader clock / power while the backward runs back to back (~4 s queued), three rocm-smi samples
+    import subprocess, time
+    for _ in range(int(4.0 / (tb * 1e-3))):
+        lib.call("siss_flash_attn_bwd_merged", q, C, k, C, v, C, o, C, do, C, lse, delta, dq, C, dk, C, dv, C, 2 * B, B, H, S, S, D, sc, PRE)
+    for _ in range(3):
+        time.sleep(0.8)
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True).stdout
+        print(" | ".join(l.strip() for l in out.splitlines() if "sclk" in l or "Power (W)" in l or "Average Graphics" in l))
+    torch.cuda.synchronize()
