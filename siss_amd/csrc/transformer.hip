@@ -66,14 +66,17 @@ __global__ __launch_bounds__(kThreads) void layernorm_fwd_kernel(const bf16_t* _
 
 // dx[r] = (accum[r] +) rstd * (dy*gamma - mean_c(dy*gamma) - xhat * mean_c(dy*gamma*xhat)); saved row = r % rows_x.
 // dgamma / dbeta: per cotangent set (set = r / set_rows), per-lane partial column sums over the block's rows,
-// folded across the block's waves in LDS, one f32 atomic per column and block.
+// folded across the block's waves in LDS; then either one f32 atomic per column and block (part == null) or -- round 6 -- one plain
+// store per column into the block's slot of `part` ([block][2][C] f32), summed per set by ln_dgamma_reduce_kernel.  (The atomics of
+// thousands of blocks land on the same 2 C addresses at the end of the launch: same-address float atomics run at ~1 / 14 of the
+// atomic rate -- 4096 blocks x 640 columns were most of a 64-us launch whose HBM time is 30-67 us.)
 template <int NCH>
 __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const bf16_t* __restrict__ accum,
                                                                  bf16_t* __restrict__ dx, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, long rows2, long rows_x, long set_rows,
-                                                                 long set_stride, int C, int rows_per_block) {
+                                                                 long set_stride, int C, int rows_per_block, float* __restrict__ part) {
     __shared__ float red[2][kThreads / 64][64 * 8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nch = C >> 3;
@@ -165,10 +168,31 @@ __global__ __launch_bounds__(kThreads) void layernorm_bwd_kernel(const bf16_t* _
                 float sum = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < kThreads / 64; ++ww) sum += red[which][ww][col];
-                atomicAdd((which ? dbeta : dgamma) + set * set_stride + c, sum);
+                if (part) part[((long)blockIdx.x * 2 + which) * C + c] = sum;
+                else atomicAdd((which ? dbeta : dgamma) + set * set_stride + c, sum);
             }
         }
     }
+}
+
+// dgamma / dbeta[set * set_stride + c] += sum over the set's blocks of part[block][which][c].  grid (ceil(2 C / 256), nsets, slices):
+// slice z sums every gridDim.z-th block (a few dozen loads per thread instead of a thousand in a row) and adds its share atomically
+// -- gridDim.z adds per address instead of one per block of the main kernel.
+__global__ __launch_bounds__(kThreads) void ln_dgamma_reduce_kernel(const float* __restrict__ part, int blocks_per_set, int C,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta, long set_stride) {
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= 2 * C) return;
+    const long set = blockIdx.y;
+    const float* src = part + (set * blocks_per_set) * 2 * C + t;
+    const int nz = gridDim.z;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = blockIdx.z;
+    for (; b + 3 * nz < blocks_per_set; b += 4 * nz) {
+        s0 += src[(long)b * 2 * C]; s1 += src[(long)(b + nz) * 2 * C]; s2 += src[(long)(b + 2 * nz) * 2 * C]; s3 += src[(long)(b + 3 * nz) * 2 * C];
+    }
+    for (; b < blocks_per_set; b += nz) s0 += src[(long)b * 2 * C];
+    const int which = t >= C, c = t - which * C;
+    atomicAdd((which ? dbeta : dgamma) + set * set_stride + c, (s0 + s1) + (s2 + s3));
 }
 
 // Exact-GELU pieces from ONE exponential: Phi(g) = 0.5 (1 + erf(g / sqrt 2)) with erf by Abramowitz-Stegun 7.1.26
@@ -434,11 +458,28 @@ int siss_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
                        long set_stride, int C, void* stream) {
     SISS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && rows2 > 0 && rows_x > 0 && set_rows > 0);
     SISS_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 64 * 8 * kMaxChunks && rows2 % set_rows == 0 && (!dgamma || dbeta));
-    // rows per block: a divisor of set_rows near 16 (blocks must not straddle sets)
-    int rpb = 32;        // 8 rows per wave, two in flight; fewer blocks also means fewer same-address dgamma / dbeta atomics
+    // rows per block: a divisor of set_rows (blocks must not straddle sets), at least 32 (8 rows per wave, two in flight) and large
+    // enough that the launch has at most ~2048 blocks: every block ends with a fold of its column sums
+    long want = rows2 / 2048;
+    if (want < 32) want = 32;
+    int rpb = (int)(want < set_rows ? want : set_rows);
     while (rpb > 1 && set_rows % rpb) --rpb;
-    LN_DISPATCH(layernorm_bwd_kernel, cdiv(rows2, rpb), (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
-                (const bf16_t*)accum, (bf16_t*)dx, dgamma, dbeta, rows2, rows_x, set_rows, set_stride, C, rpb);
+    const int nblocks = cdiv(rows2, rpb);
+    // column sums: per-block partials in the library workspace + a per-set reduction (same stream), or atomics without a workspace
+    float* part = nullptr;
+    if (dgamma) {
+        long bytes = 0;
+        float* ws = (float*)siss_workspace(&bytes);
+        if (ws && (long)nblocks * 2 * C * (long)sizeof(float) <= bytes - 4096) part = ws;
+    }
+    LN_DISPATCH(layernorm_bwd_kernel, nblocks, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                (const bf16_t*)accum, (bf16_t*)dx, dgamma, dbeta, rows2, rows_x, set_rows, set_stride, C, rpb, part);
+    if (part) {
+        const int bps = (int)(set_rows / rpb);
+        const int slices = bps >= 256 ? 32 : (bps >= 32 ? 8 : 1);
+        ln_dgamma_reduce_kernel<<<dim3(cdiv(2 * C, kThreads), (unsigned)(rows2 / set_rows), slices), kThreads, 0, (hipStream_t)stream>>>(
+            part, bps, C, dgamma, dbeta, set_stride);
+    }
     SISS_LAUNCH_RET();
 }
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--config", default="celebahq256")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--engine-attr", action="append", default=[], help="name=int: set a schedule switch of the engine")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B = a.batch
@@ -42,6 +43,9 @@ def main():
         ac = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, 1000), 0)
         kw = dict(lr=5e-6, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=500.0)
         sc = 1.0
+    for kv in a.engine_attr:
+        k_, v_ = kv.split("=")
+        setattr(eng, k_, int(v_))
     eng.init_random(seed=42)
     st = SISSStepper(eng, ac, lambd=0.5, train_batch_size=B, mixed_precision="bf16", **kw)
     hw, c = cfg.sample_size, cfg.in_channels
