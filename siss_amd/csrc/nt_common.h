@@ -62,7 +62,9 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 template <int BM, int kThreads, int MT = 4>
 __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4][MT], char* smem, int m0, int n0,
                                             int bz, int tid, int wm, int wn, int frow, int fq,
-                                            bool writer = true, int vrows = BM) {
+                                            bool writer = true, int vrows = BM, int jsel = -1) {
+    // jsel >= 0 (split-K reduce kernel: four blocks per tile): only the m-tile j == jsel of every wave is valid in `acc` -- the rows
+    // with (row >> 4 & 3) == jsel are staged and stored, the other three quarters of the tile belong to the sibling blocks
     // ---- epilogue: bf16 tile through LDS (one 34 KiB image), then 16-B coalesced rows ----
     // Registers: acc[i][j][r] = channel n = wn*64 + i*16 + fq*4 + r of pixel m = wm*64 + j*16 + frow.
     // alpha, bias and the per-image row bias (time embedding) are applied in f32 BEFORE the one rounding to
@@ -81,6 +83,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
         }
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
+            if (jsel >= 0 && j != jsel) continue;
             const int m = wm * (MT * 16) + j * 16 + frow;
             float rsub = 0.f;
             if (p.rowsub) { int gr = m0 + m; gr = gr < p.M ? gr : p.M - 1; rsub = p.rowsub[(long)bz * p.M + gr]; }
@@ -125,6 +128,11 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
 #pragma unroll 4
         for (int it = 0; it < BM / kRowsPerIt; ++it) {
             if (rows_left <= 0) break;
+            if (jsel >= 0 && (it & 3) != jsel) {             // (kRowsPerIt == 16 there: iteration it holds the rows of m-tile it & 3)
+                dst += dstep; rows_left -= kRowsPerIt;
+                if (rsrc) rsrc += rstep;
+                continue;
+            }
             u32x4_t o = *reinterpret_cast<const u32x4_t*>(src + it * kRowsPerIt * kCRow);
             if (rsrc) {
                 const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(rsrc);
@@ -147,6 +155,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
         const int row = it * kRowsPerIt + (tid >> 4);
         const int r = m0 + row;
         if (r >= p.M || row >= vrows) break;
+        if (jsel >= 0 && ((row >> 4) & 3) != jsel) continue;
         u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * kCRow + chunk * 16);
         long ro = r;                          // output (and residual) row
         if (p.Hp > 0) {

@@ -126,11 +126,16 @@ MERGED_CASES = [  # B, H, Sq, Sk, D, extra row-stride columns
     (2, 8, 1024, 77, 40, 0),      # SD cross attention: 4 chunks of 4 query tiles
     (1, 8, 640, 77, 80, 0),       # 2 chunks of 5
     (1, 4, 570, 100, 160, 8),     # 9 query tiles (the last one ragged): chunks of 5 + 4
-    # head dim 40 on whole 128-row blocks: the backward runs on the 32x32x16 kernels (csrc/flash_attn32.hip)
+    # SD's head dims on whole 128-query blocks: forward and backward run on the 32x32x16 kernels (csrc/flash_attn32.hip)
     (1, 8, 512, 384, 40, 8),      # several key / query tiles per block, rows wider than heads * D, XCD-grouped block order
     (1, 4, 256, 128, 40, 0),      # forward entries not a multiple of 8: plain block order
     (3, 8, 128, 640, 40, 0),      # one query block, five key blocks
-    (1, 8, 192, 320, 40, 0),      # rows not a multiple of 128: stays on the 16x16x32 kernels
+    (1, 8, 256, 100, 40, 0),      # ragged keys: a second key tile of 36 rows, a key block of 100
+    (1, 8, 192, 320, 40, 0),      # queries not a multiple of 128: stays on the 16x16x32 kernels
+    (1, 8, 256, 256, 80, 0),      # head dim 80: 256-B LDS rows, six contraction steps, five d tiles, VALU row sums
+    (1, 4, 128, 200, 80, 8),      # ... ragged keys (an odd number of key tiles), wide rows
+    (2, 8, 256, 256, 160, 0),     # head dim 160: 512-B rows, chunk slots past 16
+    (1, 8, 128, 77, 160, 0),      # ... cross attention
 ]
 
 
@@ -184,9 +189,13 @@ def test_flash_attention_on_the_projection_layout(dev, B, H, Sq, Sk, D, extra, p
     torch.cuda.synchronize()
     cnt = lib.dispatch_counts(reset=True)
     assert cnt["flash_attn_fwd"] == 1 and cnt["flash_attn_bwd"] == 1
-    on32 = D == 40 and Sq % 128 == 0 and Sk % 128 == 0
+    on32 = D in (40, 80, 160) and Sq % 128 == 0
     assert cnt["flash32_bwd"] == (1 if on32 else 0) and cnt["flash32_fwd"] == (1 if on32 else 0), cnt
-    assert cnt["flash_dkdv_qsplit"] == (1 if Sk <= 128 and Sq >= 512 and not on32 else 0), cnt
+    # the dK / dV kernel cuts the queries into chunks when its grid (key blocks x cotangent entries) is small (both families' rule)
+    nbh = sets * B * H
+    base, qt = (-(-Sk // 128) * nbh, Sq // 64) if on32 else (_up(Sk, 64) // 64 * nbh, _up(Sq, 64) // 64)
+    split = base < 512 and qt >= 8 and min((1024 + base - 1) // base, qt // 4) >= 2
+    assert cnt["flash_dkdv_qsplit"] == (1 if split else 0), cnt
     d_ref = (dor * heads(o, B, Sq).repeat(sets, 1, 1, 1)).sum(-1)                       # <dO, O> with the bf16 O the kernel read
     _close(delta.view(sets * B, H, Sqp)[:, :, :Sq].cpu(), d_ref, 1e-2, "delta")
     for i in range(sets):
