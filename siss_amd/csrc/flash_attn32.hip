@@ -345,20 +345,21 @@ __global__ __launch_bounds__(kT, NCH <= 7 ? 4 : (NCH <= 15 ? 2 : 1)) void fa32_b
 // blocks (block_map).  nch > 1 (few key blocks: cross-attention): every block leaves f32 partial tiles in `part`, summed by
 // fa32_dkdv_reduce_kernel -- deterministic, no atomics.
 // =====================================================================================================================
-template <int NCH, bool PRE>
-__global__ __launch_bounds__(kT, NCH <= 7 ? 3 : (NCH <= 15 ? 2 : 1)) void fa32_bwd_dkdv_kernel(P32 a) {
+// KT: 32-key tiles per wave (1: a block owns 128 keys; 2: 256 -- the streamed Q / dO fragments, row-major and transposed, then serve two
+// score blocks each: half the LDS reads and half the L2 -> LDS traffic per MFMA; D = 40 only: the accumulators double)
+template <int NCH, bool PRE, int KT>
+__global__ __launch_bounds__(kT, KT == 2 ? 2 : (NCH <= 7 ? 3 : (NCH <= 15 ? 2 : 1))) void fa32_bwd_dkdv_kernel(P32 a) {
     using T = G<NCH>;
-    constexpr int KS = T::KS, DT = T::DT, TILE = T::TILE;
+    constexpr int KS = T::KS, DT = T::DT, TILE = T::TILE, BK_ = 128 * KT;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [2 buffers][Q tile | dO tile]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r32 = lane & 31;
     int x_, z;
-    block_map(((a.Sk + 127) / 128) * a.nch, a.nBH, a.BHf, x_, z);
+    block_map(((a.Sk + BK_ - 1) / BK_) * a.nch, a.nBH, a.BHf, x_, z);
     const int kb_ = x_ / a.nch, chunk = x_ - kb_ * a.nch;
     const int bz = z / a.H, hh = z - bz * a.H;
     const int zf = z % a.BHf, bf = zf / a.H;
-    const int krow = kb_ * 128 + w * 32 + r32;
-    const bool k_ok = krow < a.Sk;
+    const int key0 = kb_ * BK_ + w * 32 * KT;                   // this wave's first key
     const unsigned lb = lds_addr(smem);
     lds_zero<NCH>(smem, tid);
     __syncthreads();
@@ -388,28 +389,34 @@ __global__ __launch_bounds__(kT, NCH <= 7 ? 3 : (NCH <= 15 ? 2 : 1)) void fa32_b
         *reinterpret_cast<u32x4_t*>(aug_dst) = split_bf16(a0 * amul, w == 0 ? 3 : 2);
     }
 
-    // ---- this wave's 32 keys: K and V as B fragments (+ the ones against the augmented columns); keys past Sk: zeros, masked below
-    bf16x8_t kf[KS], vf[KS];
-    {
+    // ---- this wave's keys: K and V as B fragments (+ the ones against the augmented columns); keys past Sk: zeros, masked below
+    bf16x8_t kf[KT][KS], vf[KT][KS];
+    float key_mask[KT];                                          // a lane keeps ONE key per tile
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int krow = key0 + kt * 32 + r32;
+        const bool k_ok = krow < a.Sk;
+        key_mask[kt] = k_ok ? 1.f : 0.f;
         const long col = hh * a.D + h * 8;
         const bf16_t* kp = a.k + ((long)bf * a.Sk + krow) * a.ldk + col;
         const bf16_t* vp = a.v + ((long)bf * a.Sk + krow) * a.ldv + col;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const bool ok = k_ok && 2 * s + h < NCH;
-            kf[s] = ok ? *reinterpret_cast<const bf16x8_t*>(kp + s * 16) : as_frag(u32x4_t{0u, 0u, 0u, 0u});
-            vf[s] = ok ? *reinterpret_cast<const bf16x8_t*>(vp + s * 16) : as_frag(u32x4_t{0u, 0u, 0u, 0u});
+            kf[kt][s] = ok ? *reinterpret_cast<const bf16x8_t*>(kp + s * 16) : as_frag(u32x4_t{0u, 0u, 0u, 0u});
+            vf[kt][s] = ok ? *reinterpret_cast<const bf16x8_t*>(vp + s * 16) : as_frag(u32x4_t{0u, 0u, 0u, 0u});
         }
         if (h == (NCH & 1)) {
-            kf[NCH / 2] = as_frag(u32x4_t{kOne2, kOne1, 0u, 0u});
-            vf[NCH / 2] = as_frag(u32x4_t{kOne2, 0u, 0u, 0u});
+            kf[kt][NCH / 2] = as_frag(u32x4_t{kOne2, kOne1, 0u, 0u});
+            vf[kt][NCH / 2] = as_frag(u32x4_t{kOne2, 0u, 0u, 0u});
         }
     }
-    const float key_mask = k_ok ? 1.f : 0.f;                    // a lane keeps ONE key
-    const bool any_masked = kb_ * 128 + 128 > a.Sk;              // (block-uniform)
-    f32x4_t dk[DT][2], dv[DT][2];                                // [d tile][key half]: lane = key (lane & 15), 4 d per tile
+    const bool any_masked = kb_ * BK_ + BK_ > a.Sk;              // (block-uniform)
+    f32x4_t dk[KT][DT][2], dv[KT][DT][2];                        // [key tile][d tile][key half]: lane = key (lane & 15), 4 d per tile
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { dk[dt][0] = kZero4; dk[dt][1] = kZero4; dv[dt][0] = kZero4; dv[dt][1] = kZero4; }
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dk[kt][dt][0] = kZero4; dk[kt][dt][1] = kZero4; dv[kt][dt][0] = kZero4; dv[kt][dt][1] = kZero4; }
     Lanes32<NCH> L;
     L.init(lb, lane);
 
@@ -427,33 +434,42 @@ __global__ __launch_bounds__(kT, NCH <= 7 ? 3 : (NCH <= 15 ? 2 : 1)) void fa32_b
         constexpr int qb = b * 2 * TILE, dob = qb + TILE;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            f32x16_t s = zero16(), dp = zero16();
+            bf16x8_t qa[KS], doa[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s = mfma32(L.rowfrag(qb, half, ks), kf[ks], s);
+            for (int ks = 0; ks < KS; ++ks) { qa[ks] = L.rowfrag(qb, half, ks); doa[ks] = L.rowfrag(dob, half, ks); }
+            bf16x8_t p0[KT], p1[KT], ds0[KT], ds1[KT];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) dp = mfma32(L.rowfrag(dob, half, ks), vf[ks], dp);
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (FA32_ABL == 3) { dp[r] += s[r]; continue; }
-                s[r] = FA32_ABL == 1 ? s[r] : __builtin_amdgcn_exp2f(PRE ? s[r] : s[r] * a.c);
-                dp[r] *= s[r];
+                for (int ks = 0; ks < KS; ++ks) s = mfma32(qa[ks], kf[kt][ks], s);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) dp = mfma32(doa[ks], vf[kt][ks], dp);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (FA32_ABL == 3) { dp[r] += s[r]; continue; }
+                    s[r] = FA32_ABL == 1 ? s[r] : __builtin_amdgcn_exp2f(PRE ? s[r] : s[r] * a.c);
+                    dp[r] *= s[r];
+                }
+                if (any_masked) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s[r] *= key_mask[kt]; dp[r] *= key_mask[kt]; }
+                }
+                to16(s, p0[kt], p1[kt]);
+                to16(dp, ds0[kt], ds1[kt]);
             }
-            if (any_masked) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] *= key_mask; dp[r] *= key_mask; }
-            }
-            bf16x8_t p0, p1, ds0, ds1;
-            to16(s, p0, p1);
-            to16(dp, ds0, ds1);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                if (FA32_ABL == 2) { dv[dt][0][0] += __builtin_bit_cast(float, (int)p0[0] | (int)p1[1] | (int)ds0[2] | (int)ds1[3]); continue; }
+                if (FA32_ABL == 2) { dv[0][dt][0][0] += __builtin_bit_cast(float, (int)p0[0][0] | (int)p1[0][1] | (int)ds0[0][2] | (int)ds1[0][3]); continue; }
                 const bf16x8_t dot = L.trfrag(dob, half, dt);
-                dv[dt][0] = mfma16(dot, p0, dv[dt][0]);
-                dv[dt][1] = mfma16(dot, p1, dv[dt][1]);
                 const bf16x8_t qt = L.trfrag(qb, half, dt);
-                dk[dt][0] = mfma16(qt, ds0, dk[dt][0]);
-                dk[dt][1] = mfma16(qt, ds1, dk[dt][1]);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    dv[kt][dt][0] = mfma16(dot, p0[kt], dv[kt][dt][0]);
+                    dv[kt][dt][1] = mfma16(dot, p1[kt], dv[kt][dt][1]);
+                    dk[kt][dt][0] = mfma16(qt, ds0[kt], dk[kt][dt][0]);
+                    dk[kt][dt][1] = mfma16(qt, ds1[kt], dk[kt][dt][1]);
+                }
             }
         }
     };
@@ -462,29 +478,32 @@ __global__ __launch_bounds__(kT, NCH <= 7 ? 3 : (NCH <= 15 ? 2 : 1)) void fa32_b
         if (t + 1 < NT) tile(std::integral_constant<int, 1>{}, t + 1);
     }
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        const int kr = kb_ * 128 + w * 32 + kh * 16 + (lane & 15);
-        if (a.part) {                                            // f32 partial tiles, unscaled; every key of the block (padding included)
-            float* pg = a.part + ((((long)z * a.nch + chunk) * ((a.Sk + 127) / 128) + kb_) * 128 + (kr - kb_ * 128)) * (2 * DT * 16) + 4 * (lane >> 4);
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                *reinterpret_cast<f32x4_t*>(pg + dt * 16) = dk[dt][kh];
-                *reinterpret_cast<f32x4_t*>(pg + DT * 16 + dt * 16) = dv[dt][kh];
+        for (int kh = 0; kh < 2; ++kh) {
+            const int kr = key0 + kt * 32 + kh * 16 + (lane & 15);
+            if (a.part) {                                        // f32 partial tiles, unscaled; every key of the block (padding included)
+                float* pg = a.part + (((long)z * a.nch + chunk) * ((a.Sk + BK_ - 1) / BK_) * BK_ + kr) * (2 * DT * 16) + 4 * (lane >> 4);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    *reinterpret_cast<f32x4_t*>(pg + dt * 16) = dk[kt][dt][kh];
+                    *reinterpret_cast<f32x4_t*>(pg + DT * 16 + dt * 16) = dv[kt][dt][kh];
+                }
+                continue;
             }
-            continue;
+            if (kr >= a.Sk) continue;
+            bf16_t* okg = a.dk + ((long)bz * a.Sk + kr) * a.lddk + hh * a.D + 4 * (lane >> 4);
+            bf16_t* ovg = a.dv + ((long)bz * a.Sk + kr) * a.lddv + hh * a.D + 4 * (lane >> 4);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                if (dt * 16 + 4 * (lane >> 4) < a.D) {
+                    *reinterpret_cast<u32x2_t*>(okg + dt * 16) =
+                        u32x2_t{pack_bf2(dk[kt][dt][kh][0] * a.kscale, dk[kt][dt][kh][1] * a.kscale),
+                                pack_bf2(dk[kt][dt][kh][2] * a.kscale, dk[kt][dt][kh][3] * a.kscale)};
+                    *reinterpret_cast<u32x2_t*>(ovg + dt * 16) =
+                        u32x2_t{pack_bf2(dv[kt][dt][kh][0], dv[kt][dt][kh][1]), pack_bf2(dv[kt][dt][kh][2], dv[kt][dt][kh][3])};
+                }
         }
-        if (kr >= a.Sk) continue;
-        bf16_t* okg = a.dk + ((long)bz * a.Sk + kr) * a.lddk + hh * a.D + 4 * (lane >> 4);
-        bf16_t* ovg = a.dv + ((long)bz * a.Sk + kr) * a.lddv + hh * a.D + 4 * (lane >> 4);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            if (dt * 16 + 4 * (lane >> 4) < a.D) {
-                *reinterpret_cast<u32x2_t*>(okg + dt * 16) =
-                    u32x2_t{pack_bf2(dk[dt][kh][0] * a.kscale, dk[dt][kh][1] * a.kscale), pack_bf2(dk[dt][kh][2] * a.kscale, dk[dt][kh][3] * a.kscale)};
-                *reinterpret_cast<u32x2_t*>(ovg + dt * 16) =
-                    u32x2_t{pack_bf2(dv[dt][kh][0], dv[dt][kh][1]), pack_bf2(dv[dt][kh][2], dv[dt][kh][3])};
-            }
-    }
 }
 
 // Sum of the query chunks' partial dK / dV: one thread per (z, key, 4 head-dim columns).
@@ -689,15 +708,21 @@ __global__ __launch_bounds__(kT, NCH <= 7 ? 4 : (NCH <= 15 ? 2 : 1)) void fa32_f
 #define FA32_INST(NCH)                                               \
     template __global__ void fa32_bwd_dq_kernel<NCH, true>(P32);     \
     template __global__ void fa32_bwd_dq_kernel<NCH, false>(P32);    \
-    template __global__ void fa32_bwd_dkdv_kernel<NCH, true>(P32);   \
-    template __global__ void fa32_bwd_dkdv_kernel<NCH, false>(P32);  \
+    template __global__ void fa32_bwd_dkdv_kernel<NCH, true, 1>(P32);   \
+    template __global__ void fa32_bwd_dkdv_kernel<NCH, false, 1>(P32);  \
     template __global__ void fa32_fwd_kernel<NCH, true>(PF);         \
     template __global__ void fa32_fwd_kernel<NCH, false>(PF);
 FA32_INST(5)
 FA32_INST(10)
 FA32_INST(20)
 #undef FA32_INST
+template __global__ void fa32_bwd_dkdv_kernel<5, true, 2>(P32);
+template __global__ void fa32_bwd_dkdv_kernel<5, false, 2>(P32);
 
+#ifndef FA32_KT2
+#define FA32_KT2 1
+#endif
+constexpr int g_kt2 = FA32_KT2;      // (probe builds: -DFA32_KT2=0 keeps one 32-key tile per wave in the dK / dV kernel)
 bool shape_ok(int D, int Sq, int Sk) { return (D == 40 || D == 80 || D == 160) && Sq % 128 == 0 && Sq >= 128 && Sk >= 1; }
 
 }  // namespace
@@ -743,14 +768,21 @@ int siss_fa32_bwd(const FA32Args& a, void* stream) {
         }
     }
     const unsigned gq = (unsigned)((long)(a.Sq / 128) * p.nBH), gk = (unsigned)((long)nkb * p.nch * p.nBH);
+    const bool kt2 = a.D == 40 && !p.part && a.Sk % 256 == 0 && g_kt2;    // 256 keys per block (two 32-key tiles per wave)
 #define FA32_GO(NCH, PRE)                                                                                                  \
     do {                                                                                                                   \
         static unsigned char a1[kMaxDevices], a2[kMaxDevices];                                                             \
         constexpr int smem = 4 * G<NCH>::TILE;                                                                             \
         if (siss_ensure_smem((const void*)fa32_bwd_dq_kernel<NCH, PRE>, smem, a1) != SISS_OK) return SISS_ERR_LAUNCH;      \
-        if (siss_ensure_smem((const void*)fa32_bwd_dkdv_kernel<NCH, PRE>, smem, a2) != SISS_OK) return SISS_ERR_LAUNCH;    \
+        if (siss_ensure_smem((const void*)fa32_bwd_dkdv_kernel<NCH, PRE, 1>, smem, a2) != SISS_OK) return SISS_ERR_LAUNCH; \
         fa32_bwd_dq_kernel<NCH, PRE><<<dim3(gq), kT, smem, st>>>(p);                                                       \
-        fa32_bwd_dkdv_kernel<NCH, PRE><<<dim3(gk), kT, smem, st>>>(p);                                                     \
+        if (NCH == 5 && kt2) {                                                                                             \
+            static unsigned char a3[kMaxDevices];                                                                          \
+            if (siss_ensure_smem((const void*)fa32_bwd_dkdv_kernel<5, PRE, 2>, 4 * G<5>::TILE, a3) != SISS_OK) return SISS_ERR_LAUNCH; \
+            fa32_bwd_dkdv_kernel<5, PRE, 2><<<dim3(gk / 2), kT, 4 * G<5>::TILE, st>>>(p);                                  \
+        } else {                                                                                                           \
+            fa32_bwd_dkdv_kernel<NCH, PRE, 1><<<dim3(gk), kT, smem, st>>>(p);                                              \
+        }                                                                                                                  \
     } while (0)
 #define FA32_GO2(NCH) do { if (a.pre) FA32_GO(NCH, true); else FA32_GO(NCH, false); } while (0)
     if (a.D == 40) FA32_GO2(5); else if (a.D == 80) FA32_GO2(10); else FA32_GO2(20);
