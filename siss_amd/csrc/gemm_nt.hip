@@ -389,7 +389,8 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
                      int batch, long strideA, long strideW, long strideC, const float* rowsub, int mul_r, void* stream,
                      float* qstats = nullptr, int* qstats_written = nullptr, int d2s = 0, const void* A2 = nullptr, long lda2 = 0,
                      const void* W2 = nullptr, int K2 = 0, const float* bias2 = nullptr, const void* Wx = nullptr, void* Cx = nullptr,
-                     long ldcx = 0, int Nx = 0, int alpha_cols = 0, const int* phase_p0 = nullptr) {
+                     long ldcx = 0, int Nx = 0, int alpha_cols = 0, const int* phase_p0 = nullptr, const void* gg_h = nullptr,
+                     long gg_rows_x = 0) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
     SISS_CHECK_ARG(alpha_cols == 0 || (alpha_cols > 0 && alpha_cols % 4 == 0 && npanels == 1 && !mul_r));   // (one-panel products: the generic kernel)
     if (qstats_written) *qstats_written = 0;
@@ -407,6 +408,9 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.rows_per_image = rows_per_image; p.Hp = Hp; p.Wp = Wp; p.alpha = alpha; p.alpha_cols = alpha_cols;
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     p.ksplit = 1; p.slab = nullptr; p.qstats = nullptr; p.d2s = d2s;
+    p.gg_h = (const bf16_t*)gg_h; p.gg_rows_x = gg_rows_x;
+    SISS_CHECK_ARG(!gg_h || (gg_rows_x > 0 && npanels == 1 && Hp == 0 && !d2s && !R && !bias && !rowbias && !rowsub && batch == 1 &&
+                             N % 8 == 0 && ldc >= 2L * N && (uintptr_t)gg_h % 16 == 0 && alpha == 1.f));
     p.A2 = (const bf16_t*)A2; p.W2 = (const bf16_t*)W2; p.bias2 = A2 ? bias2 : nullptr; p.lda2 = lda2; p.K2 = A2 ? K2 : 0;
     p.Wx = (const bf16_t*)Wx; p.Cx = (bf16_t*)Cx; p.ldcx = ldcx; p.Nx = Cx ? Nx : 0;
     SISS_CHECK_ARG(!Cx || (Wx && Nx > 0 && Nx % BN == 0 && ldcx % 8 == 0 && ldcx >= Nx && npanels == 9 && !qstats && !A2 &&
@@ -591,6 +595,20 @@ int siss_gemm_nt_d2s_phases(const void* A, long lda, const void* W, void* C, lon
     return gemm_nt_dispatch(A, lda, W, C, ldc, bias, nullptr, N, R, ldr, M, N, Kp, phase_p0[4], shifts, coffs,
                             rows_per_image, Hp, Wp, 1.0f, 1, 0, 0, 0, nullptr, 0, stream, nullptr, nullptr, 1, nullptr, 0, nullptr, 0,
                             nullptr, nullptr, nullptr, 0, 0, 0, phase_p0);
+}
+
+// The dgrad of GEGLU's output projection with the GEGLU backward in its epilogue (diffusers FeedForward: out = a * gelu(g), [a | g] =
+// h = proj(x); the reference differentiates it inside losses/ddpm_deletion_loss.py:24's unet call): acc[r][n] = sum_k A[r][k] W[n][k] is
+// d(out); dh [M][2 N] receives  dh[r][n] = acc * gelu(g),  dh[r][N + n] = acc * a * gelu'(g)  with (a, g) = h[r % rows_x][n], h[..][N + n]
+// (h: [rows_x][2 N] bf16).  Equal to siss_gemm_nt into a [M][N] tensor followed by siss_geglu_bwd (the cotangent is rounded to bf16
+// in between in both forms) without that tensor's write and read: 4 N of 12 N bytes per row of two HBM-bound passes.
+int siss_gemm_nt_geglu_bwd(const void* A, long lda, const void* W, void* dh, const void* h, long rows_x, int M, int N, int Kp,
+                           void* stream) {
+    SISS_CHECK_ARG(h && rows_x > 0);
+    static const int zero = 0;
+    return gemm_nt_dispatch(A, lda, W, dh, 2L * N, nullptr, nullptr, N, nullptr, 0, M, N, Kp, 1, &zero, &zero, 1, 0, 0, 1.0f, 1, 0, 0, 0,
+                            nullptr, 0, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr,
+                            h, rows_x);
 }
 
 // floats in the `qstats` buffer of a product with M rows and N output channels

@@ -25,6 +25,9 @@ struct NTParams {
     long long* dbg;                   // timing probe buffer ($SISS_NT_DEBUG_PTR), normally null
     int ablate;                       // $SISS_NT_ABLATE: 1 no stores, 2 no DMA after the first two groups, 4 no MFMAs
 #endif
+    const bf16_t* gg_h;               // GEGLU backward in the epilogue (generic kernel, rows without pixel structure): the accumulator is d(out) of
+    long gg_rows_x;                   // out = a * gelu(g), h = [a | g] the saved projection ([gg_rows_x][2 N], row r % gg_rows_x); C has 2 N columns:
+                                      // C[r][n] = acc * gelu(g), C[r][N + n] = acc * a * gelu'(g) -- the [rows][N] cotangent never reaches HBM
     int d2s;                          // 0, or 1 + plane: rows are pixels of space-to-depth plane (py, px) = (plane >> 1, plane & 1); the epilogue
                                       // writes (and reads R) at the pixel's place in the FULL-resolution tensor (2 Hp - 2) x (2 Wp - 2) padded
     int nphase;                       // 0, or 2..4 PHASES in one launch (generic kernel only; d2s != 0): phase z runs the panels
@@ -134,6 +137,34 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
                 continue;
             }
             u32x4_t o = *reinterpret_cast<const u32x4_t*>(src + it * kRowsPerIt * kCRow);
+            if (p.gg_h) {
+                // (the cotangent is rounded to bf16 first, exactly as the two-launch form stores it)
+                const long rx = (long)(m0 + row0 + it * kRowsPerIt) % p.gg_rows_x;
+                const u32x4_t av = *reinterpret_cast<const u32x4_t*>(p.gg_h + rx * 2 * p.N + nc);
+                const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(p.gg_h + rx * 2 * p.N + p.N + nc);
+                u32x4_t oa, og;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float ra[2], rg[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const float d = __builtin_bit_cast(float, hh ? (o[e] & 0xffff0000u) : (o[e] << 16));
+                        const float a_ = __builtin_bit_cast(float, hh ? (av[e] & 0xffff0000u) : (av[e] << 16));
+                        const float g_ = __builtin_bit_cast(float, hh ? (gv[e] & 0xffff0000u) : (gv[e] << 16));
+                        float P, ex;
+                        gelu_parts(g_, P, ex);
+                        ra[hh] = d * g_ * P;
+                        rg[hh] = d * a_ * fmaf(g_ * 0.3989422804014327f, ex, P);
+                    }
+                    oa[e] = pack_bf2(ra[0], ra[1]);
+                    og[e] = pack_bf2(rg[0], rg[1]);
+                }
+                *reinterpret_cast<u32x4_t*>(dst) = oa;
+                *reinterpret_cast<u32x4_t*>(dst + p.N) = og;
+                dst += dstep;
+                rows_left -= kRowsPerIt;
+                continue;
+            }
             if (rsrc) {
                 const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(rsrc);
 #pragma unroll

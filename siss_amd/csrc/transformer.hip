@@ -195,21 +195,6 @@ __global__ __launch_bounds__(kThreads) void ln_dgamma_reduce_kernel(const float*
     atomicAdd((which ? dbeta : dgamma) + set * set_stride + c, (s0 + s1) + (s2 + s3));
 }
 
-// Exact-GELU pieces from ONE exponential: Phi(g) = 0.5 (1 + erf(g / sqrt 2)) with erf by Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7, far below the bf16 the results are rounded to): erf(x) = 1 - (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p x),
-// x = |g| / sqrt 2 -- and exp(-x^2) = exp(-g^2 / 2) is the density term of gelu'(g) = Phi(g) + g phi(g) as well.  libm's erff cost
-// ~30 instructions per call (two calls + an expf per element in the backward): these kernels were VALU-bound at 2.5-3.3 TB/s.
-__device__ __forceinline__ void gelu_parts(float g, float& Phi, float& e) {
-    const float x = fabsf(g) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
-    e = __builtin_amdgcn_exp2f(g * g * -0.72134752044448170f);               // exp(-g^2 / 2)
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float erf_abs = fmaf(-poly, e, 1.f);
-    Phi = 0.5f * (1.f + copysignf(erf_abs, g));
-}
-__device__ __forceinline__ float gelu_f(float g) { float P, e; gelu_parts(g, P, e); return g * P; }
-__device__ __forceinline__ float dgelu_f(float g) { float P, e; gelu_parts(g, P, e); return fmaf(g * 0.3989422804014327f, e, P); }
-
 __global__ __launch_bounds__(kThreads) void quick_gelu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long nchunks) {
     const long idx = (long)blockIdx.x * kThreads + threadIdx.x;
     if (idx >= nchunks) return;

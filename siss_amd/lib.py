@@ -36,6 +36,7 @@ SIGNATURES = {
     "siss_gemm_nt": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, I, L, L, L, P],
     "siss_gemm_nt_qstats": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, P, IP, P],
     "siss_gemm_nt_alpha_cols": [P, L, P, P, L, P, P, L, I, I, I, F, I, P],
+    "siss_gemm_nt_geglu_bwd": [P, L, P, P, P, L, I, I, I, P],
     "siss_conv3x3_sc": [P, L, P, P, L, P, P, L, P, L, P, I, P, I, I, I, IP, IP, I, I, I, P, IP, P],
     "siss_conv3x3_sc_takes": [I, I, I, I, I, I, L, L, L],
     "siss_conv3x3_dgrad_sc": [P, L, P, P, L, P, L, P, P, L, I, I, I, I, IP, IP, I, I, I, P],
@@ -405,6 +406,10 @@ def call(name, *args):
             a = args
             name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], a[4], a[5], None, a[9], a[6], a[7], a[8], a[9], a[10], 1,
                                           int_array([0]), int_array([0]), 1, 0, 0, a[11], 1, 0, 0, 0]
+        elif name == "siss_gemm_nt_geglu_bwd":              # (A, lda, W, dh, h, rows_x, M, N, Kp)
+            a = args
+            name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], 2 * a[7], None, None, a[7], None, 0, a[6], a[7], a[8], 1,
+                                          int_array([0]), int_array([0]), 1, 0, 0, 1.0, 1, 0, 0, 0]
         elif name == "siss_gemm_tn_bs":
             name, args = "siss_gemm_tn", list(args[:20])
         elif name == "siss_gemm_nt_d2s_bias":               # (A, lda, W, C, ldc, bias, M, N, Kp, npanels, shifts, coffs, rpi, Hp, Wp, plane)

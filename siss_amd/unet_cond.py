@@ -35,6 +35,7 @@ class UNetCondEngine(UNetEngine):
     # the half of the chip the side launch leaves.  Same box, alternating: B = 4 46.24 / 46.27 ms with, 46.54 / 46.66 without;
     # B = 16 110.06 / 110.04 with, 108.88 / 108.90 without.
     side_max_batch = 8
+    fuse_geglu_bwd = True      # GEGLU backward in the epilogue of the producing dgrad product (round 6)
 
     def __init__(self, cfg: UNet2DConditionConfig, device="cuda", dtype=torch.bfloat16):
         super().__init__(cfg, device, dtype=dtype)
@@ -343,10 +344,16 @@ class UNetCondEngine(UNetEngine):
             dx3 = tb(".dx3", (rows2, C))
             self._linear_bwd(dy, x3, pre + ".proj_out", rows2, rows, C, C, dx_out=dx3)
             # feed-forward
-            dgg = tb(".dgg", (rows2, 4 * C))
-            self._linear_bwd(dx3, gg, b + ".ff.net.2", rows2, rows, C, 4 * C, dx_out=dgg)
             dhff = tb(".dhff", (rows2, 8 * C))
-            lib.call("siss_geglu_bwd", dgg, hff, dhff, rows2, rows, 4 * C)
+            if self.fuse_geglu_bwd and not self.f32:
+                # the output projection's dgrad with the GEGLU backward in its epilogue (siss_gemm_nt_geglu_bwd): the [rows2, 4 C]
+                # cotangent of the GEGLU output never reaches HBM (4 of the 12 bytes per element the two launches moved)
+                self._linear_bwd(dx3, gg, b + ".ff.net.2", rows2, rows, C, 4 * C, dx_out=None)
+                lib.call("siss_gemm_nt_geglu_bwd", dx3, C, self.wT[b + ".ff.net.2.weight"], dhff, hff, rows, rows2, 4 * C, C)
+            else:
+                dgg = tb(".dgg", (rows2, 4 * C))
+                self._linear_bwd(dx3, gg, b + ".ff.net.2", rows2, rows, C, 4 * C, dx_out=dgg)
+                lib.call("siss_geglu_bwd", dgg, hff, dhff, rows2, rows, 4 * C)
             dn = tb(".dn", (rows2, C))
             self._linear_bwd(dhff, n3, b + ".ff.net.0.proj", rows2, rows, 8 * C, C, dx_out=dn)
             dx2 = tb(".dx2", (rows2, C))

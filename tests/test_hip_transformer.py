@@ -80,6 +80,37 @@ def test_geglu_fwd_bwd(dev):
         _close(dh[k * rows:(k + 1) * rows].float().cpu(), gh, 1e-2, f"geglu bwd set {k}")
 
 
+@pytest.mark.parametrize("rows,Fd,K", [(192, 256, 64), (8192, 1280, 320), (100, 640, 128)])
+def test_geglu_backward_in_the_gemm_epilogue(dev, rows, Fd, K):
+    """siss_gemm_nt_geglu_bwd: the output projection's dgrad with the GEGLU backward in its epilogue, against the two launches it
+    replaces (siss_gemm_nt into a [rows2, F] cotangent, then siss_geglu_bwd) -- the same arithmetic on the same bf16-rounded
+    cotangent: BITWISE equal (three grids: one tile round, the large-grid kernel, a ragged row tile with split K)."""
+    from siss_amd import lib
+    lib.ensure_workspace(dev)
+    g = torch.Generator().manual_seed(rows + Fd)
+    sets = 2
+    h = (torch.randn(rows, 2 * Fd, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    dy = torch.randn(sets * rows, K, generator=g).to(torch.bfloat16).to(dev)           # cotangent of y = out W^T
+    wT = (torch.randn(Fd, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)      # [F][K]: d(out) = dy wT^T
+    z = lib.int_array([0])
+    dout = torch.empty(sets * rows, Fd, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_gemm_nt", dy, K, wT, dout, Fd, None, None, Fd, None, 0, sets * rows, Fd, K, 1, z, z, 1, 0, 0, 1.0, 1, 0, 0, 0)
+    ref = torch.full((sets * rows, 2 * Fd), 3.0, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_geglu_bwd", dout, h, ref, sets * rows, rows, Fd)
+    got = torch.full((sets * rows, 2 * Fd), 5.0, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_gemm_nt_geglu_bwd", dy, K, wT, got, h, rows, sets * rows, Fd, K)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    # and against autograd of a * gelu(g) through the projection, in f32
+    hr = h.float().cpu().requires_grad_(True)
+    a, gg = hr.chunk(2, dim=-1)
+    out_ref = a * F.gelu(gg)
+    for k in range(sets):
+        d_out = (dy[k * rows:(k + 1) * rows].float() @ wT.float().t()).cpu()
+        (gh,) = torch.autograd.grad(out_ref, hr, d_out, retain_graph=True)
+        _close(got[k * rows:(k + 1) * rows].float().cpu(), gh, 1.5e-2, f"fused geglu bwd set {k}")
+
+
 @pytest.mark.parametrize("B,S,H,D,Sp,Dp", [(2, 64, 8, 40, 64, 64), (3, 7, 2, 32, 64, 64), (1, 77, 8, 160, 128, 192)])
 def test_head_split_merge_roundtrip(dev, B, S, H, D, Sp, Dp):
     from siss_amd import lib
