@@ -170,6 +170,6 @@ static inline int siss_ensure_smem(const void* kernel, int bytes, unsigned char 
 // ---- dispatch counters (diagnostics): which DEVICE KERNEL a launcher call landed on.  Tests read them through
 //      siss_dispatch_count() to prove that a parity case really exercised e.g. gemm_nt_c3p_kernel. ----
 enum SissKernelId { SISS_K_NT = 0, SISS_K_NT_C3P, SISS_K_FLASH_FWD, SISS_K_FLASH_BWD, SISS_K_NT_SPLITK, SISS_K_TN1, SISS_K_TN3,
-                    SISS_K_GN_SLAB, SISS_K_GN_QSTATS, SISS_K_FLASH_QSPLIT, SISS_K_ATTN1H_FWD, SISS_K_ATTN1H_BWD, SISS_K_TN_PAIR, SISS_K_FLASH32, SISS_K_FLASH32_FWD, SISS_K_COUNT };
+                    SISS_K_GN_SLAB, SISS_K_GN_QSTATS, SISS_K_FLASH_QSPLIT, SISS_K_ATTN1H_FWD, SISS_K_ATTN1H_BWD, SISS_K_TN_PAIR, SISS_K_FLASH32, SISS_K_FLASH32_FWD, SISS_K_NT_WIDE, SISS_K_COUNT };
 void siss_count_dispatch(int kernel_id);   // gemm_nt.hip
 void* siss_workspace(long* bytes);         // gemm_nt.hip: the current device's workspace (siss_gemm_nt_set_workspace), or null

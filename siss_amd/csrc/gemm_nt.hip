@@ -28,22 +28,27 @@ namespace {
 //   STAGES = 1  large grids: single-buffered blocks at 4 per CU (latency hidden by the other three);
 //   STAGES = 2  mid-size grids: two double-buffered blocks per CU, both k-halves' fragments in registers;
 //   STAGES = 4  grids of at most 256 tiles (the 8x8 .. 32x32 layers): a 4-deep ring, optionally split-K.
-template <int BM, int NW, int STAGES>
+//   BNT = 160 (STAGES = 1 only): 128 x 160 tiles for widths that are multiples of 160 but not of 128 (SD v1.5's 320-wide level: two
+//   column tiles instead of three, no dead MFMA columns), wave tiles 64 x 80, three blocks per CU.
+template <int BM, int NW, int STAGES, int BNT = BN>
 struct Cfg {
     static constexpr int kThreads = NW * 64;
-    static constexpr int kStageBytes = (BM + BN) * BK * 2;
+    static constexpr int kStageBytes = (BM + BNT) * BK * 2;
     static constexpr int kRing = STAGES * kStageBytes;
-    static constexpr int kSmemBytes = kRing > BM * kCRow ? kRing : BM * kCRow;
+    static constexpr int kCRowT = BNT * 2 + 16;
+    static constexpr int kSmemBytes = kRing > BM * kCRowT ? kRing : BM * kCRowT;
     static constexpr int kAPieces = BM / 8 / NW;        // 8-row DMA pieces per wave
-    static constexpr int kWPieces = BN / 8 / NW;
+    static constexpr int kWPieces = BNT / 8 / NW;
+    static constexpr int kNT = BNT / 32;                // 16-column n-tiles per wave: 4 (64-wide wave tile) or 5 (80)
     static constexpr int kPerStage = kAPieces + kWPieces;
     static constexpr int kMT = BM / (NW / 2) / 16;      // 16-row m-tiles per wave: 4 (64x64 wave tile) or 8 (128x64)
 };
 
-template <int BM, int NW, int STAGES>
-__global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void gemm_nt_kernel(const NTParams p) {
-    using C_ = Cfg<BM, NW, STAGES>;
-    constexpr int MT = C_::kMT;
+template <int BM, int NW, int STAGES, int BNT = BN>
+__global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? (BNT == BN ? 4 : 3) : 2)) void gemm_nt_kernel(const NTParams p) {
+    using C_ = Cfg<BM, NW, STAGES, BNT>;
+    constexpr int MT = C_::kMT, NTL = C_::kNT;
+    static_assert(BNT == BN || STAGES == 1, "the wide tile exists for the large grids only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
 
     // XCD-aware tile order: blocks b, b+8, ... share an L2; give each XCD a contiguous run of
     // tiles (n-tiles of one m-tile adjacent) so shifted A panels and weights hit in L2.
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + BNT - 1) / BNT, tiles_m = (p.M + BM - 1) / BM;
     const int nz = p.nphase ? p.nphase : 1;             // phases: (tile, phase) blocks on grid.x, a tile's phases adjacent
     const int nwg = tiles_n * tiles_m * nz;
     int bid = blockIdx.x;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     int bz = blockIdx.z;
     if (p.nphase) { bz = bid % nz; bid /= nz; }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BNT;
     const bf16_t* A = p.A + (long)bz * p.strideA;
     const bf16_t* W = p.W + (long)bz * p.strideW;
 
@@ -120,23 +125,23 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
         }
     };
 
-    f32x4_t acc[4][MT];   // [n-tile][m-tile]
+    f32x4_t acc[NTL][MT];   // [n-tile][m-tile]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NTL; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets (bytes within a stage), kk = 0; kk = 1 flips chunk bit 2
     const int frow = lane & 15, fq = lane >> 4;
-    int a_off[MT], w_off[4];
+    int a_off[MT], w_off[NTL];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int ra = wm * (MT * 16) + i * 16 + frow;
         a_off[i] = ra * 128 + ((fq ^ ((ra >> 1) & 7)) << 4);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rw = wn * 64 + i * 16 + frow;
+    for (int i = 0; i < NTL; ++i) {
+        const int rw = wn * (BNT / 2) + i * 16 + frow;
         w_off[i] = BM * 128 + rw * 128 + ((fq ^ ((rw >> 1) & 7)) << 4);
     }
 
@@ -174,13 +179,13 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
             // 4 blocks per CU (128 VGPRs): no room for a second fragment set; the other three blocks hide the reads
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t af[MT], wf[4];
+                bf16x8_t af[MT], wf[NTL];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sb + (a_off[i] ^ (kk << 6)));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(sb + (w_off[i] ^ (kk << 6)));
+                for (int i = 0; i < NTL; ++i) wf[i] = *reinterpret_cast<const bf16x8_t*>(sb + (w_off[i] ^ (kk << 6)));
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NTL; ++i)
 #pragma unroll
                     for (int j = 0; j < MT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
@@ -224,16 +229,17 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? 4 : 2)) void g
     if (p.ksplit > 1) {
         // accumulator order, 16 B per lane: fully coalesced, read back the same way below
         const int tile = tm * tiles_n + tn;
+        static_assert(BNT == BN || STAGES == 1, "split K keeps the 128-wide tile");
         float* base = p.slab + (long)tile * p.ksplit * (BM * BN);
         float* dst = base + (long)blockIdx.y * (BM * BN);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NTL; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 *reinterpret_cast<f32x4_t*>(dst + ((i * MT + j) * C_::kThreads + tid) * 4) = acc[i][j];
         return;                                                // gemm_nt_reduce_kernel finishes the tile
     }
-    nt_epilogue<BM, C_::kThreads, MT>(p, acc, smem, m0, n0, bz, tid, wm, wn, frow, fq);
+    nt_epilogue<BM, C_::kThreads, MT, BNT>(p, acc, smem, m0, n0, bz, tid, wm, wn, frow, fq);
 }
 
 // Second half of a split-K product: sum the ksplit partial tiles of one output tile (L2-resident, written a few
@@ -273,14 +279,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_reduce_kernel(const NTParams 
     nt_epilogue<BM, kThreads, MT>(p, acc, smem, tm * BM, tn * BN, 0, tid, wm, wn, frow, fq, true, BM, j);
 }
 
-template <int BM, int NW, int STAGES>
+template <int BM, int NW, int STAGES, int BNT = BN>
 int launch_nt(const NTParams& p, int batch, hipStream_t st) {
-    using C_ = Cfg<BM, NW, STAGES>;
+    using C_ = Cfg<BM, NW, STAGES, BNT>;
     static unsigned char attr_set[kMaxDevices];
-    if (siss_ensure_smem((const void*)gemm_nt_kernel<BM, NW, STAGES>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
+    if (siss_ensure_smem((const void*)gemm_nt_kernel<BM, NW, STAGES, BNT>, C_::kSmemBytes, attr_set) != SISS_OK) return SISS_ERR_LAUNCH;
     siss_count_dispatch(p.ksplit > 1 ? SISS_K_NT_SPLITK : SISS_K_NT);
-    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN) * (p.nphase ? p.nphase : 1), p.ksplit > 1 ? p.ksplit : 1, p.nphase ? 1 : batch);
-    gemm_nt_kernel<BM, NW, STAGES><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
+    if (BNT != BN) siss_count_dispatch(SISS_K_NT_WIDE);
+    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BNT) * (p.nphase ? p.nphase : 1), p.ksplit > 1 ? p.ksplit : 1, p.nphase ? 1 : batch);
+    gemm_nt_kernel<BM, NW, STAGES, BNT><<<grid, C_::kThreads, C_::kSmemBytes, st>>>(p);
     if (p.ksplit > 1) {
         static unsigned char attr2[kMaxDevices];
         if (siss_ensure_smem((const void*)gemm_nt_reduce_kernel<BM, NW>, BM * kCRow, attr2) != SISS_OK) return SISS_ERR_LAUNCH;
@@ -288,6 +295,11 @@ int launch_nt(const NTParams& p, int batch, hipStream_t st) {
     }
     return hipGetLastError() == hipSuccess ? SISS_OK : SISS_ERR_LAUNCH;
 }
+
+#ifndef NT_WIDE_TILES
+#define NT_WIDE_TILES 1
+#endif
+constexpr int g_wide_tiles = NT_WIDE_TILES;     // (probe builds: -DNT_WIDE_TILES=0 keeps the 128-wide tile everywhere)
 
 // split-K workspace handed over by the host (siss_gemm_nt_set_workspace), one per device
 float* g_slab_dev[kMaxDevices];
@@ -339,6 +351,10 @@ int siss_gemm_nt_set_workspace(void* ptr, long bytes) {
 long siss_dispatch_count(int kernel_id) {
     return kernel_id >= 0 && kernel_id < SISS_K_COUNT ? __atomic_load_n(&g_dispatch[kernel_id], __ATOMIC_RELAXED) : -1;
 }
+// Version of this C ABI: bumped when a struct layout changes or when the Python engines start calling a new entry point
+// unconditionally (siss_amd/lib.py refuses an override library -- bench.py --lib, SISS_LIB_PATH -- that is older than it can drive).
+// 5: round 5's final build (the first version counted).  6: round 6 (flash_attn32, siss_gemm_nt_geglu_bwd: optional, gated by lib.has).
+int siss_abi_version() { return 6; }
 int siss_dispatch_reset() {
     for (int k = 0; k < SISS_K_COUNT; ++k) __atomic_store_n(&g_dispatch[k], 0L, __ATOMIC_RELAXED);
     return SISS_OK;
@@ -459,7 +475,11 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     // (more tiles than the double-buffered form keeps resident -- 2 blocks x 256 CUs -- : that form would run a second, partly
     // empty round; A/B of the threshold on one box, 2048 / 1100 / 520 / 384 / 260 tiles: SD v1.5 B = 16 112.5 / 112.8 / 111.3 /
     // 111.5 / 111.8 ms, B = 4 46.0 / 46.9 / 45.8 / 46.2 / 46.3 ms, CelebA-HQ unchanged -- e.g. 8192 x 1280 x K 10240: 640 tiles)
-    if (tiles128 > 512) return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
+    if (tiles128 > 512) {
+        // widths that are multiples of 160 but not of 128 (320, 960): 128 x 160 tiles -- no dead columns, two thirds of the A re-reads
+        if (N % 160 == 0 && N % BN != 0 && !p.gg_h && g_wide_tiles) return launch_nt<128, 4, 1, 160>(p, batch, (hipStream_t)stream);
+        return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
+    }
     // at most one block per CU anyway: a 4-deep ring (128 KiB) keeps three K-steps of DMA in flight, so a step
     // costs its MFMA time instead of an L2 round trip (the 8x8 .. 32x32 layers are bound by the serial K loop)
     if (tiles128 <= 256) {

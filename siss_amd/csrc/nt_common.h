@@ -62,10 +62,14 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 // Epilogue of a BM x 128 output tile held as acc[i][j] (i = n-tile, j = m-tile of a 64x64 wave sub-tile).
 // MT = 16-row m-tiles per wave (4: 64-row wave tile, 8: 128-row wave tile); waves are laid out 2 (n) wide.
-template <int BM, int kThreads, int MT = 4>
-__device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4][MT], char* smem, int m0, int n0,
+// BNT: columns of the tile (128; 160 for the widths that are multiples of 160 but not of 128 -- SD's 320: two tiles instead of three):
+// a wave's sub-tile is BNT / 2 columns = BNT / 32 n-tiles, a staged row has BNT / 8 16-B chunks, one per thread and store.
+template <int BM, int kThreads, int MT = 4, int BNT = BN>
+__device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[BNT / 32][MT], char* smem, int m0, int n0,
                                             int bz, int tid, int wm, int wn, int frow, int fq,
                                             bool writer = true, int vrows = BM, int jsel = -1) {
+    constexpr int NTL = BNT / 32, kCRow = BNT * 2 + 16, NCHK = BNT / 8;
+    static_assert(BNT == 128 || BNT == 160, "tile widths");
     // jsel >= 0 (split-K reduce kernel: four blocks per tile): only the m-tile j == jsel of every wave is valid in `acc` -- the rows
     // with (row >> 4 & 3) == jsel are staged and stored, the other three quarters of the tile belong to the sibling blocks
     // ---- epilogue: bf16 tile through LDS (one 34 KiB image), then 16-B coalesced rows ----
@@ -78,10 +82,10 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
     const int b1 = (img0 + 1) * rpi - m0, b2 = b1 + rpi;
     const int last_img = (p.M - 1) / rpi;
     if (writer) {
-        f32x4_t bias4[4];
+        f32x4_t bias4[NTL];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + fq * 4;
+        for (int i = 0; i < NTL; ++i) {
+            const int n = n0 + wn * (BNT / 2) + i * 16 + fq * 4;
             bias4[i] = (p.bias && n + 4 <= p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -97,8 +101,8 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
                 rb = p.rowbias + (long)img * p.ldrb;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nl = wn * 64 + i * 16 + fq * 4;
+            for (int i = 0; i < NTL; ++i) {
+                const int nl = wn * (BNT / 2) + i * 16 + fq * 4;
                 f32x4_t v = acc[i][j];
                 const float al = (p.alpha_cols == 0 || n0 + nl < p.alpha_cols) ? p.alpha : 1.f;
 #pragma unroll
@@ -114,22 +118,24 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
     }
     __syncthreads();
     bf16_t* C = p.C + (long)bz * p.strideC;
-    const int chunk = tid & 15;           // 8 channels per chunk
+    constexpr int kRowsPerIt = kThreads / NCHK;          // 16, or 12 (of the 256 threads 240 store)
+    const int chunk = NCHK == 16 ? (tid & 15) : tid % NCHK;           // 8 channels per chunk
+    const int trow = NCHK == 16 ? (tid >> 4) : tid / NCHK;
     const int nc = n0 + chunk * 8;
-    if (nc >= p.N) return;
-    constexpr int kRowsPerIt = kThreads / 16;
+    if (nc >= p.N || trow >= kRowsPerIt) return;
+    constexpr int kIts = (BM + kRowsPerIt - 1) / kRowsPerIt;
     if (p.Hp == 0 && !p.d2s && nc + 8 <= p.N) {
         // Rows without a pixel structure (linears, attention products): no halo logic, and the output / residual addresses are
         // running pointers (one 64-bit add per row instead of a 64-bit multiply-add) -- these launches have K loops of 5-20 steps,
         // so the epilogue's vector instructions weigh as much as their MFMAs.
-        const int row0 = tid >> 4;
+        const int row0 = trow;
         bf16_t* dst = C + (long)(m0 + row0) * p.ldc + nc;
         const bf16_t* rsrc = p.R ? p.R + (long)bz * p.strideC + (long)(m0 + row0) * p.ldr + nc : nullptr;
         const long dstep = (long)kRowsPerIt * p.ldc, rstep = (long)kRowsPerIt * p.ldr;
         int rows_left = (p.M - m0 < vrows ? p.M - m0 : vrows) - row0;
         const char* src = smem + row0 * kCRow + chunk * 16;
 #pragma unroll 4
-        for (int it = 0; it < BM / kRowsPerIt; ++it) {
+        for (int it = 0; it < kIts; ++it) {
             if (rows_left <= 0) break;
             if (jsel >= 0 && (it & 3) != jsel) {             // (kRowsPerIt == 16 there: iteration it holds the rows of m-tile it & 3)
                 dst += dstep; rows_left -= kRowsPerIt;
@@ -182,10 +188,10 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[4]
         return;
     }
 #pragma unroll 4
-    for (int it = 0; it < BM / kRowsPerIt; ++it) {
-        const int row = it * kRowsPerIt + (tid >> 4);
+    for (int it = 0; it < kIts; ++it) {
+        const int row = it * kRowsPerIt + trow;
         const int r = m0 + row;
-        if (r >= p.M || row >= vrows) break;
+        if (r >= p.M || row >= vrows || row >= BM) break;
         if (jsel >= 0 && ((row >> 4) & 3) != jsel) continue;
         u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * kCRow + chunk * 16);
         long ro = r;                          // output (and residual) row

@@ -37,6 +37,7 @@ SIGNATURES = {
     "siss_gemm_nt_qstats": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, P, IP, P],
     "siss_gemm_nt_alpha_cols": [P, L, P, P, L, P, P, L, I, I, I, F, I, P],
     "siss_gemm_nt_geglu_bwd": [P, L, P, P, P, L, I, I, I, P],
+    "siss_abi_version": [],
     "siss_conv3x3_sc": [P, L, P, P, L, P, P, L, P, L, P, I, P, I, I, I, IP, IP, I, I, I, P, IP, P],
     "siss_conv3x3_sc_takes": [I, I, I, I, I, I, L, L, L],
     "siss_conv3x3_dgrad_sc": [P, L, P, P, L, P, L, P, P, L, I, I, I, I, IP, IP, I, I, I, P],
@@ -163,7 +164,7 @@ _RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_sc
 # siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
 KERNEL_IDS = {"gemm_nt_kernel": 0, "gemm_nt_c3p_kernel": 1, "flash_attn_fwd": 2, "flash_attn_bwd": 3,
               "gemm_nt_kernel/splitk": 4, "gemm_tn_kernel<1>": 5, "gemm_tn_kernel<3>": 6, "gn_slab": 7, "gn_qstats": 8, "flash_dkdv_qsplit": 9,
-              "attn1h_fwd": 10, "attn1h_bwd": 11, "gemm_tn_pair": 12, "flash32_bwd": 13, "flash32_fwd": 14}
+              "attn1h_fwd": 10, "attn1h_bwd": 11, "gemm_tn_pair": 12, "flash32_bwd": 13, "flash32_fwd": 14, "gemm_nt_kernel/wide": 15}
 
 
 def dispatch_counts(reset=False):
@@ -185,6 +186,7 @@ class TNJob(C.Structure):
 
 
 _lib = None
+MIN_ABI = 5          # oldest build an A/B may load: round 5's final (siss_tn_job with bias_set_stride, attn1h / quad_stats / grouped_capped)
 
 
 def load():
@@ -208,7 +210,24 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_long if name in _RET_LONG else C.c_int
     _lib = lib
+    if override and abi_version() < MIN_ABI:
+        _lib = None
+        raise RuntimeError(f"{LIB_PATH}: ABI version {abi_version()} < {MIN_ABI} (siss_tn_job layout / entry points the engines call "
+                           "unconditionally): rebuild that tree, or A/B against a newer build")
     return lib
+
+
+def has(name):
+    """Whether the loaded library exports `name` (an older build loaded through SISS_LIB_PATH / bench.py --lib may lack newer entry
+    points: callers switch the feature off instead of failing in the middle of a step)."""
+    return hasattr(load(), name)
+
+
+def abi_version():
+    """siss_abi_version() of the loaded library (struct layouts + the entry points the engines call unconditionally); builds
+    before round 6 have no such export and count as 5."""
+    lib = load()
+    return int(lib.siss_abi_version()) if hasattr(lib, "siss_abi_version") else 5
 
 
 _WORKSPACE = {}

@@ -345,7 +345,7 @@ class UNetCondEngine(UNetEngine):
             self._linear_bwd(dy, x3, pre + ".proj_out", rows2, rows, C, C, dx_out=dx3)
             # feed-forward
             dhff = tb(".dhff", (rows2, 8 * C))
-            if self.fuse_geglu_bwd and not self.f32:
+            if self.fuse_geglu_bwd and not self.f32 and lib.has("siss_gemm_nt_geglu_bwd"):
                 # the output projection's dgrad with the GEGLU backward in its epilogue (siss_gemm_nt_geglu_bwd): the [rows2, 4 C]
                 # cotangent of the GEGLU output never reaches HBM (4 of the 12 bytes per element the two launches moved)
                 self._linear_bwd(dx3, gg, b + ".ff.net.2", rows2, rows, C, 4 * C, dx_out=None)

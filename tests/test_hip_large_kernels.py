@@ -120,6 +120,61 @@ def test_conv3x3_on_the_persistent_and_fused_wgrad_kernels(dev, n, h, w, ci, co,
         _close(dB[s].cpu(), dy[s * n:(s + 1) * n].sum(dim=(0, 2, 3)), 2e-3, f"bias grad set {s}")
 
 
+# 128 x 160 tiles of the generic NT kernel (round 6): widths that are multiples of 160 but not of 128 on grids of more than 512 tiles
+@pytest.mark.parametrize("n,h,w,ci,co", [(8, 64, 64, 320, 320), (2, 96, 96, 64, 960), (6, 72, 72, 320, 640)])
+def test_conv3x3_and_linear_on_the_160_wide_tiles(dev, n, h, w, ci, co):
+    """SD v1.5's 320-wide level: a 3x3 convolution (bias, per-image row bias, residual, halo mask; its dgrad) and a linear layer (bias +
+    residual, ragged last row tile) whose output width is 320 / 960 land on gemm_nt_kernel<128, 4, 1, 160> -- the dispatch counter says
+    so -- against torch fp32 on the same bf16 operands; a 640-wide product of the same grid keeps the 128-wide tile."""
+    from siss_amd import lib, ops
+    from siss_amd.layout import Act
+    g = torch.Generator().manual_seed(n * 100 + h + ci + co)
+    wide = co % 160 == 0 and co % 128 != 0
+    x = _bf(torch.randn(n, ci, h, w, generator=g))
+    wt = _bf(torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3 * ci ** 0.5)))
+    bias, temb = torch.randn(co, generator=g), torch.randn(n, co, generator=g)
+    res = _bf(torch.randn(n, co, h, w, generator=g))
+    y_ref = F.conv2d(x, wt, bias, padding=1) + temb[:, :, None, None] + res
+    xa, ra = Act.from_nchw(x, dev), Act.from_nchw(res, dev)
+    wn = ops.conv_w_to_native(wt).to(dev)
+    out = Act(n, h, w, co, dev)
+    out.buf.fill_(7.0)
+    out.buf[: out.guard * co] = 0
+    out.buf[-out.guard * co:] = 0
+    lib.dispatch_counts(reset=True)
+    ops.conv_fprop(xa, wn.to(torch.bfloat16), out, bias=bias.to(dev), rowbias=temb.to(dev), residual=ra)
+    torch.cuda.synchronize()
+    cnt = lib.dispatch_counts(reset=True)
+    # (a width of whole 128-column tiles goes to the persistent 3x3 kernel)
+    assert cnt["gemm_nt_kernel"] + cnt["gemm_nt_c3p_kernel"] == 1 and cnt["gemm_nt_kernel/wide"] == (1 if wide else 0), cnt
+    assert out.halo_is_zero()
+    _close(out.to_nchw().cpu(), y_ref, 1e-2, "fprop")
+    if ci % 160 == 0 and ci % 128 != 0:                       # the dgrad's width is the input's
+        dy = _bf(torch.randn(n, co, h, w, generator=g))
+        xr = x.clone().requires_grad_(True)
+        (dx_ref,) = torch.autograd.grad(F.conv2d(xr, wt, padding=1), xr, dy)
+        dx = Act(n, h, w, ci, dev)
+        dx.buf.fill_(-3.0)
+        dx.buf[: dx.guard * ci] = 0
+        dx.buf[-dx.guard * ci:] = 0
+        ops.conv_dgrad(Act.from_nchw(dy, dev), ops.dgrad_weight(wn), dx)
+        torch.cuda.synchronize()
+        assert lib.dispatch_counts(reset=True)["gemm_nt_kernel/wide"] == 1
+        assert dx.halo_is_zero()
+        _close(dx.to_nchw().cpu(), dx_ref, 1e-2, "dgrad")
+    # a linear layer on token rows (no pixel structure: the running-pointer store path), ragged last row tile
+    rows = n * h * w - 37
+    xl = _bf(torch.randn(rows, ci, generator=g))
+    wl = _bf(torch.randn(co, ci, generator=g) / ci ** 0.5)
+    rl = _bf(torch.randn(rows, co, generator=g))
+    yl = torch.full((rows, co), 5.0, dtype=torch.bfloat16, device=dev)
+    xd, wd, rd, bd = xl.to(torch.bfloat16).to(dev), wl.to(torch.bfloat16).to(dev), rl.to(torch.bfloat16).to(dev), bias.to(dev)
+    ops.gemm_nt(lib.ptr(xd), ci, wd, lib.ptr(yl), co, rows, co, ci, [0], [0], bias=bd, res_ptr=lib.ptr(rd), ldr=co)
+    torch.cuda.synchronize()
+    assert lib.dispatch_counts(reset=True)["gemm_nt_kernel/wide"] == (1 if wide else 0)
+    _close(yl.float().cpu(), _bf(xl @ wl.t() + bias) + rl, 1e-2, "linear")
+
+
 # (n, h, w, cin of the 3x3, cout, channels of the shortcut's input, row stride of that input [0 = its channel count], statistics)
 SC_CASES = [
     (2, 128, 128, 128, 128, 256, 0, False),      # up-block shape: 256-channel concat -> 128; one tile crosses the image seam
