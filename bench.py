@@ -262,12 +262,31 @@ def main():
         st.autotune_overlap(one_step)          # overlapped vs serial gradient exchange: keep the faster (untimed)
         sync()
     graph = None
-    # Multi-GPU: the step contains an RCCL all-reduce; capturing a collective into a hipGraph is not something
-    # this repo can test (no multi-GPU box in the build loop), and the eager schedule is GPU-bound anyway
-    # (67.75 ms eager vs 67.71 ms replayed at N=1 on the same box, end of round 1), so N>1 launches eagerly unless
-    # SISS_GRAPH_DP=1.
-    use_graph = a.graph and (world == 1 or os.environ.get("SISS_GRAPH_DP") == "1")
-    if use_graph:
+    graph_note = None
+    # Multi-GPU: the step contains an RCCL all-reduce.  A world-size-1 communicator captured and replayed such a step
+    # (tests/test_hip_rccl.py); whether the multi-rank kernels do, and whether it pays, is measured here like the exchange modes:
+    # "serial + hipGraph" is one more autotune candidate (SISSStepper.try_captured_serial: every rank captures, the ranks agree on the
+    # outcome, a failure anywhere falls back to the eager schedule in process).  SISS_GRAPH_DP=0 skips the candidate, =1 takes it
+    # whenever it captures.
+    gdp = os.environ.get("SISS_GRAPH_DP", "auto")
+    if world > 1 and a.graph and gdp != "0":
+        prev = (st.overlap, st.exchange)
+        g_, secs, err = st.try_captured_serial(one_step)
+        tim = getattr(st, "overlap_timings", None) or {}
+        eager_best = min([v for k, v in tim.items() if k.endswith("_ms") and isinstance(v, float)], default=None)
+        if g_ is not None:
+            tim["serial_hipgraph_ms"] = secs * 1e3
+            if gdp == "1" or eager_best is None or secs * 1e3 < eager_best:
+                graph, graph_note = g_, "serial all-reduce inside the step's hipGraph"
+            else:
+                st.set_overlap(*prev)                    # an eager mode was faster on this node
+                del g_
+        else:
+            tim["serial_hipgraph_error"] = err
+        st.overlap_timings = tim
+        sync()
+    use_graph = (a.graph and world == 1) or graph is not None
+    if use_graph and graph is None:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -519,7 +538,7 @@ def main():
                        "hipgraph": bool(use_graph), "rng_in_timed_region": True,
                        "eager_task_loop_ms_per_step": round(eager_ms, 3) if eager_ms else None,
                        **({"dp_selfcheck": selfcheck} if selfcheck else {}),
-                       **({"dp_exchange": "overlapped all-reduce (two grouped collectives)" if st.overlap else "serial " + st.exchange,
+                       **({"dp_exchange": graph_note or ("overlapped all-reduce (two grouped collectives)" if st.overlap else "serial " + st.exchange),
                            "dp_autotune": getattr(st, "overlap_timings", None),
                            "dp_allreduce": exchange} if world > 1 else {})},
             "step_tflop_algorithmic": step_tflop,
@@ -530,6 +549,14 @@ def main():
             "kernel_ms_per_step": {k: round(v[1] / max(min(a.steps, 3), 1), 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]},
         }
         print(json.dumps(out))
+        if world > 1:
+            # one grep-able line beside the JSON (stderr: stdout carries the ONE JSON line): did every rank take part, which exchange
+            # ran, what a link moved
+            ar = (exchange or {}).get("allreduce") or {}
+            print(f"[siss dp] rccl_ranks_seen={(selfcheck or {}).get('rccl_ranks_seen')} world={world} "
+                  f"mode={out['config']['dp_exchange']!r} hipgraph={bool(use_graph)} "
+                  f"allreduce_ms={ar.get('ms')} bus_GBps_per_link={ar.get('bus_GBps_per_link')} ms_per_step={out['ms_per_step']}",
+                  file=sys.stderr, flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -540,13 +567,27 @@ def _smi_under_load(enqueue):
     import re
     import shutil
     import subprocess
-    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(exe):
+    # Never under a profiler: rocprofv3's preloaded library initialises the GPU in every child that inherits its environment, and
+    # rocm-smi is a `#!/usr/bin/env python3` script -- the env -> python3 hop would then be an exec of a GPU-initialised process
+    # (ADVICE r05).  Otherwise: the interpreter invoked directly on the script (no shebang hop), with the preload / tool variables
+    # scrubbed from the child's environment anyway.
+    if any(k == "LD_PRELOAD" or k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_", "HSA_TOOLS_")) for k in os.environ):
         return None
+    script = "/opt/rocm/libexec/rocm_smi/rocm_smi.py"
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if os.path.exists(script):
+        cmd = [sys.executable, script]
+    elif os.path.exists(exe):
+        cmd = [exe]
+    else:
+        return None
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_", "HSA_TOOLS_"))}
     try:
         enqueue()
         time.sleep(0.3)                                # (the first replays ramp the clocks)
-        r = subprocess.run([exe, "--showpower", "--showmaxpower", "--showclocks", "--showtemp"], capture_output=True, text=True, timeout=20)
+        r = subprocess.run(cmd + ["--showpower", "--showmaxpower", "--showclocks", "--showtemp"], capture_output=True, text=True,
+                           timeout=20, env=env)
         txt = r.stdout
         grab = lambda pat: (lambda m: float(m.group(1)) if m else None)(re.search(pat, txt))
         out = {"power_w": grab(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)"),

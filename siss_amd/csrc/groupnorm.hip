@@ -672,7 +672,7 @@ long siss_gn_partial_words(int n, int H, int W, int C, int G) {
 // GroupNorm statistics of a padded-NHWC tensor (M flat rows of N channels, row stride ld elements, zero halo rows) in the format
 // the persistent 3x3 convolution leaves them (siss_gemm_nt_qstats; siss_conv_qstats_words(M, N) floats): what siss_groupnorm_fwd_qs
 // takes as qsA / qsB for a producer that forms none.  rows_per_image >= 256 (a 254-row tile spans at most two images), N % 8 == 0,
-// N <= 2048.  One read of the tensor.
+// N <= 512 (one block folds a tile's quads: four partial sums per 8-channel chunk in 256 threads).  One read of the tensor.
 int siss_quad_stats(const void* x, long ld, int M, int N, int rows_per_image, float* qs, void* stream) {
     SISS_CHECK_ARG(x && qs && M > 0 && N > 0 && N % 8 == 0 && N <= 8 * kThreads && ld >= N && ld % 8 == 0 && rows_per_image >= 256);
     SISS_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)qs % 8 == 0 && (N >> 3) * 4 <= kThreads);

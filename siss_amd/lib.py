@@ -401,8 +401,9 @@ def kernel_symbol(name, a):
     return name
 
 
-def call(name, *args):
-    """Call a launcher on torch's current stream; tensors are passed as raw pointers."""
+def call(name, *args, refusable=False):
+    """Call a launcher on torch's current stream; tensors are passed as raw pointers.  refusable: status 1 (a shape the launcher
+    does not take) is RETURNED instead of raised -- for entry points documented to refuse shapes the caller then runs another way."""
     lib = load()
     if getattr(_MODE, "f32", False):
         if name in F32_ENTRY:
@@ -455,9 +456,14 @@ def call(name, *args):
         PROF.append((base, s, e, _work(name, args), _shape_key(name, args), kernel_symbol(name, args), hbm_bytes(name, args)))
     else:
         rc = fn(*conv, stream_ptr())
+    if rc == 1 and refusable:
+        if PROF is not None:
+            PROF.pop()                      # nothing ran
+        return 1
     if rc != 0:
         raise RuntimeError(f"{name} failed with status {rc} "
                            f"({'bad argument' if rc == 1 else 'launch error'})")
+    return 0
 
 
 def query(name, *args):

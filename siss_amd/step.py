@@ -182,6 +182,58 @@ class SISSStepper:
             self.overlap_timings["errors"] = errors
         return self.overlap
 
+    def try_captured_serial(self, step_fn, iters=3):
+        """N > 1 insurance (round 6): the step with its SERIAL all-reduce captured into a hipGraph, as one more candidate beside the eager
+        exchange modes (a world-size-1 RCCL communicator captured and replayed such a step: tests/test_hip_rccl.py; whether the
+        multi-rank kernels do is the node's to say).  Captures on every rank, AGREES on the outcome (a rank-local failure makes every
+        rank fall back: nobody replays a graph the others do not have), times `iters` replays (max over ranks) and restores
+        parameters / moments / stepper state.  Returns (graph, seconds per step, None) with the stepper left on the serial exchange,
+        or (None, None, reason) with the previous exchange mode restored -- in process, no re-exec, no relaunch."""
+        dist = torch.distributed
+        import time
+        self._gather_optimizer_state()
+        saved = [t.clone() for t in (self.opt.p, self.opt.m, self.opt.v, self.opt.scalars)]
+        saved_state = (self.superfactor, self.last, self._micro)
+        prev = (self.overlap, self.exchange)
+        self.set_overlap(False, "allreduce")
+        graph, err, secs = None, None, None
+        try:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=self.e.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                step_fn()                                            # settle allocations on the capture stream
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    step_fn()
+            cur.wait_stream(side)
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:                                       # capture refused / launch error: eager it is
+            err, graph = (str(e) or type(e).__name__)[:200], None
+        flags = [None] * self.world
+        dist.all_gather_object(flags, err is None, group=self.pg)
+        if all(flags):
+            dist.barrier(group=self.pg); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                graph.replay()
+            dist.barrier(group=self.pg); torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], device=self.e.device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.pg)
+            secs = float(tt.item()) / iters
+        else:
+            graph, err = None, err or "capture failed on another rank"
+            torch.cuda.synchronize()
+        self._pending, self._state_shard = [], None
+        for dst, src in zip((self.opt.p, self.opt.m, self.opt.v, self.opt.scalars), saved):
+            dst.copy_(src)
+        self.superfactor, self.last, self._micro = saved_state
+        self.e.refresh_weights(cast_shadow=True)
+        if graph is None:
+            self.set_overlap(*prev)
+        return graph, secs, err
+
     # ------------------------------------------------------------------ one micro-batch
     def micro_step(self, x0, a0, noise, t, u, conditioning=None, erase_target=None):
         """Inputs: x0/a0/noise [B,C,H,W] (cast to the io dtype like delete_celeb.py:561-581),

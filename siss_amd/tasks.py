@@ -231,37 +231,43 @@ class _DeleteBase(Task):
 
         def write_log(handle, meta):
             st = handle.get()
-            st["global_step"], st["lr"] = meta
-            st["elapsed_s"] = time.perf_counter() - t0
+            st["global_step"], st["lr"], st["elapsed_s"] = meta          # (elapsed: stamped when the step was queued)
             log.write(json.dumps(st) + "\n")
             log.flush()
             if rank == 0:
                 print(f"step {meta[0]}/{n_steps}  |g_x| {st['norm_loss_x']:.4g}  |g_a| {st['norm_loss_a']:.4g}  "
                       f"s {st['scaling_factor']:.4g}")
 
-        for step in range(n_steps):
-            # lr_scheduler.step() after every optimizer step (delete_celeb.py:770); accelerate's wrapper advances the
-            # schedule once per PROCESS per optimizer step (AcceleratedScheduler, split_batches=False)
-            stepper.opt.lr = lr * lr_multiplier(lr_name, step * world, warm, total)
-            for _ in range(ga):
-                x0 = self.prepare_batch(next(it_all).to(device, non_blocking=True), g)
-                a0 = self.prepare_batch(next(it_del).to(device, non_blocking=True), g)
-                noise = self.sample_noise(x0.shape, device, g)                      # SAME noise for both batches
-                t = torch.randint(self.timestep_low, T, (B,), device=device, generator=g)
-                u = torch.rand(B, device=device, generator=g)
-                stepper.micro_step(x0, a0, noise, t, u, cond)
-            # the step's scalars travel to the host behind its kernels; they are read (and logged) once the NEXT step is queued,
-            # so the device never waits for the host between steps (same lines, written one step later)
-            handle, meta = stepper.stats_async(), (step + 1, stepper.opt.lr)
+        try:
+            for step in range(n_steps):
+                # lr_scheduler.step() after every optimizer step (delete_celeb.py:770); accelerate's wrapper advances the
+                # schedule once per PROCESS per optimizer step (AcceleratedScheduler, split_batches=False)
+                stepper.opt.lr = lr * lr_multiplier(lr_name, step * world, warm, total)
+                for _ in range(ga):
+                    x0 = self.prepare_batch(next(it_all).to(device, non_blocking=True), g)
+                    a0 = self.prepare_batch(next(it_del).to(device, non_blocking=True), g)
+                    noise = self.sample_noise(x0.shape, device, g)                      # SAME noise for both batches
+                    t = torch.randint(self.timestep_low, T, (B,), device=device, generator=g)
+                    u = torch.rand(B, device=device, generator=g)
+                    stepper.micro_step(x0, a0, noise, t, u, cond)
+                # the step's scalars travel to the host behind its kernels; they are read (and logged) once the NEXT step is queued,
+                # so the device never waits for the host between steps (same lines, written one step later)
+                handle, meta = stepper.stats_async(), (step + 1, stepper.opt.lr, time.perf_counter() - t0)
+                if pending is not None:
+                    write_log(*pending)
+                pending = (handle, meta)
+                if eval_every and (step + 1) % eval_every == 0 and not isinstance(self, DeleteSD):
+                    write_log(*pending)                 # every rank flushes at an evaluation step (the logs stay in step)
+                    pending = None
+                    if rank == 0:
+                        self.evaluate(unet, sched, ds_del[0], step + 1, device)
+        finally:
+            # the last COMPLETED optimizer step reaches the log also when the next one raises or the job is interrupted
             if pending is not None:
-                write_log(*pending)
-            pending = (handle, meta)
-            if rank == 0 and eval_every and (step + 1) % eval_every == 0 and not isinstance(self, DeleteSD):
-                write_log(*pending)
-                pending = None
-                self.evaluate(unet, sched, ds_del[0], step + 1, device)
-        if pending is not None:
-            write_log(*pending)
+                try:
+                    write_log(*pending)
+                except Exception:
+                    pass
         it_all.close()
         if rank == 0 and cfg.get("save_final", True):
             unet.save_pretrained(os.path.join(cfg.output_dir, "unet"))

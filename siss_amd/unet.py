@@ -185,9 +185,6 @@ class UNetEngine:
     # (csrc/attn1h.hip) between a fused q / k / v projection and to_out as a 1x1 convolution on the padded layout -- 9 launches per
     # site and step where the materialised form (False) takes 26
     fused_attn = True
-    # One-panel weight gradients at the TOP resolution (a resnet's 1x1 conv_shortcut, conv_out, conv_in: HBM-bound launches at
-    # 200-520 TF/s) wait for the next fused 3-tap weight gradient and ride in ITS launch (siss_gemm_tn_pair: one round of blocks
-    # shared by the two products; the streaming one-tap blocks run beside MFMA-bound 3-tap blocks)
     # WEIGHT GRADIENTS ON A SIDE STREAM (round 5).  Nothing in the backward pass waits for a weight gradient (they only feed the flat
     # gradient buffer), and the low-resolution middle of the pass (up / mid / down blocks at <= side_max_px pixels: grids of 13-160
     # tiles on a 256-CU chip, GroupNorm slabs, attention) leaves most CUs idle.  When the pass enters it, the grouped launches queued
@@ -205,6 +202,10 @@ class UNetEngine:
     side_max_px = 256
     side_follow = 1            # the grouped launches that fill up AFTER the first batch go to the side stream too (behind it)
     prep_side = True
+    # One-panel weight gradients at the TOP resolution (a resnet's 1x1 conv_shortcut, conv_out, conv_in: HBM-bound launches at
+    # 200-520 TF/s) wait for the next fused 3-tap weight gradient and ride in ITS launch (siss_gemm_tn_pair: one round of blocks
+    # shared by the two products; the streaming one-tap blocks run beside MFMA-bound 3-tap blocks).  Round 6 A/B (same box, CelebA-HQ
+    # B = 16, alternating): 51.59 / 51.85 ms with, 51.69 / 52.12 without -- kept (docs/experiments.md).
     pair_top = True
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
@@ -800,7 +801,11 @@ class UNetEngine:
             # the partner: a waiting product over the SAME cotangent (the resnet's own conv_shortcut: its Y tiles are in L2), else the oldest
             same = [i for i, (_, d) in enumerate(self._pair1) if d is dy]
             j1, dy1 = self._pair1.pop(same[0] if same else 0)
-            lib.call("siss_gemm_tn_pair", lib.C.byref(job), lib.C.byref(j1), 0)
+            # (the launcher refuses a pair it cannot split over the device -- fewer CUs than the 3-tap product's base grid needs, no
+            # room for a one-tap block: status 1 -- the two products then run as launches of their own)
+            if lib.call("siss_gemm_tn_pair", lib.C.byref(job), lib.C.byref(j1), 0, refusable=True):
+                self._launch_tn_job(job)
+                self._launch_tn_job(j1)
             if not any(d is dy1 for _, d in self._pair1):
                 self._unhold(dy1)
             return

@@ -229,6 +229,21 @@ def main():
             rec["error"] = f"{type(e).__name__}: {str(e)[:400]}"
         OUT["graph_capture"] = rec
         OUT["no_group"] = {k: ref_stats[k] for k in KEYS}
+        # (v) the same as bench.py's autotune candidate (SISSStepper.try_captured_serial, round 6): capture, agree, time, RESTORE --
+        # the step after it must equal the no-group step again (parameters, moments and step counter put back)
+        if rec.get("replayed"):
+            eng.load_state_dict(sd)
+            st.opt.m.zero_(); st.opt.v.zero_(); st.opt.scalars.zero_()
+            st.set_overlap(True, "allreduce")
+            g2, secs, err = st.try_captured_serial(lambda: st.step(*mb))
+            cand = {"captured": g2 is not None, "ms_per_step": None if secs is None else secs * 1e3, "error": err,
+                    "mode_after": ("overlap" if st.overlap else "serial") + "/" + st.exchange}
+            if g2 is not None:
+                g2.replay()                                          # the kept graph replays from the restored state
+                torch.cuda.synchronize()
+                same_step(st.stats(), ref_stats, "replay after try_captured_serial")
+                cand["state_restored"] = True
+            OUT["captured_serial_candidate"] = cand
     finish(True)
     if MODE == "graph":          # a refused capture can leave the communicator in a state whose teardown blocks: the record is out, leave
         sys.stdout.flush(); sys.stderr.flush()

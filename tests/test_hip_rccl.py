@@ -49,3 +49,9 @@ def test_hipgraph_capture_of_a_step_with_its_collective_is_attempted_and_recorde
     gc = rec["graph_capture"]
     assert gc["attempted"]
     assert gc.get("replay_matches_no_group_step") or gc.get("error"), gc
+    # (v) bench.py's N > 1 autotune candidate: captured -> the stepper stays on the serial exchange and its state is put back;
+    # refused -> the previous mode is restored (in process)
+    if gc.get("replayed"):
+        cand = rec["captured_serial_candidate"]
+        assert (cand["captured"] and cand["state_restored"] and cand["mode_after"] == "serial/allreduce") or \
+               (not cand["captured"] and cand["error"] and cand["mode_after"] == "overlap/allreduce"), cand

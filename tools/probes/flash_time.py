@@ -28,6 +28,6 @@ if os.environ.get("CLOCK"):
         lib.call("siss_flash_attn_bwd_merged", q, C, k, C, v, C, o, C, do, C, lse, delta, dq, C, dk, C, dv, C, 2 * B, B, H, S, S, D, sc, PRE)
     for _ in range(3):
         time.sleep(0.8)
-        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True).stdout
+        out = subprocess.run([sys.executable, "/opt/rocm/libexec/rocm_smi/rocm_smi.py", "--showpower", "--showclocks"], capture_output=True, text=True).stdout   # (no env-shebang hop)
         print(" | ".join(l.strip() for l in out.splitlines() if "sclk" in l or "Power (W)" in l or "Average Graphics" in l))
     torch.cuda.synchronize()
