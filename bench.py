@@ -269,7 +269,8 @@ def main():
     # outcome, a failure anywhere falls back to the eager schedule in process).  SISS_GRAPH_DP=0 skips the candidate, =1 takes it
     # whenever it captures.
     gdp = os.environ.get("SISS_GRAPH_DP", "auto")
-    if world > 1 and a.graph and gdp != "0":
+    # (RCCL only: the gloo rehearsal's collectives synchronise with the host and cannot be captured)
+    if world > 1 and a.graph and gdp != "0" and torch.distributed.get_backend() == "nccl":
         prev = (st.overlap, st.exchange)
         g_, secs, err = st.try_captured_serial(one_step)
         tim = getattr(st, "overlap_timings", None) or {}
