@@ -765,6 +765,22 @@ int siss_gemm_nt_d2s_bias_f32(const void* A, long lda, const void* W, void* C, l
     return nt_f32(A, lda, W, C, ldc, bias, nullptr, 0, nullptr, 0, M, N, Kp, npanels, shifts, coffs, rows_per_image, Hp, Wp, 1 + plane, stream);
 }
 
+// siss_gemm_nt_d2s_phases with f32 tensors (round 6: the one-launch form of the four planes / phases is part of the schedule the f32
+// instrument covers): the four single-plane products one after the other -- the same arithmetic per element, W's planes back to back.
+int siss_gemm_nt_d2s_phases_f32(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const void* R, long ldr,
+                                int M, int N, int Kp, const int* phase_p0, const int* shifts, const int* coffs, int rows_per_image,
+                                int Hp, int Wp, void* stream) {
+    SISS_CHECK_ARG(phase_p0 && phase_p0[0] == 0 && shifts && coffs && Hp > 2 && Wp > 2 && W);
+    for (int z = 0; z < 4; ++z) {
+        const int np = phase_p0[z + 1] - phase_p0[z];
+        SISS_CHECK_ARG(np >= 1);
+        const int rc = nt_f32(A, lda, (const float*)W + (long)phase_p0[z] * N * Kp, C, ldc, bias, nullptr, 0, R, ldr, M, N, Kp, np,
+                              shifts + phase_p0[z], coffs + phase_p0[z], rows_per_image, Hp, Wp, 1 + z, stream);
+        if (rc != SISS_OK) return rc;
+    }
+    return SISS_OK;
+}
+
 // siss_conv3x3_sc with f32 tensors: C = conv1x1(A2; W2) + bias2 first, then C = conv3x3(A; W) + bias + rowbias + C.  No statistics
 // (`written` reports 0: the consuming GroupNorm makes its own pass).
 int siss_conv3x3_sc_f32(const void* A, long lda, const void* W, void* C, long ldc, const float* bias, const float* rowbias, long ldrb,

@@ -128,7 +128,7 @@ F32_ENTRY.update({"siss_transpose_bf16": "siss_transpose_f32", "siss_cast_f32_bf
                   "siss_conv_weight_dgrad_multi_bf16": "siss_conv_weight_dgrad_multi_f32"})
 # round 5: f32 forms of the engine's SCHEDULE SWITCHES (folded shortcut, depth-to-space epilogue, sub-pixel upsample, grouped wgrads),
 # so that UNetEngine(dtype=float32, f32_fused=True) runs the fused schedule against the fp32 oracle
-F32_ENTRY.update({n: n + "_f32" for n in ("siss_gemm_nt_d2s", "siss_gemm_nt_d2s_bias", "siss_conv3x3_sc", "siss_conv3x3_dgrad_sc",
+F32_ENTRY.update({n: n + "_f32" for n in ("siss_gemm_nt_d2s", "siss_gemm_nt_d2s_bias", "siss_gemm_nt_d2s_phases", "siss_conv3x3_sc", "siss_conv3x3_dgrad_sc",
                                           "siss_gemm_tn_bs", "siss_gemm_tn_grouped", "siss_groupnorm_bwd_ld_s2d",
                                           "siss_upsample_phase_weights")})
 F32_SAME = {"siss_upsample_phase_wgrad_fold", "siss_timestep_sincos", "siss_linear_small_fwd", "siss_linear_small_bwd", "siss_linear_multi_fwd", "siss_linear_multi_bwd",

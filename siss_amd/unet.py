@@ -1144,7 +1144,7 @@ class UNetEngine:
             if self.d2s_epilogue:
                 # each plane GEMM writes its pixels straight to their place in dx (and adds the cotangent x already has):
                 # no dz tensor, no depth-to-space pass
-                if self.phase_launch and not self.f32 and len(planes) == 4:
+                if self.phase_launch and (not self.f32 or self.f32_fused) and len(planes) == 4:
                     p0 = [0]                             # the four planes' products as ONE launch
                     for plane in sorted(planes):
                         p0.append(p0[-1] + len(planes[plane]))
@@ -1211,7 +1211,7 @@ class UNetEngine:
             py, px = plane >> 1, plane & 1
             return [(a + py - 1) * wp + (b + px - 1) for a in range(2) for b in range(2)]
         z4 = lib.int_array([0] * 4)
-        if self.phase_launch and not self.f32:           # the four phase products as ONE launch
+        if self.phase_launch and (not self.f32 or self.f32_fused):    # the four phase products as ONE launch
             lib.call("siss_gemm_nt_d2s_phases", x.data, ldx, wf, y.data, getattr(y, "ld", C), ps.p(pre + ".conv.bias"), None, 0,
                      x.rows, C, C, lib.int_array([0, 4, 8, 12, 16]),
                      lib.int_array([s_ for plane in range(4) for s_ in phase_shifts(plane)]), lib.int_array([0] * 16),

@@ -252,7 +252,7 @@ def test_engine_forms_statistics_once_per_skip_tensor(dev):
         eng.quad_stats = on
         calls = []
         orig = lib.call
-        lib.call = lambda name, *a, _o=orig, _c=calls: (_c.append(name), _o(name, *a))[1]
+        lib.call = lambda name, *a, _o=orig, _c=calls, **k: (_c.append(name), _o(name, *a, **k))[1]
         try:
             for _ in range(2):                              # twice: the entries of the first pass must not serve the second
                 pred = eng.forward(x if _ == 1 else x * 0.5, t).clone()

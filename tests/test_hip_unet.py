@@ -512,7 +512,7 @@ def test_depth_to_space_in_the_dgrad_epilogue_equals_the_separate_pass():
         eng.d2s_epilogue, eng.phase_launch = bool(fused), fused == "one launch"
         calls = []
         orig = lib.call
-        lib.call = lambda name, *a, _o=orig, _c=calls: (_c.append(name), _o(name, *a))[1]
+        lib.call = lambda name, *a, _o=orig, _c=calls, **k: (_c.append(name), _o(name, *a, **k))[1]
         try:
             eng.forward(x, t)
             eng.zero_grad()
@@ -640,7 +640,7 @@ def test_folded_shortcut_equals_the_separate_1x1_product():
         eng.fold_shortcut = fold
         calls = []
         orig = lib.call
-        lib.call = lambda name, *a, _o=orig, _c=calls: (_c.append(name), _o(name, *a))[1]
+        lib.call = lambda name, *a, _o=orig, _c=calls, **k: (_c.append(name), _o(name, *a, **k))[1]
         try:
             pred = eng.forward(x, t).clone()
             eng.zero_grad()
