@@ -33,6 +33,11 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes table binds exactly the declared set
     assert sorted(lib.SIGNATURES) == names
     lib.load()
+    # the export count DESIGN.md quotes is the header's (tools/gen_header.py writes it between the markers)
+    d = open(os.path.join(ROOT, "DESIGN.md")).read()
+    m = re.search(r"<!--exports-->(\d+) ", d)
+    assert m and int(m.group(1)) == len(names), (m and m.group(1), len(names))
+    assert lib.abi_version() >= lib.MIN_ABI
 
 
 def test_ctypes_table_has_the_arity_of_every_prototype():
