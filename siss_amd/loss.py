@@ -39,6 +39,7 @@ def mixture_fwd(x0, a0, noise, t, u, alphas_cumprod, gamma_tab, sigma_tab, lambd
     mixture row select (ddpm_deletion_loss.py:18-23) and IS weights (:33-45)."""
     assert x0.is_cuda and x0.shape == a0.shape == noise.shape and x0.dtype == a0.dtype == noise.dtype
     assert x0.dtype in (torch.float32, torch.bfloat16)
+    assert alphas_cumprod.is_cuda and gamma_tab.is_cuda and sigma_tab.is_cuda, "the schedule tables are read by the kernel: device tensors"
     x0, a0, noise = x0.contiguous(), a0.contiguous(), noise.contiguous()
     B = x0.shape[0]
     chw = x0[0].numel()
