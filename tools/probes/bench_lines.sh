@@ -1,0 +1,10 @@
+out=gpurun_out/evidence_r06
+mkdir -p $out
+cp gpurun_out/r06_hbm_traffic.json profiles/latest_hbm_traffic.json 2>/dev/null || cp $out/r06_hbm_traffic.json profiles/latest_hbm_traffic.json
+python bench.py --steps 20 --warmup 3 > $out/bench_celeb_bs16.json 2> $out/bench_celeb_bs16.err
+python bench.py --steps 20 --warmup 3 --loss-fn double_forward_with_neg_del --no-cpu-baseline > $out/bench_celeb_bs16_no_is.json 2> /dev/null
+python bench.py --config sd15 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_sd15_bs16.json 2> /dev/null
+python bench.py --config sd15 --batch 4 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_sd15_bs4.json 2> /dev/null
+for f in bench_celeb_bs16 bench_celeb_bs16_no_is bench_sd15_bs16 bench_sd15_bs4; do python -c "
+import json,sys
+d=json.loads(open('$out/$f.json').read().strip().splitlines()[-1]); print('$f', d['ms_per_step'], d['value'], d.get('device_under_load'), d['step_scalars'])"; done
