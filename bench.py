@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("SISS_GRAPH", "1")),
                     help="replay the step from a captured hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--engine-attr", action="append", default=[], help="name=int: set a schedule switch of the engine (A/B runs)")
+    ap.add_argument("--stepper-attr", action="append", default=[], help="name=int: set a switch of the stepper (A/B runs)")
     ap.add_argument("--lib-set", action="append", default=[], help="name=int: call a process-wide setter of the library (A/B runs)")
     ap.add_argument("--lib", default=None, help="path of another build of libsiss_hip.so (same-box A/B of a kernel change)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,6 +238,10 @@ def main():
                          process_group=pg, mixed_precision="bf16")
         x0 = (torch.rand(B, cin, hw, hw, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
         a0 = (torch.rand(1, cin, hw, hw, generator=g, device=dev) * 2 - 1).repeat(B, 1, 1, 1).to(torch.bfloat16)
+    for kv in filter(None, a.stepper_attr):
+        k, v = kv.split("=")
+        assert hasattr(st, k), k
+        setattr(st, k, type(getattr(st, k))(int(v)))
     # The per-micro-step draws of the reference loop are INSIDE the timed step (delete_celeb.py:581 noise =
     # randn(shape, dtype=weight_dtype), :593 t = randint(999, 1000), ddpm_deletion_loss.py:18 rand(B) > lambd): device
     # RNG from the default generator, whose philox offset advances correctly under hipGraph replay.

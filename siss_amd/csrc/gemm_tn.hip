@@ -651,6 +651,12 @@ static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW,
     const int rows = row_end - row_begin;
     const bool overwrite = nsplits == -1;                  // one split per tile, dW = product (no read, no zero fill needed)
     if (overwrite) nsplits = 1;
+    // -2 (round 6): automatic like 0, and a product that lands on ONE split OVERWRITES its tiles instead of read-add-writing them
+    // (the caller knows that this is the first product into dW since it was zeroed: the first micro-batch of a step) -- the
+    // low-resolution layers' weight gradients are bound by their output (a 1280 x 1280 x 9 tile set against a 400-row reduction),
+    // and the read was half of its traffic.  Products that split still add atomically into the zeroed dW.
+    const bool overwrite_if_one = nsplits == -2;
+    if (overwrite_if_one) nsplits = 0;
     const bool automatic = nsplits <= 0;
     if (grouped && nsplits <= 0) {
         // a grouped launch fills the chip with OTHER jobs' blocks: no split for occupancy's sake; splits only bound a
@@ -695,7 +701,7 @@ static int tn_setup(const void* Y, long ldy, const void* X, long ldx, float* dW,
         fused3 = best_f3;
     }
     p.nsplits = nsplits;
-    p.rmw = overwrite ? 2 : (automatic && nsplits == 1 ? 1 : 0);
+    p.rmw = overwrite ? 2 : (automatic && nsplits == 1 ? (overwrite_if_one ? 2 : 1) : 0);
     int rps = cdiv(rows, nsplits);
     rps = cdiv(rps, BR) * BR;
     p.rows_per_split = rps;
@@ -750,6 +756,7 @@ extern "C" {
 // the block that owns a tile read-add-writes it with plain accesses instead of atomics.
 // nsplits == -1: one split per tile and dW is OVERWRITTEN with the product (no accumulation: the caller needs no zero
 // fill; attention dK / dV).
+// nsplits == -2: as 0, but a product that lands on one split overwrites its tiles (the first product into a zeroed dW: no read).
 int siss_gemm_tn(const void* Y, long ldy, const void* X, long ldx, float* dW, long set_stride, int N, int C,
                  int npanels, const int* shifts, const int* coffs, int nsets, int rows_per_set,
                  long x_set_rows, int row_begin, int row_end, int nsplits, const void* zero_page,

@@ -36,6 +36,7 @@ SUBSCORE = "subscore_bernoulli"
 
 class SISSStepper:
     _warned_fp32 = False
+    wgrad_overwrite = True          # (A/B switch; see UNetEngine.wgrad_overwrite)
 
     def __init__(self, engine: UNetEngine, alphas_cumprod, *, lr, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=1e-2, scaling_norm=None, eta=None, lambd=0.5, train_batch_size,
@@ -244,6 +245,8 @@ class SISSStepper:
         cond = dict(conditioning or {})
         if self._micro == 0:
             e.zero_grad(beside_forward=True)           # (909 MB of HBM writes beside the forward pass; joined by the backward pass)
+        # first micro-batch of a step: one-split weight gradients overwrite their tiles (ONE backward pass per micro-batch below)
+        e.wgrad_overwrite = self._micro == 0 and self.wgrad_overwrite
         x0, a0, noise = (v.to(device=e.device, dtype=self.io_dtype).contiguous() for v in (x0, a0, noise))
         B = x0.shape[0]
         scale = 1.0 / (self.train_batch_size * self.world * self.ga)

@@ -207,6 +207,10 @@ class UNetEngine:
     # shared by the two products; the streaming one-tap blocks run beside MFMA-bound 3-tap blocks).  Round 6 A/B (same box, CelebA-HQ
     # B = 16, alternating): 51.59 / 51.85 ms with, 51.69 / 52.12 without -- kept (docs/experiments.md).
     pair_top = True
+    # Set by the stepper for the FIRST micro-batch of a step (the gradient buffer has just been zeroed and every weight receives exactly one
+    # weight-gradient product per backward pass): one-split products then overwrite their tiles instead of read-add-writing them
+    # (siss_gemm_tn nsplits = -2).  Off for a backward pass driven any other way (the class surface accumulates across passes).
+    wgrad_overwrite = False
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
     def __init__(self, cfg: UNet2DConfig, device="cuda", dtype=torch.bfloat16, f32_fused=False):
@@ -542,6 +546,9 @@ class UNetEngine:
         for a in rel:
             self._put(a)
 
+    def _ns_auto(self):
+        return -2 if (self.wgrad_overwrite and not self.f32) else 0
+
     def _launch_tn_job(self, job):
         lib.call("siss_gemm_tn", job.Y, job.ldy, job.X, job.ldx, job.dW, job.set_stride, job.N, job.C, job.npanels,
                  lib.int_array(list(job.shifts)[:job.npanels]), lib.int_array(list(job.coffs)[:job.npanels]), job.nsets,
@@ -777,7 +784,7 @@ class UNetEngine:
         if self.group_rows and re - rb <= self.group_rows and isinstance(dy, Act):
             job = lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
                             dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
-                            rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=0, x_set_rows=x_set_rows,
+                            rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=self._ns_auto(), x_set_rows=x_set_rows,
                             zero_page=zp.data_ptr(), dbias=dbias.data_ptr() if dbias is not None else None,
                             dbias2=dbias2.data_ptr() if dbias2 is not None else None,
                             shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t))))
@@ -790,7 +797,7 @@ class UNetEngine:
                 and (t == 1 or (ops.is_conv3_panels(shifts, coffs) and self._pair1))):
             job = lib.TNJob(Y=dy.data.data_ptr(), ldy=dy.c, X=x.data.data_ptr(), ldx=ldx or getattr(x, "ld", x.c),
                             dW=dW_view.data_ptr(), set_stride=ps.total, N=co, C=ci, npanels=t, nsets=nsets,
-                            rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=0, x_set_rows=x_set_rows,
+                            rows_per_set=rows_per_set, row_begin=rb, row_end=re, nsplits=self._ns_auto(), x_set_rows=x_set_rows,
                             zero_page=zp.data_ptr(), dbias=dbias.data_ptr() if dbias is not None else None,
                             dbias2=dbias2.data_ptr() if dbias2 is not None else None,
                             shifts=(lib.I * 9)(*shifts, *([0] * (9 - t))), coffs=(lib.I * 9)(*coffs, *([0] * (9 - t))))
@@ -978,7 +985,7 @@ class UNetEngine:
                     z9 = (lib.I * 9)(*([0] * 9))
                     self._wq.append((lib.TNJob(Y=dyt.data_ptr(), ldy=C, X=xin.data_ptr(), ldx=C, dW=dW.data_ptr(),
                                                set_stride=ps.total, N=C, C=C, npanels=1, nsets=ns, rows_per_set=si * S,
-                                               row_begin=0, row_end=si * S, nsplits=0,
+                                               row_begin=0, row_end=si * S, nsplits=self._ns_auto(),
                                                x_set_rows=si * S if B == nb else 0, zero_page=zp.data_ptr(),
                                                dbias=ps.g(wname + ".bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
                                      (dyt, xin)))
@@ -1081,7 +1088,7 @@ class UNetEngine:
                 z9 = (lib.I * 9)(*([0] * 9))
                 self._wq.append((lib.TNJob(Y=dqkv.data_ptr(), ldy=3 * C, X=hn.data_ptr(), ldx=C, dW=dW.data_ptr(),
                                            set_stride=ps.total, N=3 * C, C=C, npanels=1, nsets=ns, rows_per_set=si * S,
-                                           row_begin=0, row_end=si * S, nsplits=0, x_set_rows=xsr, zero_page=zp.data_ptr(),
+                                           row_begin=0, row_end=si * S, nsplits=self._ns_auto(), x_set_rows=xsr, zero_page=zp.data_ptr(),
                                            dbias=ps.g(pre + ".to_q.bias", gb).data_ptr(), dbias2=None, shifts=z9, coffs=z9),
                                  (dqkv, hn)))
                 if len(self._wq) >= self.group_max:

@@ -146,7 +146,7 @@ class UNetCondEngine(UNetEngine):
             z9 = (lib.I * 9)(*([0] * 9))
             self._wq.append((lib.TNJob(Y=dy.data_ptr(), ldy=n_out, X=xin.data_ptr(), ldx=k_in, dW=dW.data_ptr(),
                                        set_stride=ps.total, N=n_out, C=k_in, npanels=1, nsets=ns, rows_per_set=rps,
-                                       row_begin=0, row_end=rps, nsplits=0, x_set_rows=rps if rows_x == rows2 else 0,
+                                       row_begin=0, row_end=rps, nsplits=self._ns_auto(), x_set_rows=rps if rows_x == rows2 else 0,
                                        zero_page=zp.data_ptr(),
                                        dbias=ps.g(wname + ".bias", gb).data_ptr() if bias else None, dbias2=None,
                                        shifts=z9, coffs=z9), (dy, xin)))
