@@ -18,7 +18,9 @@
 // global_atomic_add_f32; 16 consecutive floats per lane group).
 #include "common.h"
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -597,11 +599,30 @@ __global__ __launch_bounds__(TCfg<3>::kThreads, 2) void gemm_tn_mixed_kernel(con
     }
 }
 
+// HOST-side log of the products that OVERWROTE their output (rmw == 2): one record (first float, float count) per set, in launch
+// order, drained by siss_gemm_tn_overwrite_log.  The engine learns from it which stretches of the gradient buffer a backward pass
+// writes without reading -- those need no zero fill before the next step (UNetEngine.zero_grad(sparse_key=...)) -- and checks every
+// such pass against what the fill assumed.  Bounded: with nobody draining it the log stops at kOwMax records and says so.
+struct OwRec { const float* ptr; long floats; };
+constexpr size_t kOwMax = 1 << 16;
+std::mutex g_ow_mu;
+std::vector<OwRec> g_ow;
+bool g_ow_overflow = false;
+void note_overwrite(const TNParams& p) {
+    if (p.rmw != 2) return;
+    std::lock_guard<std::mutex> lock(g_ow_mu);
+    for (int s = 0; s < p.nsets; ++s) {
+        if (g_ow.size() >= kOwMax) { g_ow_overflow = true; return; }
+        g_ow.push_back({p.dW + (long)s * p.set_stride, (long)p.npanels * p.N * p.C});
+    }
+}
+
 template <int TAPS>
 int launch_tn(const TNParams& p, hipStream_t st) {
     using C_ = TCfg<TAPS>;
     static unsigned char attr_set[kMaxDevices], attr_ilv[kMaxDevices];
     siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
+    note_overwrite(p);
     dim3 grid(cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits);
     if constexpr (TAPS == 3) {                             // fragment reads interleaved with the MFMAs: measured +5 % (996 -> 1044, 1057 -> 1112 TF/s)
         constexpr int smem_ilv = TCfg<3, true>::kSmemBytes;
@@ -734,6 +755,7 @@ static int launch_tn_group(const TNParams* ps, int n, hipStream_t st, int max_bl
             g.nwg[j] = cdiv(p.N, BN) * cdiv(p.C, BC) * (p.npanels / TAPS) * p.nsets * p.nsplits;
             total += (g.nwg[j] + 7) & ~7;
             siss_count_dispatch(TAPS == 3 ? SISS_K_TN3 : SISS_K_TN1);
+            note_overwrite(p);
         }
         g.first[g.njobs] = total;
         if (max_blocks > 0 && total > max_blocks) {
@@ -785,6 +807,21 @@ int siss_gemm_tn_bs(const void* Y, long ldy, const void* X, long ldx, float* dW,
     p.bias_stride = bias_set_stride;
     if (fused3) return launch_tn<3>(p, (hipStream_t)stream);
     return launch_tn<1>(p, (hipStream_t)stream);
+}
+
+// Drains the host-side log of overwriting products (nsplits == -1, or -2 landing on one split) launched by this process since the
+// last call: up to max_records records of two longs (address of the first float, float count), one per cotangent set, in launch
+// order.  Returns the number of records there were (more than max_records: the rest is dropped), or -1 if the log had filled up
+// (65536 records without a drain: its content is then incomplete; -2: bad arguments).  out may be null with max_records = 0 (just clear).
+long siss_gemm_tn_overwrite_log(long* out, long max_records) {
+    if (max_records < 0 || (!out && max_records > 0)) return -2;
+    std::lock_guard<std::mutex> lock(g_ow_mu);
+    const long n = (long)g_ow.size();
+    for (long i = 0; i < n && i < max_records; ++i) { out[2 * i] = (long)(uintptr_t)g_ow[i].ptr; out[2 * i + 1] = g_ow[i].floats; }
+    const bool over = g_ow_overflow;
+    g_ow.clear();
+    g_ow_overflow = false;
+    return over ? -1 : n;
 }
 
 // Balance of siss_gemm_tn_pair: relative cost of a 64-row K-step of a one-tap virtual block against a 3-tap block's (permille;

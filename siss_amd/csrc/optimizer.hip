@@ -298,9 +298,35 @@ __global__ void upsample_phase_wgrad_fold_kernel(const float* __restrict__ dW4, 
     }
 }
 
+// Zero fill of a LIST of stretches of one buffer in one launch (the gradient buffer minus what the coming backward pass overwrites).
+// Units are 16-byte granules: tab = n starts, then n + 1 prefix sums of the lengths; thread g of the compacted index space finds
+// its stretch by binary search (the table is a few KB: L1 / L2 hits) and stores one float4.
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ base, const long* __restrict__ tab, int n, long total) {
+    const long* start = tab;
+    const long* pre = tab + n;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pre[mid] <= g) lo = mid; else hi = mid - 1;
+        }
+        reinterpret_cast<f32x4_t*>(base)[start[lo] + (g - pre[lo])] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// base[16 * start_i .. 16 * (start_i + len_i)) bytes = 0 for the n stretches of the DEVICE table tab: n starts followed by the n + 1
+// prefix sums of the lengths (longs, in 16-byte granules; total_granules = the last prefix sum).  Stretches must not overlap.
+int siss_zero_ranges(float* base, const long* tab, int n, long total_granules, void* stream) {
+    SISS_CHECK_ARG(base && tab && n > 0 && total_granules > 0 && (uintptr_t)base % 16 == 0);
+    long blocks = cdiv(total_granules, 256L);
+    if (blocks > 8192) blocks = 8192;
+    zero_ranges_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(base, tab, n, total_granules);
+    SISS_LAUNCH_RET();
+}
 
 long siss_opt_partials_words(void) { return 3L * kMaxBlocks; }
 long siss_opt_scalars_words(void) { return sizeof(StepScalars) / sizeof(float); }

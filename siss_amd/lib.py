@@ -60,6 +60,8 @@ SIGNATURES = {
     "siss_gemm_tn_grouped_capped": [P, I, I, P],
     "siss_gemm_tn_pair": [P, P, I, P],
     "siss_gemm_tn_set_pair_cost": [I],
+    "siss_gemm_tn_overwrite_log": [P, L],
+    "siss_zero_ranges": [P, P, I, L, P],
     "siss_gn_partial_words": [I, I, I, I, I],
     "siss_groupnorm_set_slab": [I],
     "siss_groupnorm_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, F, I, I, P],
@@ -131,7 +133,7 @@ F32_ENTRY.update({"siss_transpose_bf16": "siss_transpose_f32", "siss_cast_f32_bf
 F32_ENTRY.update({n: n + "_f32" for n in ("siss_gemm_nt_d2s", "siss_gemm_nt_d2s_bias", "siss_gemm_nt_d2s_phases", "siss_conv3x3_sc", "siss_conv3x3_dgrad_sc",
                                           "siss_gemm_tn_bs", "siss_gemm_tn_grouped", "siss_groupnorm_bwd_ld_s2d",
                                           "siss_upsample_phase_weights")})
-F32_SAME = {"siss_upsample_phase_wgrad_fold", "siss_timestep_sincos", "siss_linear_small_fwd", "siss_linear_small_bwd", "siss_linear_multi_fwd", "siss_linear_multi_bwd",
+F32_SAME = {"siss_zero_ranges", "siss_upsample_phase_wgrad_fold", "siss_timestep_sincos", "siss_linear_small_fwd", "siss_linear_small_bwd", "siss_linear_multi_fwd", "siss_linear_multi_bwd",
             "siss_nchw_channel_sums", "siss_mixture_fwd", "siss_mixture_select", "siss_loss_bwd_seed", "siss_mse_bwd_seed",
             "siss_ddpm_step", "siss_grad_norms_scale", "siss_grad_norm_partials", "siss_grad_scalars", "siss_recombine_clip_adamw"}
 for _b, _f in F32_ENTRY.items():
@@ -158,7 +160,7 @@ class f32_mode:
         return False
 
 
-_RET_LONG = {"siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words",
+_RET_LONG = {"siss_gemm_tn_overwrite_log", "siss_loss_partials_words", "siss_opt_partials_words", "siss_opt_scalars_words",
              "siss_gn_partial_words", "siss_dispatch_count", "siss_conv_qstats_words"}
 
 # siss_dispatch_count() ids (common.h SissKernelId): which device kernel a launcher call landed on
@@ -468,3 +470,13 @@ def call(name, *args, refusable=False):
 
 def query(name, *args):
     return getattr(load(), name)(*args)
+
+
+def overwrite_log(max_records=8192):
+    """Drain siss_gemm_tn_overwrite_log: [(address, floats), ...] of the weight-gradient products that overwrote their output since
+    the last drain (host-side bookkeeping, no device work), or None when the log is unusable (it had filled up, or held more)."""
+    buf = (C.c_long * (2 * max_records))()
+    n = load().siss_gemm_tn_overwrite_log(C.cast(buf, C.c_void_p), max_records)
+    if n < 0 or n > max_records:
+        return None
+    return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]

@@ -243,10 +243,13 @@ class SISSStepper:
         backward; no host sync."""
         e = self.e
         cond = dict(conditioning or {})
-        if self._micro == 0:
-            e.zero_grad(beside_forward=True)           # (909 MB of HBM writes beside the forward pass; joined by the backward pass)
         # first micro-batch of a step: one-split weight gradients overwrite their tiles (ONE backward pass per micro-batch below)
         e.wgrad_overwrite = self._micro == 0 and self.wgrad_overwrite
+        if self._micro == 0:
+            # the fill runs beside the forward pass (joined by the backward pass) and skips what that backward pass will overwrite:
+            # the key names everything its split decisions depend on
+            key = (self.loss_fn, tuple(x0.shape), tuple(sorted((k, tuple(v.shape)) for k, v in cond.items())))
+            e.zero_grad(beside_forward=True, sparse_key=key)
         x0, a0, noise = (v.to(device=e.device, dtype=self.io_dtype).contiguous() for v in (x0, a0, noise))
         B = x0.shape[0]
         scale = 1.0 / (self.train_batch_size * self.world * self.ga)

@@ -211,6 +211,11 @@ class UNetEngine:
     # weight-gradient product per backward pass): one-split products then overwrite their tiles instead of read-add-writing them
     # (siss_gemm_tn nsplits = -2).  Off for a backward pass driven any other way (the class surface accumulates across passes).
     wgrad_overwrite = False
+    fill_grads = True          # (timing probes only: a bound on what the fill costs)
+    # zero_grad(sparse_key=...) skips the stretches of the gradient buffer that the coming backward pass overwrites (recorded from the
+    # first pass under the same key, checked on every later one).  SD v1.5, same box: B = 4 -1.0 ms, B = 16 -0.8 ms (docs/experiments.md).
+    sparse_fill = True
+    sparse_min_floats = 16384  # ... stretches of at least this many floats (the rest is simply filled)
     pair_min_rows = 280000     # ... of at least this many reduction rows per set (CelebA-HQ B = 16: the 256 x 256 level)
 
     def __init__(self, cfg: UNet2DConfig, device="cuda", dtype=torch.bfloat16, f32_fused=False):
@@ -256,6 +261,7 @@ class UNetEngine:
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._side_phase = False
         self._prep_pending, self._wT_stale = False, False
+        self._fill_key, self._fill_plan, self._fill_plans = None, None, {}
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -1484,16 +1490,85 @@ class UNetEngine:
         self.tape.append(head_bwd)
         return pred
 
-    def zero_grad(self, beside_forward=False):
-        """beside_forward: the fill runs on the side stream (behind everything issued so far) and is joined by the next backward()."""
+    def zero_grad(self, beside_forward=False, sparse_key=None):
+        """beside_forward: the fill runs on the side stream (behind everything issued so far) and is joined by the next backward().
+        sparse_key (hashable; the stepper's first micro-batch, with wgrad_overwrite set): everything that decides how the NEXT
+        backward pass splits its weight gradients (loss, batch shape).  The first pass under a key runs behind a full fill and
+        records which stretches of the gradient buffer it OVERWROTE (siss_gemm_tn_overwrite_log: one-split products under
+        nsplits = -2); later fills under the same key skip those stretches (siss_zero_ranges: one launch over the complement),
+        and every such pass is checked against the record -- a pass that overwrote anything else raises."""
+        self._fill_key, self._fill_plan = None, None
+        if not self.fill_grads:
+            return
+        plan = None
+        if sparse_key is not None and self.sparse_fill and self.wgrad_overwrite and not self.f32 and lib.has("siss_zero_ranges"):
+            # (+ the schedule switches that decide which launch -- hence which split rule -- a weight gradient takes)
+            sparse_key = (sparse_key, self.group_rows, self.group_attn, self.pair_top, self.pair_min_rows, self.fold_shortcut,
+                          self.subpixel_up, self.subpixel_min_px, self.subpixel_queue, self.fused_attn, self.sparse_min_floats)
+            self._fill_key = sparse_key
+            plan = self._fill_plan = self._fill_plans.get(sparse_key)
+        g = self.ps.grads
+
+        def fill():
+            if plan is None:
+                g.zero_()
+            elif plan["n"]:
+                lib.call("siss_zero_ranges", g, plan["table"], plan["n"], plan["granules"])
+
         if beside_forward and self.prep_side and self.device.type == "cuda":
             st = self._side_stream()
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
-                self.ps.grads.zero_()
+                fill()
             self._prep_pending = True
             return
-        self.ps.grads.zero_()
+        fill()
+
+    def _overwritten(self):
+        """The drained overwrite log as sorted (first float, floats) stretches of the gradient buffer; None if unusable."""
+        recs = lib.overwrite_log()
+        if recs is None:
+            return None
+        g = self.ps.grads
+        base, end = g.data_ptr(), g.data_ptr() + g.numel() * 4
+        return tuple(sorted(((a - base) // 4, n) for a, n in recs if base <= a and a + 4 * n <= end))
+
+    def _check_sparse_fill(self):
+        """End of the backward pass that followed zero_grad(sparse_key=...): record what it overwrote (first pass under the key)
+        or compare it with what the sparse fill assumed."""
+        key, plan, self._fill_key, self._fill_plan = self._fill_key, self._fill_plan, None, None
+        if key is None:
+            return
+        got = self._overwritten()
+        if plan is not None:
+            if got != plan["stretches"]:
+                self._fill_plans.clear()
+                raise RuntimeError("sparse gradient fill: this backward pass did not overwrite the stretches the fill before it skipped "
+                                   f"(key {key!r}: {len(plan['stretches'])} recorded, {0 if got is None else len(got)} now) -- the gradients of "
+                                   "this step are invalid; schedule switches changed between steps? (UNetEngine.sparse_fill = False)")
+            return
+        if got is None or torch.cuda.is_current_stream_capturing():    # (the table below is a host-to-device copy)
+            return
+        # skip list: the overwritten stretches shrunk to 16-byte granules, small ones ignored; the fill covers the complement
+        skip, total = [], self.ps.grads.numel()
+        for a, n in got:
+            a4, b4 = -(-a // 4), (a + n) // 4
+            if 4 * (b4 - a4) >= self.sparse_min_floats:
+                if skip and a4 < skip[-1][1]:
+                    return                                 # overlapping products: not the one-product-per-weight pass this is for
+                skip.append((a4, b4))
+        starts, lens, at = [], [], 0
+        for a4, b4 in skip + [(total // 4, total // 4)]:
+            if a4 > at:
+                starts.append(at); lens.append(a4 - at)
+            at = b4
+        assert total % 4 == 0
+        pre = [0]
+        for n in lens:
+            pre.append(pre[-1] + n)
+        self._fill_plans[key] = dict(stretches=got, n=len(starts), granules=pre[-1],
+                                     table=torch.tensor(starts + pre, dtype=torch.int64, device=self.device),
+                                     skipped_bytes=16 * (total // 4 - pre[-1]))
 
     def backward(self, cot, nsets=2, grad_base_set=0):
         """cot: [nb, Cout, H, W] f32 cotangent of pred, nb = nsets * set_images.  With the shared
@@ -1509,6 +1584,8 @@ class UNetEngine:
         self.nb, self.nsets, self.set_images, self.gbase, self.cot = nb, nsets, nb // nsets, grad_base_set, cot
         if self._wT_stale:                             # (a backward pass without a forward since the last lazy refresh)
             self._refresh_dgrad_copies()
+        if self._fill_key is not None:
+            lib.overwrite_log(0)                       # (whatever other callers left in the log is not this pass's)
         if self._prep_pending:                         # the gradient fill / dgrad weight copies issued beside the forward pass
             torch.cuda.current_stream().wait_stream(self._side)
             self._prep_pending = False
@@ -1530,4 +1607,5 @@ class UNetEngine:
         self._side_phase = False
         self._flush_wgrads()
         self._join_side()
+        self._check_sparse_fill()
         assert not self.gmap, f"{len(self.gmap)} dangling cotangents"

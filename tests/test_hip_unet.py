@@ -744,3 +744,59 @@ def test_subpixel_upsample_equals_the_upsample_copy_form():
         for n in ("up_blocks.0.upsamplers.0.conv.weight", "up_blocks.0.upsamplers.0.conv.bias"):
             rel = float((g1[s][n] - g0[s][n]).norm() / g0[s][n].norm())
             assert rel <= 2e-2, (s, n, rel)
+
+
+def test_sparse_gradient_fill_is_bitwise_the_full_fill(setup):
+    """zero_grad(sparse_key=...): from the second step under a key the fill skips what the backward pass overwrites
+    (siss_gemm_tn nsplits = -2 + siss_gemm_tn_overwrite_log + siss_zero_ranges).  Same inputs, gradient buffer poisoned before
+    every step: the gradients of each of three steps are those of the full fill -- bit for bit where a product overwrote them,
+    to the float atomics' ordering elsewhere -- and so are the parameters; a pass that does not overwrite what the fill skipped raises."""
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    eng, _, sd = setup
+    ac = S.alphas_cumprod()
+    batches = [_batch(torch.Generator().manual_seed(11 + i)) for i in range(3)]
+
+    def run(sparse):
+        eng._fill_plans.clear()
+        eng.sparse_fill, eng.sparse_min_floats = sparse, 256
+        out = []
+        for mb in batches:                       # every step from the same state (the atomics' noise would drift apart otherwise)
+            eng.load_state_dict(sd)
+            st = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
+                             train_batch_size=4, mixed_precision=None)
+            eng.ps.grads.fill_(float("nan"))
+            st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+            out.append((eng.ps.grads.clone(), {k: v.clone() for k, v in eng.state_dict().items()}))
+        return out, st
+
+    try:
+        full, _ = run(False)
+        assert not eng._fill_plans
+        got, st = run(True)
+        (key, plan), = eng._fill_plans.items()
+        assert plan["skipped_bytes"] > 0 and plan["n"] > 0, plan
+        skipped = torch.zeros(eng.ps.grads.numel(), dtype=torch.bool, device="cuda")
+        for a, n in plan["stretches"]:
+            if n >= eng.sparse_min_floats:
+                skipped[-(-a // 4) * 4:(a + n) // 4 * 4] = True
+        assert int(skipped.sum()) * 4 == plan["skipped_bytes"]
+        for i, ((ga, pa), (gb, pb)) in enumerate(zip(full, got)):
+            assert torch.isfinite(gb).all(), i
+            ga, gb = ga.view(-1), gb.view(-1)
+            assert torch.equal(ga[skipped], gb[skipped]), i                     # one-split products: deterministic
+            torch.testing.assert_close(gb, ga, rtol=1e-3, atol=1e-6 * float(ga.abs().max()))
+            for k in pa:
+                assert torch.isfinite(pb[k]).all(), (i, k)
+                # (an Adam step is lr * g / (|g| + eps): the atomics' last bit can turn a near-zero gradient's update around)
+                torch.testing.assert_close(pb[k], pa[k], rtol=0, atol=2.5e-4)
+                assert float((pb[k] - pa[k]).abs().mean()) < 2e-6, (i, k)
+        # a pass that overwrites something else than the fill assumed is an error, not a wrong gradient
+        plan["stretches"] = plan["stretches"][:-1]
+        mb = batches[0]
+        with pytest.raises(RuntimeError, match="sparse gradient fill"):
+            st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+        assert not eng._fill_plans
+    finally:
+        eng.sparse_fill, eng.sparse_min_floats = True, 16384
+        eng._fill_plans.clear()
