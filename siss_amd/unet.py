@@ -1503,8 +1503,7 @@ class UNetEngine:
         plan = None
         if sparse_key is not None and self.sparse_fill and self.wgrad_overwrite and not self.f32 and lib.has("siss_zero_ranges"):
             # (+ the schedule switches that decide which launch -- hence which split rule -- a weight gradient takes)
-            sparse_key = (sparse_key, self.group_rows, self.group_attn, self.pair_top, self.pair_min_rows, self.fold_shortcut,
-                          self.subpixel_up, self.subpixel_min_px, self.subpixel_queue, self.fused_attn, self.sparse_min_floats)
+            sparse_key = (sparse_key,) + self._wgrad_sig()
             self._fill_key = sparse_key
             plan = self._fill_plan = self._fill_plans.get(sparse_key)
         g = self.ps.grads
@@ -1523,6 +1522,10 @@ class UNetEngine:
             self._prep_pending = True
             return
         fill()
+
+    def _wgrad_sig(self):
+        return (self.group_rows, self.group_attn, self.pair_top, self.pair_min_rows, self.fold_shortcut, self.subpixel_up,
+                self.subpixel_min_px, self.subpixel_queue, self.fused_attn, self.sparse_min_floats)
 
     def _overwritten(self):
         """The drained overwrite log as sorted (first float, floats) stretches of the gradient buffer; None if unusable."""

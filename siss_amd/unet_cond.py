@@ -36,6 +36,7 @@ class UNetCondEngine(UNetEngine):
     # B = 16 110.06 / 110.04 with, 108.88 / 108.90 without.
     side_max_batch = 8
     fuse_geglu_bwd = True      # GEGLU backward in the epilogue of the producing dgrad product (round 6)
+    fuse_kv = True             # cross-attention: to_k / to_v as one [2C][Ckv] projection and one weight-gradient product (round 6)
 
     def __init__(self, cfg: UNet2DConditionConfig, device="cuda", dtype=torch.bfloat16):
         super().__init__(cfg, device, dtype=dtype)
@@ -126,6 +127,9 @@ class UNetCondEngine(UNetEngine):
         return sd
 
     # ------------------------------------------------------------------ token-space primitives
+    def _wgrad_sig(self):
+        return super()._wgrad_sig() + (self.fuse_kv,)
+
     def _linear(self, x, wname, out, rows, n_out, k_in, bias=True, residual=None):
         """out[rows, n_out] = x[rows, k_in] W^T (+ b) (+ residual)."""
         ps = self.ps
@@ -202,24 +206,34 @@ class UNetCondEngine(UNetEngine):
         qmul = float(scale) * 1.4426950408889634
         fused_qkv = (flash and xq is xkv and Ckv == C and wk.data_ptr() == wq.data_ptr() + 2 * C * C
                      and wv.data_ptr() == wk.data_ptr() + 2 * C * C)
+        # cross-attention on the fused path: k and v are ONE projection of the text embedding (to_k / to_v back to back: a [2C][Ckv]
+        # matrix) into one [rows, 2C] tensor, and one weight-gradient product in the backward pass (the text takes no gradient)
+        fused_kv = (flash and self.fuse_kv and xq is not xkv and wv.data_ptr() == wk.data_ptr() + 2 * C * Ckv)
         if fused_qkv:
             qkv = bb(".qkv", (rq, 3 * C))
             ops.gemm_nt(lib.ptr(xq), C, wq, lib.ptr(qkv), 3 * C, rq, 3 * C, C, [0], [0], alpha=qmul, alpha_cols=C)
             q, k, v, ldqkv = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], 3 * C
+            ldq = ldqkv
         else:
-            q, k, v, ldqkv = keep(".q", (rq, C)), keep(".k", (rk, C)), keep(".v", (rk, C)), C
+            q, ldq = keep(".q", (rq, C)), C
             if flash:
                 ops.gemm_nt(lib.ptr(xq), C, wq, lib.ptr(q), C, rq, C, C, [0], [0], alpha=qmul)
             else:
                 self._linear(xq, pre + ".to_q", q, rq, C, C, bias=False)
-            self._linear(xkv, pre + ".to_k", k, rk, C, Ckv, bias=False)
-            self._linear(xkv, pre + ".to_v", v, rk, C, Ckv, bias=False)
+            if fused_kv:
+                kv = keep(".kv", (rk, 2 * C))
+                self._linear(xkv, pre + ".to_k", kv, rk, 2 * C, Ckv, bias=False)
+                k, v, ldqkv = kv[:, :C], kv[:, C:], 2 * C
+            else:
+                k, v, ldqkv = keep(".k", (rk, C)), keep(".v", (rk, C)), C
+                self._linear(xkv, pre + ".to_k", k, rk, C, Ckv, bias=False)
+                self._linear(xkv, pre + ".to_v", v, rk, C, Ckv, bias=False)
         o = bb(".o", (rq, C))
         if flash:
             # QK^T -> softmax -> .V in ONE kernel (csrc/flash_attn.hip): the S x S matrices never reach HBM; the base-2
             # log-sum-exp is all the backward needs besides q, k, v, o
             lse = bb(".lse", (BH, Sqp), torch.float32)
-            lib.call("siss_flash_attn_fwd_merged", q, ldqkv, k, ldqkv, v, ldqkv, o, C, lse, B, Hh, Sq, Sk, D, float(scale), 1)
+            lib.call("siss_flash_attn_fwd_merged", q, ldq, k, ldqkv, v, ldqkv, o, C, lse, B, Hh, Sq, Sk, D, float(scale), 1)
         else:
             qh, kh, vh = bb(".qh", (BH, Sqp, Dp)), bb(".kh", (BH, Skp, Dp)), bb(".vh", (BH, Skp, Dp))
             lib.call("siss_head_split", q, qh, B, Sq, Hh, D, Sqp, Dp)
@@ -250,6 +264,10 @@ class UNetCondEngine(UNetEngine):
             if fused_qkv:
                 dqkv = tb(".dqkv", (rows2, 3 * C))
                 dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
+            elif fused_kv:
+                assert dxkv is None
+                dq, dkv = tb(".dq", (rows2, C)), tb(".dkv", (nb * Sk, 2 * C))
+                dk, dv = dkv[:, :C], dkv[:, C:]
             else:
                 dq, dk, dv = tb(".dq", (rows2, C)), tb(".dk", (nb * Sk, C)), tb(".dv", (nb * Sk, C))
             delta = tb(".delta", (nBH * Sqp,), torch.float32)
@@ -257,7 +275,7 @@ class UNetCondEngine(UNetEngine):
                 # FlashAttention-2 style: P is recomputed per tile from q, k and the saved log-sum-exp; all cotangent
                 # (batch, head) entries in one launch pair, cotangent batch b against forward batch b % B; delta[q] =
                 # sum_k P[q][k] dP[q][k] = <dO[q], O[q]> is formed by the dQ kernel from tiles it loads anyway
-                lib.call("siss_flash_attn_bwd_merged", q, ldqkv, k, ldqkv, v, ldqkv, o, C, do, C, lse, delta, dq, ldqkv, dk, ldqkv,
+                lib.call("siss_flash_attn_bwd_merged", q, ldq, k, ldqkv, v, ldqkv, o, C, do, C, lse, delta, dq, ldq, dk, ldqkv,
                          dv, ldqkv, nb, B, Hh, Sq, Sk, D, float(scale), 1)
             else:
                 doh = tb(".doh", (nBH, Sqp, Dp))
@@ -299,6 +317,9 @@ class UNetCondEngine(UNetEngine):
                 wts = [self.wT[pre + n + ".weight"] for n in (".to_q", ".to_k", ".to_v")]
                 assert wts[1].data_ptr() == wts[0].data_ptr() + 2 * C * C and wts[2].data_ptr() == wts[1].data_ptr() + 2 * C * C
                 ops.gemm_nt(lib.ptr(dqkv), 3 * C, wts[0], lib.ptr(dxq), C, rows2, C, C, [0, 0, 0], [0, C, 2 * C])
+            elif fused_kv:
+                self._linear_bwd(dq, xq, pre + ".to_q", rows2, rq, C, C, dx_out=dxq, bias=False)
+                self._linear_bwd(dkv, xkv, pre + ".to_k", nb * Sk, rk, 2 * C, Ckv, dx_out=None, bias=False)
             else:
                 self._linear_bwd(dq, xq, pre + ".to_q", rows2, rq, C, C, dx_out=dxq, bias=False)
                 self._linear_bwd(dk, xkv, pre + ".to_k", nb * Sk, rk, C, Ckv, dx_out=dxkv, accumulate=True, bias=False)

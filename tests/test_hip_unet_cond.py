@@ -195,6 +195,39 @@ def test_dual_backward_matches_oracle(setup):
         assert not bad, bad[:10]
 
 
+def test_fused_cross_attention_kv_projection_equals_the_two_projections(setup):
+    """UNetCondEngine.fuse_kv: to_k / to_v of a cross-attention as one [2C][Ckv] projection (forward) and one weight-gradient
+    product (backward) against the two of each: same K loops per output element, so the prediction is bit for bit the same and
+    the gradients agree to the float atomics' ordering."""
+    eng, _, sd = setup
+    eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    hw, X = eng.cfg.sample_size, eng.cfg.cross_attention_dim
+    x = torch.randn(B, 4, hw, hw, generator=g).cuda()
+    t = torch.tensor([999, 300]).cuda()
+    ctx = torch.randn(B, 77, X, generator=g).cuda()
+    cot = torch.randn(2 * B, 4, hw, hw, generator=g).cuda()
+    out = {}
+    try:
+        for fused in (True, False):
+            eng.fuse_kv = fused
+            pred = eng.forward(x, t, encoder_hidden_states=ctx).clone()
+            eng.zero_grad()
+            eng.backward(cot, nsets=2)
+            torch.cuda.synchronize()
+            out[fused] = (pred, eng.ps.grads.clone())
+    finally:
+        eng.fuse_kv = True
+    assert torch.equal(out[True][0], out[False][0])
+    ga, gb = out[True][1], out[False][1]
+    torch.testing.assert_close(ga, gb, rtol=1e-3, atol=1e-5 * float(gb.abs().max()))
+    for n in (k for k in sd if k.endswith("attn2.to_k.weight") or k.endswith("attn2.to_v.weight")):
+        sp = eng.ps.specs[n]
+        a, b = ga[:, sp.off:sp.off + sp.numel], gb[:, sp.off:sp.off + sp.numel]
+        assert float(b.abs().max()) > 0 and _cos(a, b) > 0.99999, n
+
+
 def test_siss_step_with_text_conditioning_matches_oracle(setup):
     """delete_sd.py:864-1127 loop body: SISS on latents with conditioning={'encoder_hidden_states': ...}."""
     from siss_amd.step import SISSStepper
