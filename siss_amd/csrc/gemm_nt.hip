@@ -353,7 +353,8 @@ long siss_dispatch_count(int kernel_id) {
 }
 // Version of this C ABI: bumped when a struct layout changes or when the Python engines start calling a new entry point
 // unconditionally (siss_amd/lib.py refuses an override library -- bench.py --lib, SISS_LIB_PATH -- that is older than it can drive).
-// 5: round 5's final build (the first version counted).  6: round 6 (flash_attn32, siss_gemm_nt_geglu_bwd: optional, gated by lib.has).
+// 5: round 5's final build (the first version counted).  6: round 6 (flash_attn32; optional and gated by lib.has: siss_gemm_nt_geglu_bwd,
+// siss_zero_ranges + siss_gemm_tn_overwrite_log; nsplits = -2 reads as 0 in an older library).
 int siss_abi_version() { return 6; }
 int siss_dispatch_reset() {
     for (int k = 0; k < SISS_K_COUNT; ++k) __atomic_store_n(&g_dispatch[k], 0L, __ATOMIC_RELAXED);
