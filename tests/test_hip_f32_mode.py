@@ -50,18 +50,23 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
 
 
+_REFS = {}
+
+
 def _fwd_bwd_errors(eng, net, kw, B=4, seed=0):
     g = torch.Generator().manual_seed(seed)
     c, hw = kw["in_channels"], kw["sample_size"]
     x = torch.randn(B, c, hw, hw, generator=g)
     t = torch.tensor([999, 10, 700, 3][:B])
     cots = [torch.randn(B, c, hw, hw, generator=g) for _ in range(2)]
-    refs = []
-    for ct in cots:
-        net.zero_grad()
+    # ONE f64 forward, a backward per cotangent; shared by the schedule variants of a configuration (same seeds: same weights, same inputs)
+    key = (repr(sorted(kw.items())), B, seed)
+    if key not in _REFS:
+        names, params = zip(*net.named_parameters())
         pred_ref = net(x.double(), t)[0]
-        pred_ref.backward(ct.double())
-        refs.append({n: p.grad.clone() for n, p in net.named_parameters()})
+        _REFS[key] = (pred_ref.detach(), [dict(zip(names, torch.autograd.grad(pred_ref, params, ct.double(), retain_graph=(i == 0))))
+                                          for i, ct in enumerate(cots)])
+    pred_ref, refs = _REFS[key]
     pred = eng.forward(x.cuda(), t.cuda()).cpu()
     eng.zero_grad()
     eng.backward(torch.cat(cots).cuda().contiguous(), nsets=2)
@@ -241,12 +246,9 @@ def test_f32_sd_unet_forward_and_dual_backward_match_the_oracle_at_1e4(case):
     t = torch.tensor([999, 40])
     ctx = torch.randn(B, 13, X, generator=g)
     cots = [torch.randn(B, 4, hw, hw, generator=g) for _ in range(2)]
-    refs = []
-    for ct in cots:
-        net.zero_grad()
-        pred_ref = net(x.double(), t, ctx.double())[0]
-        pred_ref.backward(ct.double())
-        refs.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    names, params = zip(*net.named_parameters())
+    pred_ref = net(x.double(), t, ctx.double())[0]                     # one f64 forward, a backward per cotangent
+    refs = [dict(zip(names, torch.autograd.grad(pred_ref, params, ct.double(), retain_graph=(i == 0)))) for i, ct in enumerate(cots)]
     pred = eng.forward(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).cpu()
     eng.zero_grad()
     eng.backward(torch.cat(cots).cuda().contiguous(), nsets=2)
