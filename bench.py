@@ -312,9 +312,12 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     sync()
     t0 = time.perf_counter()
+    host_s = 0.0
     for i in range(a.steps):
         marks[i].record()
+        h0 = time.perf_counter()
         run()
+        host_s += time.perf_counter() - h0
     marks[a.steps].record()
     sync()
     dt = time.perf_counter() - t0
@@ -540,6 +543,10 @@ def main():
             "value": round(steps_per_sec * B * GA * world, 3), "unit": "samples/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "steps_per_sec": round(steps_per_sec, 4), "step_ms": step_ms,
+            # host time inside the launch calls of the timed steps (hipGraphLaunch returns when its packets are queued).  The two-stream
+            # graph takes ~28-40 us per kernel node here (33 of SD B = 4's 43 ms; a linear graph 0.3 ms) and still stays ahead of the
+            # device: the linear schedule measures the same step time (docs/experiments.md, round 6)
+            "launch_host_ms_per_step": round(host_s / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": workload,
