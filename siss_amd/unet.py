@@ -1524,8 +1524,9 @@ class UNetEngine:
         fill()
 
     def _wgrad_sig(self):
-        return (self.group_rows, self.group_attn, self.pair_top, self.pair_min_rows, self.fold_shortcut, self.subpixel_up,
-                self.subpixel_min_px, self.subpixel_queue, self.fused_attn, self.sparse_min_floats)
+        return (self.group_rows, self.group_max, self.group_attn, self.pair_top, self.pair_min_rows, self.fold_shortcut, self.subpixel_up,
+                self.subpixel_min_px, self.subpixel_queue, self.fused_attn, self.sparse_min_floats, self.wgrad_side, self.side_follow,
+                self.on_early_grads_final is not None)
 
     def _overwritten(self):
         """The drained overwrite log as sorted (first float, floats) stretches of the gradient buffer; None if unusable."""
