@@ -1,6 +1,7 @@
+# The four bench lines again on the current tree (bench.py changes only; kernel sources unchanged).  Usage (GPU box): bash tools/probes/bench_lines.sh
 out=gpurun_out/evidence_r06
 mkdir -p $out
-cp gpurun_out/r06_hbm_traffic.json profiles/latest_hbm_traffic.json 2>/dev/null || cp $out/r06_hbm_traffic.json profiles/latest_hbm_traffic.json
+# (the traffic fingerprint is profiles/latest_hbm_traffic.json as committed: re-run tools/evidence.sh after a change under siss_amd/csrc)
 python bench.py --steps 20 --warmup 3 > $out/bench_celeb_bs16.json 2> $out/bench_celeb_bs16.err
 python bench.py --steps 20 --warmup 3 --loss-fn double_forward_with_neg_del --no-cpu-baseline > $out/bench_celeb_bs16_no_is.json 2> /dev/null
 python bench.py --config sd15 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_sd15_bs16.json 2> /dev/null
