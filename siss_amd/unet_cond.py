@@ -35,6 +35,13 @@ class UNetCondEngine(UNetEngine):
     # the half of the chip the side launch leaves.  Same box, alternating: B = 4 46.24 / 46.27 ms with, 46.54 / 46.66 without;
     # B = 16 110.06 / 110.04 with, 108.88 / 108.90 without.
     side_max_batch = 8
+    # Round 6: ONE stream for this network.  With the sparse gradient fill the side work beside the forward pass is 0.85 ms of traffic and the
+    # side-stream weight gradients were neutral (above), while a captured step that forks to a second stream takes the runtime's per-node
+    # graph launch: 32.5 ms of host time per 42.6-ms step at B = 4 (78 of 105 at B = 16) against 0.27 ms for the linear graph -- same step
+    # time on the device (same box: B = 4 42.60 / 42.56 linear, 42.56 / 42.88 forked; B = 16 105.18 / 105.17, 104.99 / 105.53;
+    # tools/probes/graph_linear.sh), and a host that is no longer within a quarter of becoming the bound.
+    wgrad_side = False
+    prep_side = False
     fuse_geglu_bwd = True      # GEGLU backward in the epilogue of the producing dgrad product (round 6)
     fuse_kv = True             # cross-attention: to_k / to_v as one [2C][Ckv] projection and one weight-gradient product (round 6)
 
