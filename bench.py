@@ -547,6 +547,10 @@ def main():
             # graph takes ~28-40 us per kernel node here (33 of SD B = 4's 43 ms; a linear graph 0.3 ms) and still stays ahead of the
             # device: the linear schedule measures the same step time (docs/experiments.md, round 6)
             "launch_host_ms_per_step": round(host_s / a.steps * 1e3, 3),
+            # the gradient fill of a step: bytes of the [g_x ; g_a] buffer, and how many of them the fill skips because the backward pass
+            # overwrites them (UNetEngine.zero_grad(sparse_key=...); None: full fill)
+            "gradient_fill": {"buffer_bytes": eng.ps.grads.numel() * 4,
+                              "skipped_bytes": max([p["skipped_bytes"] for p in getattr(eng, "_fill_plans", {}).values()], default=None)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": workload,
