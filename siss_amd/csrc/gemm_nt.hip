@@ -86,6 +86,7 @@ __global__ __launch_bounds__(NW * 64, (STAGES == 1 && BM == 128 ? (BNT == BN ? 4
         const int row = (w * C_::kWPieces + j) * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+        if (BNT == BN && p.gf_y) gn = (n0 >> 1) + (row >> 6) * (p.N >> 1) + (row & 63);   // GEGLU forward: 64 a rows, then the 64 g rows of the same columns
         wsrc[j] = W + (long)gn * p.Kp + lc * 8;
     }
     const int kchunks = p.Kp / BK;
@@ -407,7 +408,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
                      float* qstats = nullptr, int* qstats_written = nullptr, int d2s = 0, const void* A2 = nullptr, long lda2 = 0,
                      const void* W2 = nullptr, int K2 = 0, const float* bias2 = nullptr, const void* Wx = nullptr, void* Cx = nullptr,
                      long ldcx = 0, int Nx = 0, int alpha_cols = 0, const int* phase_p0 = nullptr, const void* gg_h = nullptr,
-                     long gg_rows_x = 0) {
+                     long gg_rows_x = 0, void* gf_y = nullptr) {
     SISS_CHECK_ARG(A && W && C && shifts && coffs);
     SISS_CHECK_ARG(alpha_cols == 0 || (alpha_cols > 0 && alpha_cols % 4 == 0 && npanels == 1 && !mul_r));   // (one-panel products: the generic kernel)
     if (qstats_written) *qstats_written = 0;
@@ -426,6 +427,9 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     p.inv_wp = Wp > 0 ? 1.0f / (float)Wp : 0.f;
     p.ksplit = 1; p.slab = nullptr; p.qstats = nullptr; p.d2s = d2s;
     p.gg_h = (const bf16_t*)gg_h; p.gg_rows_x = gg_rows_x;
+    p.gf_y = (bf16_t*)gf_y;
+    SISS_CHECK_ARG(!gf_y || (npanels == 1 && Hp == 0 && !d2s && !R && !rowbias && !rowsub && batch == 1 && !gg_h && N % 128 == 0 &&
+                             ldc == N && (uintptr_t)gf_y % 16 == 0 && alpha == 1.f && alpha_cols == 0));
     SISS_CHECK_ARG(!gg_h || (gg_rows_x > 0 && npanels == 1 && Hp == 0 && !d2s && !R && !bias && !rowbias && !rowsub && batch == 1 &&
                              N % 8 == 0 && ldc >= 2L * N && (uintptr_t)gg_h % 16 == 0 && alpha == 1.f));
     p.A2 = (const bf16_t*)A2; p.W2 = (const bf16_t*)W2; p.bias2 = A2 ? bias2 : nullptr; p.lda2 = lda2; p.K2 = A2 ? K2 : 0;
@@ -478,7 +482,7 @@ int gemm_nt_dispatch(const void* A, long lda, const void* W, void* C, long ldc, 
     // 111.5 / 111.8 ms, B = 4 46.0 / 46.9 / 45.8 / 46.2 / 46.3 ms, CelebA-HQ unchanged -- e.g. 8192 x 1280 x K 10240: 640 tiles)
     if (tiles128 > 512) {
         // widths that are multiples of 160 but not of 128 (320, 960): 128 x 160 tiles -- no dead columns, two thirds of the A re-reads
-        if (N % 160 == 0 && N % BN != 0 && !p.gg_h && g_wide_tiles) return launch_nt<128, 4, 1, 160>(p, batch, (hipStream_t)stream);
+        if (N % 160 == 0 && N % BN != 0 && !p.gg_h && !p.gf_y && g_wide_tiles) return launch_nt<128, 4, 1, 160>(p, batch, (hipStream_t)stream);
         return launch_nt<128, 4, 1>(p, batch, (hipStream_t)stream);
     }
     // at most one block per CU anyway: a 4-deep ring (128 KiB) keeps three K-steps of DMA in flight, so a step
@@ -630,6 +634,19 @@ int siss_gemm_nt_geglu_bwd(const void* A, long lda, const void* W, void* dh, con
     return gemm_nt_dispatch(A, lda, W, dh, 2L * N, nullptr, nullptr, N, nullptr, 0, M, N, Kp, 1, &zero, &zero, 1, 0, 0, 1.0f, 1, 0, 0, 0,
                             nullptr, 0, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr,
                             h, rows_x);
+}
+
+// GEGLU's input projection with the GEGLU forward in its epilogue: h[r][0 : 2F] = A[r] . W^T + bias (W: [2F][Kp], rows 0 .. F-1 the
+// value half, F .. 2F-1 the gate half) AND y[r][f] = h[r][f] * gelu(h[r][F + f]) in one launch -- a tile computes 64 value columns and
+// the 64 gate columns that go with them.  Equal to siss_gemm_nt into h followed by siss_geglu_fwd (y is formed from the bf16-rounded h
+// in both forms) without the second pass's read of h.  F % 64 == 0.
+int siss_gemm_nt_geglu_fwd(const void* A, long lda, const void* W, const float* bias, void* h, void* y, int M, int F, int Kp,
+                           void* stream) {
+    SISS_CHECK_ARG(y && F > 0 && F % 64 == 0);
+    static const int zero = 0;
+    return gemm_nt_dispatch(A, lda, W, h, 2L * F, bias, nullptr, 0, nullptr, 0, M, 2 * F, Kp, 1, &zero, &zero, 1, 0, 0, 1.0f, 1, 0, 0, 0,
+                            nullptr, 0, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr,
+                            nullptr, 0, y);
 }
 
 // floats in the `qstats` buffer of a product with M rows and N output channels

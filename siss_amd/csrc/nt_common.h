@@ -28,6 +28,9 @@ struct NTParams {
     const bf16_t* gg_h;               // GEGLU backward in the epilogue (generic kernel, rows without pixel structure): the accumulator is d(out) of
     long gg_rows_x;                   // out = a * gelu(g), h = [a | g] the saved projection ([gg_rows_x][2 N], row r % gg_rows_x); C has 2 N columns:
                                       // C[r][n] = acc * gelu(g), C[r][N + n] = acc * a * gelu'(g) -- the [rows][N] cotangent never reaches HBM
+    bf16_t* gf_y;                     // GEGLU forward in the epilogue (generic kernel, 128-wide tiles, rows without pixel structure): W / bias / C are the
+                                      // [2 F] projection h = [a | g] (N = 2 F, F % 64 == 0); a tile holds columns [t 64, t 64 + 64) of a AND of g, stores
+                                      // both into C = h and y[r][f] = a * gelu(g) (from the bf16-rounded h, as siss_geglu_fwd reads it) into gf_y [M][F]
     int d2s;                          // 0, or 1 + plane: rows are pixels of space-to-depth plane (py, px) = (plane >> 1, plane & 1); the epilogue
                                       // writes (and reads R) at the pixel's place in the FULL-resolution tensor (2 Hp - 2) x (2 Wp - 2) padded
     int nphase;                       // 0, or 2..4 PHASES in one launch (generic kernel only; d2s != 0): phase z runs the panels
@@ -85,7 +88,8 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[BN
         f32x4_t bias4[NTL];
 #pragma unroll
         for (int i = 0; i < NTL; ++i) {
-            const int n = n0 + wn * (BNT / 2) + i * 16 + fq * 4;
+            int n = n0 + wn * (BNT / 2) + i * 16 + fq * 4;
+            if (p.gf_y) n = (n0 >> 1) + wn * (p.N >> 1) + i * 16 + fq * 4;       // (waves wn = 0 hold the a columns, wn = 1 the g columns)
             bias4[i] = (p.bias && n + 4 <= p.N) ? *reinterpret_cast<const f32x4_t*>(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -121,7 +125,8 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[BN
     constexpr int kRowsPerIt = kThreads / NCHK;          // 16, or 12 (of the 256 threads 240 store)
     const int chunk = NCHK == 16 ? (tid & 15) : tid % NCHK;           // 8 channels per chunk
     const int trow = NCHK == 16 ? (tid >> 4) : tid / NCHK;
-    const int nc = n0 + chunk * 8;
+    int nc = n0 + chunk * 8;
+    if (BNT == 128 && p.gf_y) nc = (n0 >> 1) + (chunk >> 3) * (p.N >> 1) + (chunk & 7) * 8;   // chunks 0-7: a columns, 8-15: g columns
     if (nc >= p.N || trow >= kRowsPerIt) return;
     constexpr int kIts = (BM + kRowsPerIt - 1) / kRowsPerIt;
     if (p.Hp == 0 && !p.d2s && nc + 8 <= p.N) {
@@ -134,6 +139,34 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4_t (&acc)[BN
         const long dstep = (long)kRowsPerIt * p.ldc, rstep = (long)kRowsPerIt * p.ldr;
         int rows_left = (p.M - m0 < vrows ? p.M - m0 : vrows) - row0;
         const char* src = smem + row0 * kCRow + chunk * 16;
+        if (BNT == 128 && p.gf_y) {
+            // GEGLU forward: chunks 0-7 hold 8 value columns (and find the matching gate columns 8 chunks further in the staged row),
+            // chunks 8-15 the gate columns; both store h, the value threads also y = a * gelu(g).  (A loop of its own, not unrolled:
+            // the four-blocks-per-CU instantiation has no register to spare.)
+            bf16_t* ydst = p.gf_y + (long)(m0 + row0) * (p.N >> 1) + (n0 >> 1) + (chunk & 7) * 8;
+            const long ystep = (long)kRowsPerIt * (p.N >> 1);
+#pragma unroll 1
+            for (int it = 0; it < kIts; ++it) {
+                if (rows_left <= 0) break;
+                if (jsel < 0 || (it & 3) == jsel) {
+                    const u32x4_t o = *reinterpret_cast<const u32x4_t*>(src + it * kRowsPerIt * kCRow);
+                    *reinterpret_cast<u32x4_t*>(dst) = o;
+                    if (chunk < 8) {
+                        const u32x4_t gv = *reinterpret_cast<const u32x4_t*>(src + it * kRowsPerIt * kCRow + 128);
+                        u32x4_t y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a0 = __builtin_bit_cast(float, o[e] << 16), a1 = __builtin_bit_cast(float, o[e] & 0xffff0000u);
+                            const float g0 = __builtin_bit_cast(float, gv[e] << 16), g1 = __builtin_bit_cast(float, gv[e] & 0xffff0000u);
+                            y[e] = pack_bf2(a0 * gelu_f(g0), a1 * gelu_f(g1));
+                        }
+                        *reinterpret_cast<u32x4_t*>(ydst) = y;
+                    }
+                }
+                dst += dstep; ydst += ystep; rows_left -= kRowsPerIt;
+            }
+            return;
+        }
 #pragma unroll 4
         for (int it = 0; it < kIts; ++it) {
             if (rows_left <= 0) break;

@@ -37,6 +37,7 @@ SIGNATURES = {
     "siss_gemm_nt_qstats": [P, L, P, P, L, P, P, L, P, L, I, I, I, I, IP, IP, I, I, I, F, P, IP, P],
     "siss_gemm_nt_alpha_cols": [P, L, P, P, L, P, P, L, I, I, I, F, I, P],
     "siss_gemm_nt_geglu_bwd": [P, L, P, P, P, L, I, I, I, P],
+    "siss_gemm_nt_geglu_fwd": [P, L, P, P, P, P, I, I, I, P],
     "siss_abi_version": [],
     "siss_conv3x3_sc": [P, L, P, P, L, P, P, L, P, L, P, I, P, I, I, I, IP, IP, I, I, I, P, IP, P],
     "siss_conv3x3_sc_takes": [I, I, I, I, I, I, L, L, L],
@@ -431,6 +432,10 @@ def call(name, *args, refusable=False):
         elif name == "siss_gemm_nt_geglu_bwd":              # (A, lda, W, dh, h, rows_x, M, N, Kp)
             a = args
             name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[3], 2 * a[7], None, None, a[7], None, 0, a[6], a[7], a[8], 1,
+                                          int_array([0]), int_array([0]), 1, 0, 0, 1.0, 1, 0, 0, 0]
+        elif name == "siss_gemm_nt_geglu_fwd":              # (A, lda, W, bias, h, y, M, F, Kp)
+            a = args
+            name, args = "siss_gemm_nt", [a[0], a[1], a[2], a[4], 2 * a[7], a[3], None, 0, None, 0, a[6], 2 * a[7], a[8], 1,
                                           int_array([0]), int_array([0]), 1, 0, 0, 1.0, 1, 0, 0, 0]
         elif name == "siss_gemm_tn_bs":
             name, args = "siss_gemm_tn", list(args[:20])

@@ -43,6 +43,7 @@ class UNetCondEngine(UNetEngine):
     wgrad_side = False
     prep_side = False
     fuse_geglu_bwd = True      # GEGLU backward in the epilogue of the producing dgrad product (round 6)
+    fuse_geglu_fwd = True      # GEGLU forward in the epilogue of its input projection (round 6)
     fuse_kv = True             # cross-attention: to_k / to_v as one [2C][Ckv] projection and one weight-gradient product (round 6)
 
     def __init__(self, cfg: UNet2DConditionConfig, device="cuda", dtype=torch.bfloat16):
@@ -352,9 +353,14 @@ class UNetCondEngine(UNetEngine):
         x2, at2_b = self._attention(n2, self.ctx, b + ".attn2", nm + ".at2", B, S, Sk, C, X, residual=x1)
         n3, ln3_b = self._layernorm(x2, b + ".norm3", nm + ".ln3", rows, C)
         hff = bb(".hff", (rows, 8 * C))
-        self._linear(n3, b + ".ff.net.0.proj", hff, rows, 8 * C, C)
         gg = bb(".gg", (rows, 4 * C))
-        lib.call("siss_geglu_fwd", hff, gg, rows, 4 * C)
+        if self.fuse_geglu_fwd and (4 * C) % 64 == 0 and not self.f32 and lib.has("siss_gemm_nt_geglu_fwd"):
+            # the projection h = [a | g] and a * gelu(g) from ONE launch (the tile holds matching value / gate columns)
+            lib.call("siss_gemm_nt_geglu_fwd", n3, C, ps.sh(b + ".ff.net.0.proj.weight"), ps.p(b + ".ff.net.0.proj.bias"), hff, gg,
+                     rows, 4 * C, C)
+        else:
+            self._linear(n3, b + ".ff.net.0.proj", hff, rows, 8 * C, C)
+            lib.call("siss_geglu_fwd", hff, gg, rows, 4 * C)
         x3 = bb(".x3", (rows, C))
         self._linear(gg, b + ".ff.net.2", x3, rows, C, 4 * C, residual=x2)
         y = bb(".y", (rows, C))

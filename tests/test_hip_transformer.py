@@ -111,6 +111,34 @@ def test_geglu_backward_in_the_gemm_epilogue(dev, rows, Fd, K):
         _close(got[k * rows:(k + 1) * rows].float().cpu(), gh, 1.5e-2, f"fused geglu bwd set {k}")
 
 
+@pytest.mark.parametrize("rows,Fd,K", [(192, 256, 64), (8192, 1280, 320), (100, 640, 128), (4096, 5120, 1280), (300, 1280, 768)])
+def test_geglu_forward_in_the_gemm_epilogue(dev, rows, Fd, K):
+    """siss_gemm_nt_geglu_fwd: GEGLU's input projection h = x W^T + b with y = a * gelu(g) formed in its epilogue (a tile holds 64
+    value columns and the 64 gate columns that go with them), against the two launches it replaces (siss_gemm_nt into h, then
+    siss_geglu_fwd): the same K loops per element and the same bf16-rounded h: BITWISE equal h and y (grids: one tile round, the
+    large-grid kernel, ragged row tiles, split K), and against torch in f32."""
+    from siss_amd import lib
+    lib.ensure_workspace(dev)
+    g = torch.Generator().manual_seed(rows + Fd + K)
+    x = torch.randn(rows, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(2 * Fd, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+    b = (0.3 * torch.randn(2 * Fd, generator=g)).to(dev)
+    z = lib.int_array([0])
+    h_ref = torch.full((rows, 2 * Fd), 3.0, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_gemm_nt", x, K, w, h_ref, 2 * Fd, b, None, 0, None, 0, rows, 2 * Fd, K, 1, z, z, 1, 0, 0, 1.0, 1, 0, 0, 0)
+    y_ref = torch.full((rows, Fd), 3.0, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_geglu_fwd", h_ref, y_ref, rows, Fd)
+    h = torch.full((rows, 2 * Fd), 5.0, dtype=torch.bfloat16, device=dev)
+    y = torch.full((rows, Fd), 5.0, dtype=torch.bfloat16, device=dev)
+    lib.call("siss_gemm_nt_geglu_fwd", x, K, w, b, h, y, rows, Fd, K)
+    torch.cuda.synchronize()
+    assert torch.equal(h, h_ref), float((h.float() - h_ref.float()).abs().max())
+    assert torch.equal(y, y_ref), float((y.float() - y_ref.float()).abs().max())
+    hf = x.float() @ w.float().t() + b
+    a, gg = hf.chunk(2, dim=-1)
+    _close(y.float().cpu(), (a * F.gelu(gg)).cpu(), 1.5e-2, "fused geglu fwd")
+
+
 @pytest.mark.parametrize("B,S,H,D,Sp,Dp", [(2, 64, 8, 40, 64, 64), (3, 7, 2, 32, 64, 64), (1, 77, 8, 160, 128, 192)])
 def test_head_split_merge_roundtrip(dev, B, S, H, D, Sp, Dp):
     from siss_amd import lib
