@@ -744,27 +744,30 @@ def test_subpixel_upsample_equals_the_upsample_copy_form():
             assert rel <= 2e-2, (s, n, rel)
 
 
-def test_sparse_gradient_fill_is_bitwise_the_full_fill(setup):
+@pytest.mark.parametrize("ga", [1, 2])
+def test_sparse_gradient_fill_is_bitwise_the_full_fill(setup, ga):
     """zero_grad(sparse_key=...): from the second step under a key the fill skips what the backward pass overwrites
     (siss_gemm_tn nsplits = -2 + siss_gemm_tn_overwrite_log + siss_zero_ranges).  Same inputs, gradient buffer poisoned before
     every step: the gradients of each of three steps are those of the full fill -- bit for bit where a product overwrote them,
-    to the float atomics' ordering elsewhere -- and so are the parameters; a pass that does not overwrite what the fill skipped raises."""
+    to the float atomics' ordering elsewhere -- and so are the parameters; a pass that does not overwrite what the fill skipped raises.
+    ga = 2: the second micro-batch of a step ADDS to the tiles the first one overwrote (delete_celeb.py:705-711)."""
     from siss_amd.step import SISSStepper
     from oracle import schedule as S
     eng, _, sd = setup
     ac = S.alphas_cumprod()
-    batches = [_batch(torch.Generator().manual_seed(11 + i)) for i in range(3)]
+    batches = [[_batch(torch.Generator().manual_seed(11 + 7 * i + j)) for j in range(ga)] for i in range(3)]
 
     def run(sparse):
         eng._fill_plans.clear()
         eng.sparse_fill, eng.sparse_min_floats = sparse, 256
         out = []
-        for mb in batches:                       # every step from the same state (the atomics' noise would drift apart otherwise)
+        for mbs in batches:                      # every step from the same state (the atomics' noise would drift apart otherwise)
             eng.load_state_dict(sd)
             st = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
-                             train_batch_size=4, mixed_precision=None)
+                             train_batch_size=4, grad_accum=ga, mixed_precision=None)
             eng.ps.grads.fill_(float("nan"))
-            st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+            for mb in mbs:
+                st.micro_step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
             out.append((eng.ps.grads.clone(), {k: v.clone() for k, v in eng.state_dict().items()}))
         return out, st
 
@@ -791,9 +794,9 @@ def test_sparse_gradient_fill_is_bitwise_the_full_fill(setup):
                 assert float((pb[k] - pa[k]).abs().mean()) < 2e-6, (i, k)
         # a pass that overwrites something else than the fill assumed is an error, not a wrong gradient
         plan["stretches"] = plan["stretches"][:-1]
-        mb = batches[0]
+        mb = batches[0][0]
         with pytest.raises(RuntimeError, match="sparse gradient fill"):
-            st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+            st.micro_step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
         assert not eng._fill_plans
     finally:
         eng.sparse_fill, eng.sparse_min_floats = True, 16384
