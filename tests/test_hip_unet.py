@@ -801,3 +801,41 @@ def test_sparse_gradient_fill_is_bitwise_the_full_fill(setup, ga):
     finally:
         eng.sparse_fill, eng.sparse_min_floats = True, 16384
         eng._fill_plans.clear()
+
+
+@pytest.mark.parametrize("loss_fn", ["naive_del", "double_forward_with_neg_del"])
+def test_sparse_gradient_fill_with_other_objectives(setup, loss_fn):
+    """The sparse fill under a ONE-set objective (naive_del: nsets = 1 -- the second gradient set is never written and must come
+    out of every fill as zeros) and under the two-forward objective (a batch-2B pass: another key, another record)."""
+    from siss_amd.step import SISSStepper
+    from oracle import schedule as S
+    eng, _, sd = setup
+    ac = S.alphas_cumprod()
+    batches = [_batch(torch.Generator().manual_seed(41 + i)) for i in range(3)]
+
+    def run(sparse):
+        eng._fill_plans.clear()
+        eng.sparse_fill, eng.sparse_min_floats = sparse, 256
+        out = []
+        for mb in batches:
+            eng.load_state_dict(sd)
+            st = SISSStepper(eng, ac, lr=1e-4, betas=(0.95, 0.999), weight_decay=1e-6, scaling_norm=5.0, lambd=0.5,
+                             train_batch_size=4, loss_fn=loss_fn, mixed_precision=None, superfactor=3.0)
+            eng.ps.grads.fill_(float("nan"))
+            st.step(mb["x0"], mb["a0"], mb["noise"], mb["t"].cuda(), mb["u"])
+            out.append(eng.ps.grads.clone())
+        return out
+
+    try:
+        full = run(False)
+        got = run(True)
+        (plan,) = eng._fill_plans.values()
+        assert plan["skipped_bytes"] > 0
+        for i, (ga, gb) in enumerate(zip(full, got)):
+            assert torch.isfinite(gb).all(), i
+            torch.testing.assert_close(gb, ga, rtol=1e-3, atol=1e-6 * float(ga.abs().max()))
+            if loss_fn == "naive_del":
+                assert float(gb[1].abs().max()) == 0.0, i        # the set nobody writes
+    finally:
+        eng.sparse_fill, eng.sparse_min_floats = True, 16384
+        eng._fill_plans.clear()
