@@ -261,7 +261,7 @@ class UNetEngine:
         self._side, self._side_busy, self._side_held, self._side_release, self._side_mark = None, False, {}, [], None
         self._side_phase = False
         self._prep_pending, self._wT_stale = False, False
-        self._fill_key, self._fill_plan, self._fill_plans = None, None, {}
+        self._fill_key, self._fill_plan, self._fill_plans, self._fill_tables = None, None, {}, []
         self._up_w = {}
 
     # ------------------------------------------------------------------ parameters
@@ -1570,8 +1570,9 @@ class UNetEngine:
         pre = [0]
         for n in lens:
             pre.append(pre[-1] + n)
-        self._fill_plans[key] = dict(stretches=got, n=len(starts), granules=pre[-1],
-                                     table=torch.tensor(starts + pre, dtype=torch.int64, device=self.device),
+        table = torch.tensor(starts + pre, dtype=torch.int64, device=self.device)
+        self._fill_tables.append(table)                    # never freed: a captured step may hold its address (a few KB per key)
+        self._fill_plans[key] = dict(stretches=got, n=len(starts), granules=pre[-1], table=table,
                                      skipped_bytes=16 * (total // 4 - pre[-1]))
 
     def backward(self, cot, nsets=2, grad_base_set=0):
